@@ -1,0 +1,125 @@
+/* seg3d_hip.h -- C ABI of libseg3d_hip.so, the MI355X (gfx950) engine behind the segmentation3d plugin API.
+ *
+ * The reference (qinliuliuqin/Medical-Segmentation3d-Toolkit) has no native boundary: its hot path bottoms out in
+ * torch.nn modules.  Each entry point below names the reference call site (file:line under
+ * /root/reference/segmentation3d) whose arithmetic it replaces.  The Python host binds these with ctypes
+ * (medical-segmentation3d-toolkit_amd/segmentation3d/_engine.py); INTEGRATION.md shows the stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed, e.g. torch.Tensor.data_ptr()) unless noted "host";
+ *   - activations are fp32 NDHWC: element (n, z, y, x, c) at (((n*D + z)*H + y)*W + x)*C + c;
+ *     probabilities / targets at the plugin API edge are fp32 NCDHW planar ([N][C][S], S = D*H*W);
+ *   - weights are passed in the reference layouts (Conv3d [Cout][Cin][k][k][k], ConvTranspose3d [Cin][Cout][k][k][k])
+ *     and re-packed on device by seg3d_pack_weights_*;
+ *   - `stream` is a hipStream_t (0 = default stream); all work is enqueued on it, nothing synchronises;
+ *   - the caller owns every buffer including workspaces (sizes via the *_count / *_floats / *_blocks helpers);
+ *     the library keeps no mutable global state, so every call is safe under hipGraph stream capture;
+ *   - return value: 0 = ok, <0 = error (SEG3D_ERR_*), message via seg3d_last_error() (thread-local).
+ */
+#ifndef SEG3D_HIP_H
+#define SEG3D_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEG3D_ABI_VERSION 1
+
+/* ---- library ------------------------------------------------------------------------------------------------ */
+const char* seg3d_last_error(void);
+int seg3d_abi_version(void);
+const char* seg3d_target_arch(void);
+int seg3d_device_count(void);
+
+/* ---- layout bridges (utils/image_tools.py:274-326 convert_image_to_tensor / convert_tensor_to_image define the
+ *      NCDHW <-> (x,y,z) contract; torch.cat((up, skip), 1) at network/module/vnet_upblock.py:21) ------------------ */
+int seg3d_ncdhw_to_ndhwc(const float* in, float* out, int N, int C, long long S, void* stream);
+int seg3d_ndhwc_to_ncdhw(const float* in, float* out, int N, int C, long long S, void* stream);
+int seg3d_copy_channels(const float* src, float* dst, long long nvox, int C, int src_ld, int src_off, int dst_ld,
+                        int dst_off, void* stream);
+
+/* ---- weight packers: W(a, b, t) = w[a*sa + b*sb + t], a = reduction channel, b = output channel, t = tap ---------- */
+int seg3d_pack_weights_tapmajor(const float* w, float* wp, int A, int B, int BP, int T, long long sa, long long sb,
+                                int flip, void* stream);
+int seg3d_pack_weights_mfma(const float* w, float* wp, int A, int B, int T, long long sa, long long sb, int flip,
+                            void* stream);
+long long seg3d_packed_mfma_floats(int A, int B, int T);
+
+/* ---- convolutions ---------------------------------------------------------------------------------------------
+ * nn.Conv3d k3 s1 p1  : network/module/conv_gn_relu3.py:10, vnet_inblock.py:9, vnet_outblock.py:13
+ * nn.Conv3d k2 s2     : network/module/vnet_downblock.py:11
+ * nn.Conv3d k1        : network/module/vnet_outblock.py:16
+ * nn.ConvTranspose3d k2 s2 : network/module/vnet_upblock.py:11
+ * Backward (autograd of the above, core/seg_train.py:124): dgrad = the adjoint op with re-packed weights
+ * (k3: same kernel, flipped taps; k2s2 <-> convT), wgrad = seg3d_*_wgrad. */
+int seg3d_conv3d_fwd_direct(const float* x, const float* wp_tapmajor, const float* bias, float* y, int N, int Di, int Hi,
+                            int Wi, int Cin, int Cout, int ksize, int stride, void* stream);
+int seg3d_convT3d_k2s2_fwd_direct(const float* x, const float* wp_tapmajor, const float* bias, float* y, int N, int Di,
+                                  int Hi, int Wi, int Cin, int Cout, void* stream);
+long long seg3d_wgrad_direct_workspace_floats(int N, int Dq, int Hq, int Wq, int CA, int CB, int ntaps);
+int seg3d_wgrad_direct(const float* P, const float* Q, float* part, int N, int Dp, int Hp, int Wp, int CA, int CB,
+                       int ksize, int stride, int* n_chunks_out /* host */, void* stream);
+int seg3d_wgrad_reduce(const float* part, float* dw, int chunks, int T, int A, int B, long long sa, long long sb,
+                       void* stream);
+
+/* fp32 MFMA implicit-GEMM path for k3 s1 p1 with Cin % 4 == 0 (the FLOP-dominant C->C layers) */
+long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W, int Cout);
+int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp_mfma, const float* bias, float* y, float* stats_partial,
+                             int N, int D, int H, int W, int Cin, int Cout, void* stream);
+long long seg3d_conv3d_k3_mfma_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H, int W,
+                               int Cin, int Cout, void* stream);
+
+/* ---- GroupNorm(1, C) [+ ReLU] [+ residual]  (network/module/conv_gn_relu3.py:11,14; residual_block3.py:24,46) ------ */
+long long seg3d_gn_stats_count(long long M);
+int seg3d_gn_stats_partial(const float* y, float* part, int N, long long M, void* stream);
+int seg3d_gn_stats_finalize(const float* part, float* mean_rstd, int N, int count, long long M, float eps, void* stream);
+int seg3d_gn_apply(const float* y, const float* mean_rstd, const float* gamma, const float* beta, const float* res,
+                   float* out, int N, long long S, int C, int relu, void* stream);
+long long seg3d_gn_bwd_blocks(long long S);
+int seg3d_gn_bwd_reduce(const float* dout, const float* out, const float* y, const float* mean_rstd, float* part, int N,
+                        long long S, int C, int relu, void* stream);
+int seg3d_gn_bwd_finalize(const float* part, const float* gamma, const float* mean_rstd, float* abx, float* s12,
+                          float* dgamma, float* dbeta, float* dbias, int N, long long S, int C, void* stream);
+int seg3d_gn_bwd_apply(const float* dout, const float* out, const float* y, const float* mean_rstd, const float* s12,
+                       const float* gamma, float* dy, float* dres, int N, long long S, int C, int relu, void* stream);
+
+/* ---- head softmax (network/module/vnet_outblock.py:18,23) ---------------------------------------------------------- */
+int seg3d_softmax_fwd(const float* in_ndhwc, float* probs_ncdhw, int N, int C, long long S, void* stream);
+int seg3d_softmax_bwd(const float* probs_ncdhw, const float* dprobs_ncdhw, float* din_ndhwc, int N, int C, long long S,
+                      void* stream);
+
+/* ---- losses: MultiDiceLoss (loss/multi_dice_loss.py:24-43 + loss/binary_dice_loss.py:9-36),
+ *              FocalLoss (loss/focal_loss.py:27-61) ------------------------------------------------------------------ */
+long long seg3d_dice_blocks(long long S);
+int seg3d_dice_fwd(const float* probs, const float* target, const float* weights, float* part, float* sums, float* loss,
+                   int N, int C, long long S, void* stream);
+int seg3d_dice_bwd(const float* probs, const float* target, const float* sums, const float* weights, const float* gout,
+                   float* dprobs, int N, int C, long long S, void* stream);
+long long seg3d_focal_blocks(long long total_vox);
+int seg3d_focal_fwd(const float* probs, const float* target, const float* alpha, float* part, float* loss, int N, int C,
+                    long long S, long long sn, long long sc, long long ss, float gamma, int size_average, void* stream);
+int seg3d_focal_bwd(const float* probs, const float* target, const float* alpha, const float* gout, float* dprobs, int N,
+                    int C, long long S, long long sn, long long sc, long long ss, float gamma, int size_average,
+                    void* stream);
+
+/* ---- optimizer: optim.Adam(...).step()  (core/seg_train.py:83,127) -------------------------------------------------- */
+int seg3d_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+/* ---- sliding-window batcher (core/seg_infer.py:208-246, 313-327, 336-339; utils/image_tools.py:435-469;
+ *      utils/normalizer.py:6-81) ---------------------------------------------------------------------------------- */
+long long seg3d_patch_stats_blocks(int bx, int by, int bz);
+int seg3d_patch_gather_normalize(const float* volume, const int* starts_xyz, float* batch, double* workspace,
+                                 float* mean_std, int Z, int Y, int X, int bx, int by, int bz, int P, int normalizer_type,
+                                 float mean, float stddev, int clip, float clip_sigma, void* stream);
+int seg3d_patch_scatter_accumulate(const float* probs, const int* starts_xyz, float* acc, float* count, int Z, int Y,
+                                   int X, int bx, int by, int bz, int P, int C, int lox, int loy, int loz, int ex, int ey,
+                                   int ez, void* stream);
+int seg3d_finalize_argmax(float* acc, const float* count, signed char* mask, int C, long long voxels, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEG3D_HIP_H */

@@ -1,0 +1,75 @@
+"""Build libseg3d_hip.so (gfx950) in-tree with hipcc.  No cmake, no JIT cache: the .so lands next to the sources
+(`medical-segmentation3d-toolkit_amd/lib/`) so it travels to the GPU box with the repo snapshot.
+
+Usage:  python medical-segmentation3d-toolkit_amd/build_native.py [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(REPO, 'include')
+OBJ_DIR = os.path.join(HERE, 'build')
+LIB_DIR = os.path.join(HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libseg3d_hip.so')
+
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-I', INCLUDE, '-I', CSRC,
+         '-Wall', '-Wno-unused-function', '-ffp-contract=off']
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip') or f.endswith('.cpp'))
+
+
+def _newest_header_mtime():
+    m = 0.0
+    for d in (CSRC, INCLUDE):
+        for f in os.listdir(d):
+            if f.endswith('.h'):
+                m = max(m, os.path.getmtime(os.path.join(d, f)))
+    return m
+
+
+def _compile(src, force, hdr_mtime):
+    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + '.o')
+    path = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(path)
+            and os.path.getmtime(obj) > hdr_mtime):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', path, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for {}:\n{}\n{}'.format(src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hdr = _newest_header_mtime()
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, hdr), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(c for _, c in results)
+    if rebuilt or not os.path.exists(LIB_PATH):
+        cmd = [HIPCC, '-shared', '-fPIC', '--offload-arch=' + ARCH] + objs + ['-o', LIB_PATH]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n{}\n{}'.format(r.stdout, r.stderr))
+        if verbose:
+            print('built', LIB_PATH)
+    elif verbose:
+        print('up to date', LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

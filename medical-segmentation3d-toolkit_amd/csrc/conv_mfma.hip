@@ -1,0 +1,458 @@
+// conv_mfma.hip -- 3x3x3 stride-1 pad-1 convolution (forward, data-gradient, weight-gradient) as an
+// implicit GEMM on the CDNA4 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// These are the layers that hold 99 % of the V-Net FLOPs (every C->C k3 conv with
+// C >= 16, reference call sites network/module/conv_gn_relu3.py:10, residual_block3.py:13-16). In fp32 they
+// are FLOP-bound (arithmetic intensity 216..1152 FLOP/B vs. a ridge of ~20), so the roof is the fp32 MFMA
+// peak of 157.3 TFLOP/s, not HBM.
+//
+// Forward / dgrad  (conv3d_k3_mfma_kernel)
+//   GEMM view: M = voxels, N = Cout, K = 27 taps x Cin.  A workgroup (4 waves) owns one spatial tile
+//   TZ x TY x TX of output voxels and one block of 32 output channels.  The input tile with its 1-voxel halo
+//   is staged in LDS 8 input channels at a time as [half][halo voxel][4 floats] so that a lane's A operands
+//   for 4 consecutive MFMAs come from ONE ds_read_b128; the matching weight chunk [27][half][32][4] is a
+//   straight copy of the packed weights (layout.hip: pack_mfma_kernel).  MFMA r of a group takes
+//   k = {r, 4 + r} of the 8-channel chunk (lanes 0-31 / 32-63), which both operands agree on.
+//   Each wave keeps MA accumulators (32 voxels x 32 channels each).  Zero padding = zeros written to LDS.
+//   dgrad is the same kernel run on dy with flipped / transposed weights (pack with flip = 1).
+//   The epilogue adds the bias and emits the per-workgroup (sum, sum of squares) that GroupNorm(1, C)
+//   needs (conv_gn_relu3.py:11), so the statistics cost no extra pass over y.
+//
+// Weight gradient (conv3d_k3_wgrad_mfma_kernel)
+//   GEMM view: M = Cin (32 block), N = Cout (32 block), K = voxels; one accumulator per tap.  A workgroup owns
+//   one (ci block, co block) pair and walks a strided share of the spatial tiles; wave w owns taps 7w..7w+6.
+//   A = x[v + tap][ci] and B = dy[v][co] are single ds_read_b32 per lane (lanes 0-31: voxel 2k, 32-63: 2k+1).
+//   Partial slabs are reduced in fixed order by conv3d_k3_wgrad_reduce_kernel (bitwise reproducible).
+#include "seg3d_common.h"
+#include "seg3d_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SEG3D_MAXE 10          // float4 input-tile loads per thread per K-chunk  (2 * NV <= 2560)
+#define SEG3D_W_CHUNK 6912     // 27 * 2 * 32 * 4 floats
+
+__device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+template <int MA>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ stats, int N, int D, int H, int W, int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
+    int ntx) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HY = TY + 2, HX = TX + 2;
+  const int NV = (TZ + 2) * HY * HX;
+  const int MT = TZ * TY * TX;
+  float* xs = lds;                                   // [2][NV][4]
+  float* ws = lds + 8 * NV;                          // [27][2][32][4]
+  int* voff = reinterpret_cast<int*>(ws + SEG3D_W_CHUNK);  // [MT] global voxel index or -1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int CIB = (Cin + 7) >> 3;
+  const int cob = blockIdx.y;
+
+  int b = blockIdx.x;
+  const int tix = b % ntx; b /= ntx;
+  const int tiy = b % nty; b /= nty;
+  const int tiz = b % ntz;
+  const int n = b / ntz;
+  const int z0 = tiz * TZ, y0 = tiy * TY, x0 = tix * TX;
+
+  // global offsets (in floats) of this thread's staged float4s; the voxel set is the same for every K-chunk
+  int goff[SEG3D_MAXE];
+  const int hh = tid & 1;
+#pragma unroll
+  for (int e = 0; e < SEG3D_MAXE; ++e) {
+    const int eidx = tid + e * 256;
+    goff[e] = -1;
+    if (eidx < 2 * NV) {
+      const int v = eidx >> 1;
+      const int hx = v % HX;
+      const int t = v / HX;
+      const int hy = t % HY;
+      const int hz = t / HY;
+      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+      if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        goff[e] = (((n * D + gz) * H + gy) * W + gx) * Cin + hh * 4;
+    }
+  }
+  for (int idx = tid; idx < MT; idx += 256) {
+    const int tx = idx % TX;
+    const int t = idx / TX;
+    const int ty = t % TY;
+    const int tz = t / TY;
+    const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
+    voff[idx] = (gz < D && gy < H && gx < W) ? ((n * D + gz) * H + gy) * W + gx : -1;
+  }
+  // LDS base (in floats) of each of this lane's A rows
+  int abase[MA];
+#pragma unroll
+  for (int m = 0; m < MA; ++m) {
+    const int idx = (wave + 4 * m) * 32 + li;
+    int vb = 0;
+    if (idx < MT) {
+      const int tx = idx % TX;
+      const int t = idx / TX;
+      const int ty = t % TY;
+      const int tz = t / TY;
+      vb = (tz * HY + ty) * HX + tx;
+    }
+    abase[m] = (lh * NV + vb) * 4;
+  }
+  const int bbase = (lh * 32 + li) * 4;
+
+  f32x16 acc[MA];
+#pragma unroll
+  for (int m = 0; m < MA; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  for (int cib = 0; cib < CIB; ++cib) {
+    __syncthreads();  // previous chunk fully consumed
+    const bool half_ok = cib * 8 + hh * 4 < Cin;
+#pragma unroll
+    for (int e = 0; e < SEG3D_MAXE; ++e) {
+      const int eidx = tid + e * 256;
+      if (eidx < 2 * NV) {
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (goff[e] >= 0 && half_ok) val = *reinterpret_cast<const f32x4*>(x + (i64)goff[e] + cib * 8);
+        *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) = val;
+      }
+    }
+    {
+      const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * SEG3D_W_CHUNK);
+      f32x4* wdst = reinterpret_cast<f32x4*>(ws);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int idx = tid + k * 256;
+        if (idx < SEG3D_W_CHUNK / 4) wdst[idx] = wsrc[idx];
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tap = (kz * 3 + ky) * 3 + kx;
+          const int tapoff = ((kz * HY + ky) * HX + kx) * 4;
+          const f32x4 bw = *reinterpret_cast<const f32x4*>(ws + tap * 256 + bbase);
+          f32x4 av[MA];
+#pragma unroll
+          for (int m = 0; m < MA; ++m) av[m] = *reinterpret_cast<const f32x4*>(xs + abase[m] + tapoff);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < MA; ++m)
+              acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][r], bw[r], acc[m], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, store, GroupNorm partial statistics ----
+  const int co = cob * 32 + li;
+  const bool co_ok = co < Cout;
+  const float bv = (bias && co_ok) ? bias[co] : 0.f;
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < MA; ++m) {
+    const int sub = wave + 4 * m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int idx = sub * 32 + mfma_row(r, lh);
+      if (idx < MT && co_ok) {
+        const int vo = voff[idx];
+        if (vo >= 0) {
+          const float val = acc[m][r] + bv;
+          y[(i64)vo * Cout + co] = val;
+          s[0] += val;
+          s[1] += val * val;
+        }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    block_sum_256<2>(s, xs);
+    if (tid == 0) {
+      const int tiles_per_sample = ntz * nty * ntx;
+      const int tile = (tiz * nty + tiy) * ntx + tix;
+      float* dst = stats + (((i64)n * tiles_per_sample + tile) * gridDim.y + cob) * 2;
+      dst[0] = s[0];
+      dst[1] = s[1];
+    }
+  }
+}
+
+struct Seg3dTile {
+  int tz, ty, tx;
+};
+
+// Pick the output tile for one level: at most 512 voxels (4 waves x 4 accumulators), halo tile <= 1280 voxels,
+// as few wasted (masked) voxels and as little halo as possible, and enough workgroups to fill 256 CUs.
+static Seg3dTile seg3d_pick_tile(int N, int D, int H, int W, int cout_blocks) {
+  const int cand_z[] = {1, 2, 3, 4, 6, 8};
+  const int cand_y[] = {2, 3, 4, 6, 8, 12, 16};
+  const int cand_x[] = {4, 6, 8, 12, 16, 24, 32};
+  Seg3dTile best = {1, 2, 4};
+  double best_cost = 1e30;
+  for (int tz : cand_z)
+    for (int ty : cand_y)
+      for (int tx : cand_x) {
+        if (tz > D && tz != 1) continue;
+        const int mt = tz * ty * tx;
+        if (mt > 512 || mt < 32) continue;
+        const int nv = (tz + 2) * (ty + 2) * (tx + 2);
+        if (2 * nv > SEG3D_MAXE * 256) continue;
+        const int ntz = seg3d_cdiv(D, tz), nty = seg3d_cdiv(H, ty), ntx = seg3d_cdiv(W, tx);
+        const double tiles = (double)N * ntz * nty * ntx;
+        const int subs = (mt + 31) / 32;
+        const int ma = (subs + 3) / 4;
+        // MFMA slots issued per tile (4 waves x ma) vs useful voxels
+        const double slots = tiles * 4.0 * ma * 32.0;
+        const double useful = (double)N * D * H * W;
+        double cost = slots / useful;                 // >= 1, MFMA waste
+        cost *= 1.0 + 0.08 * ((double)nv / mt - 1.0);  // halo staging overhead (mild)
+        const double wgs = tiles * cout_blocks;
+        if (wgs < 512.0) cost *= 1.0 + 0.5 * (512.0 - wgs) / 512.0;  // under-filled chip
+        if (cost < best_cost) {
+          best_cost = cost;
+          best = {tz, ty, tx};
+        }
+      }
+  return best;
+}
+
+static size_t seg3d_fwd_lds_bytes(const Seg3dTile& t) {
+  const int nv = (t.tz + 2) * (t.ty + 2) * (t.tx + 2);
+  const int mt = t.tz * t.ty * t.tx;
+  return (size_t)(8 * nv + SEG3D_W_CHUNK + ((mt + 3) & ~3)) * 4;
+}
+
+extern "C" long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W, int Cout) {
+  const int cob = (Cout + 31) / 32;
+  Seg3dTile t = seg3d_pick_tile(N, D, H, W, cob);
+  return (long long)seg3d_cdiv(D, t.tz) * seg3d_cdiv(H, t.ty) * seg3d_cdiv(W, t.tx) * cob;
+}
+
+template <int MA>
+static int launch_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
+                      int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s) {
+  const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
+  const size_t lds = seg3d_fwd_lds_bytes(t);
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma_kernel<MA>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) {
+      seg3d_set_error("conv3d_k3_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SEG3D_ERR_LAUNCH;
+    }
+    configured = 160 * 1024;
+  }
+  dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
+  hipLaunchKernelGGL((conv3d_k3_mfma_kernel<MA>), grid, dim3(256), lds, s, x, wp, bias, y, stats, N, D, H, W, Cin, Cout,
+                     t.tz, t.ty, t.tx, ntz, nty, ntx);
+  return SEG3D_OK;
+}
+
+// x [N][D][H][W][Cin], wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 27), y [N][D][H][W][Cout];
+// stats (optional): [N][seg3d_conv3d_k3_mfma_stats_count][2] partial (sum, sumsq) of y per sample.
+extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N,
+                                        int D, int H, int W, int Cin, int Cout, void* stream) {
+  SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_mfma_fwd: null pointer");
+  SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k3_mfma_fwd: bad dims");
+  SEG3D_REQUIRE((Cin % 4) == 0, "seg3d_conv3d_k3_mfma_fwd: Cin must be a multiple of 4 (got %d); use the direct kernel", Cin);
+  SEG3D_REQUIRE((i64)N * D * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31),
+                "seg3d_conv3d_k3_mfma_fwd: tensor exceeds 2^31 elements");
+  const int cob = (Cout + 31) / 32;
+  Seg3dTile t = seg3d_pick_tile(N, D, H, W, cob);
+  const int subs = (t.tz * t.ty * t.tx + 31) / 32;
+  const int ma = (subs + 3) / 4;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  switch (ma) {
+    case 1: rc = launch_fwd<1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s); break;
+    case 2: rc = launch_fwd<2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s); break;
+    case 3: rc = launch_fwd<3>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s); break;
+    case 4: rc = launch_fwd<4>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s); break;
+    default:
+      SEG3D_UNSUPPORTED("seg3d_conv3d_k3_mfma_fwd: internal tile error (ma=%d)", ma);
+  }
+  if (rc != SEG3D_OK) return rc;
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_fwd");
+  return SEG3D_OK;
+}
+
+// ================================================================================================================
+// weight gradient
+// ================================================================================================================
+#define SEG3D_WG_TZ 2
+#define SEG3D_WG_TY 4
+#define SEG3D_WG_TX 16
+#define SEG3D_WG_MT (SEG3D_WG_TZ * SEG3D_WG_TY * SEG3D_WG_TX)                           // 128 voxels
+#define SEG3D_WG_HY (SEG3D_WG_TY + 2)
+#define SEG3D_WG_HX (SEG3D_WG_TX + 2)
+#define SEG3D_WG_NV ((SEG3D_WG_TZ + 2) * SEG3D_WG_HY * SEG3D_WG_HX)                     // 432 halo voxels
+#define SEG3D_WG_XE ((SEG3D_WG_NV * 8 + 255) / 256)                                     // float4 per thread: 14
+#define SEG3D_WG_YE ((SEG3D_WG_MT * 8) / 256)                                           // 4
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const float* __restrict__ x,
+                                                                        const float* __restrict__ dy,
+                                                                        float* __restrict__ part, int N, int D, int H,
+                                                                        int W, int Cin, int Cout, int ntz, int nty,
+                                                                        int ntx, int ntiles, int COB32) {
+  __shared__ __attribute__((aligned(16))) float xs[SEG3D_WG_NV * 32];
+  __shared__ __attribute__((aligned(16))) float dys[SEG3D_WG_MT * 32];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int cib = blockIdx.y / COB32, cob = blockIdx.y % COB32;
+  const int ci0 = cib * 32, co0 = cob * 32;
+
+  int tapoff[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    int tap = wave * 7 + j;
+    if (tap > 26) tap = 26;  // idle slot of wave 3 recomputes tap 26 into a discarded accumulator
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    tapoff[j] = ((kz * SEG3D_WG_HY + ky) * SEG3D_WG_HX + kx) * 32;
+  }
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int q = tid & 7;  // float4 index inside the 32-channel row
+  const bool xq_ok = ci0 + 4 * q < Cin;
+  const bool yq_ok = co0 + 4 * q < Cout;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tix = b % ntx; b /= ntx;
+    const int tiy = b % nty; b /= nty;
+    const int tiz = b % ntz;
+    const int n = b / ntz;
+    const int z0 = tiz * SEG3D_WG_TZ, y0 = tiy * SEG3D_WG_TY, x0 = tix * SEG3D_WG_TX;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < SEG3D_WG_XE; ++e) {
+      const int eidx = tid + e * 256;
+      if (eidx < SEG3D_WG_NV * 8) {
+        const int v = eidx >> 3;
+        const int hx = v % SEG3D_WG_HX;
+        const int t = v / SEG3D_WG_HX;
+        const int hy = t % SEG3D_WG_HY;
+        const int hz = t / SEG3D_WG_HY;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (xq_ok && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+          val = *reinterpret_cast<const f32x4*>(x + ((((i64)n * D + gz) * H + gy) * W + gx) * Cin + ci0 + 4 * q);
+        *reinterpret_cast<f32x4*>(xs + v * 32 + 4 * q) = val;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < SEG3D_WG_YE; ++e) {
+      const int eidx = tid + e * 256;
+      const int v = eidx >> 3;
+      const int tx = v % SEG3D_WG_TX;
+      const int t = v / SEG3D_WG_TX;
+      const int ty = t % SEG3D_WG_TY;
+      const int tz = t / SEG3D_WG_TY;
+      const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (yq_ok && gz < D && gy < H && gx < W)
+        val = *reinterpret_cast<const f32x4*>(dy + ((((i64)n * D + gz) * H + gy) * W + gx) * Cout + co0 + 4 * q);
+      *reinterpret_cast<f32x4*>(dys + v * 32 + 4 * q) = val;
+    }
+    __syncthreads();
+
+#pragma unroll 4
+    for (int kp = 0; kp < SEG3D_WG_MT / 2; ++kp) {
+      const int v = 2 * kp + lh;
+      const int tx = v % SEG3D_WG_TX;
+      const int t = v / SEG3D_WG_TX;
+      const int ty = t % SEG3D_WG_TY;
+      const int tz = t / SEG3D_WG_TY;
+      const int base = ((tz * SEG3D_WG_HY + ty) * SEG3D_WG_HX + tx) * 32 + li;
+      const float bvv = dys[v * 32 + li];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const float a = xs[base + tapoff[j]];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // part[slab = blockIdx.x][pair = blockIdx.y][tap][ci row][co col]
+  float* dst = part + ((i64)blockIdx.x * gridDim.y + blockIdx.y) * 27 * 1024;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = wave * 7 + j;
+    if (tap < 27) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[tap * 1024 + mfma_row(r, lh) * 32 + li] = acc[j][r];
+    }
+  }
+}
+
+// dw[a*sa + b*sb + t] = sum_slab part[slab][a/32][b/32][t][a%32][b%32]   (a = ci, b = co)
+__global__ __launch_bounds__(256) void conv3d_k3_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                       float* __restrict__ dw, int slabs, int A, int B,
+                                                                       int COB32, int npairs, i64 sa, i64 sb) {
+  const i64 total = (i64)27 * A * B;
+  for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+    const int b = (int)(idx % B);
+    i64 r = idx / B;
+    const int a = (int)(r % A);
+    const int t = (int)(r / A);
+    const int pair = (a >> 5) * COB32 + (b >> 5);
+    const float* p = part + ((i64)pair * 27 + t) * 1024 + (a & 31) * 32 + (b & 31);
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += p[(i64)k * npairs * 27 * 1024];
+    dw[a * sa + b * sb + t] = s;
+  }
+}
+
+static int seg3d_wgrad_slabs(int N, int D, int H, int W, int npairs) {
+  const int ntiles = N * seg3d_cdiv(D, SEG3D_WG_TZ) * seg3d_cdiv(H, SEG3D_WG_TY) * seg3d_cdiv(W, SEG3D_WG_TX);
+  int slabs = 1024 / npairs;
+  if (slabs < 1) slabs = 1;
+  if (slabs > ntiles) slabs = ntiles;
+  return slabs;
+}
+
+extern "C" long long seg3d_conv3d_k3_mfma_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
+  const int npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
+  return (long long)seg3d_wgrad_slabs(N, D, H, W, npairs) * npairs * 27 * 1024;
+}
+
+// dw is written in the reference Conv3d layout [Cout][Cin][3][3][3]  (sa = 27 for ci, sb = Cin*27 for co).
+extern "C" int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D,
+                                          int H, int W, int Cin, int Cout, void* stream) {
+  SEG3D_REQUIRE(x && dy && dw && workspace, "seg3d_conv3d_k3_mfma_wgrad: null pointer");
+  SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k3_mfma_wgrad: bad dims");
+  SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
+                "seg3d_conv3d_k3_mfma_wgrad: Cin and Cout must be multiples of 4 (got %d, %d)", Cin, Cout);
+  const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
+  const int npairs = CIB32 * COB32;
+  const int ntz = seg3d_cdiv(D, SEG3D_WG_TZ), nty = seg3d_cdiv(H, SEG3D_WG_TY), ntx = seg3d_cdiv(W, SEG3D_WG_TX);
+  const int ntiles = N * ntz * nty * ntx;
+  const int slabs = seg3d_wgrad_slabs(N, D, H, W, npairs);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv3d_k3_wgrad_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s, x, dy, workspace, N, D, H, W, Cin,
+                     Cout, ntz, nty, ntx, ntiles, COB32);
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_wgrad");
+  const i64 total = (i64)27 * Cin * Cout;
+  hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, s, workspace, dw, slabs,
+                     Cin, Cout, COB32, npairs, (i64)27, (i64)Cin * 27);
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_wgrad(reduce)");
+  return SEG3D_OK;
+}

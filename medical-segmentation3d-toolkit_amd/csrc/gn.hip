@@ -1,0 +1,411 @@
+// gn.hip -- GroupNorm(1, C) (+ ReLU, + residual add) forward and backward on NDHWC fp32 tensors.
+//
+// Reference semantics: nn.GroupNorm(1, C), eps 1e-5, affine, i.e. per-sample LayerNorm over C*D*H*W elements
+// (network/module/conv_gn_relu3.py:11, vnet_inblock.py:10, vnet_downblock.py:12, vnet_upblock.py:12,
+// vnet_outblock.py:14,17), followed by ReLU (conv_gn_relu3.py:14) and, at the end of a residual block,
+// ReLU(input + GN(conv)) (residual_block3.py:24,46).
+//
+// All kernels are HBM-bound streaming passes (16 B per lane).  Spatial reductions: per-thread fp32 partials over
+// <= a few thousand elements, wave64 shuffle reduction, one slot per workgroup, then an fp64 finalize in a fixed
+// order -- deterministic and accurate enough for the 1e-4 parity bar on 14.2 M-element samples.
+//
+// forward :  y (raw conv output) -> [stats partials] -> mean/rstd -> out = act(gamma*xhat + beta (+ res))
+// backward:  g = dout * [out > 0];  per (n, c): A = sum g, B = sum g*xhat, X = sum xhat
+//            dgamma = sum_n B, dbeta = sum_n A, s1_n = sum_c gamma A / M, s2_n = sum_c gamma B / M
+//            dy = rstd_n * (gamma_c g - s1_n - xhat s2_n),  dres = g
+//            dbias_c (of the producing conv) = sum_{n,s} dy = sum_n rstd_n (gamma_c A_nc - S s1_n - s2_n X_nc)
+#include "seg3d_common.h"
+#include "seg3d_hip.h"
+
+#define GN_STATS_CHUNK 16384  // elements per workgroup in the statistics pass
+
+// ---- statistics ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __restrict__ y, float* __restrict__ part,
+                                                                 i64 M, int nblk) {
+  __shared__ float red[8];
+  const int n = blockIdx.y;
+  const float* base = y + (i64)n * M;
+  const i64 e0 = (i64)blockIdx.x * GN_STATS_CHUNK;
+  i64 e1 = e0 + GN_STATS_CHUNK;
+  if (e1 > M) e1 = M;
+  float s[2] = {0.f, 0.f};
+  // the chunk start is a multiple of 4 floats; M*4 bytes per sample keeps 16-byte alignment when M % 4 == 0
+  if ((M & 3) == 0) {
+    for (i64 e = e0 + 4 * threadIdx.x; e < e1; e += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(base + e);
+      s[0] += (v.x + v.y) + (v.z + v.w);
+      s[1] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    for (i64 e = e0 + threadIdx.x; e < e1; e += 256) {
+      const float v = base[e];
+      s[0] += v;
+      s[1] += v * v;
+    }
+  }
+  block_sum_256<2>(s, red);
+  if (threadIdx.x == 0) {
+    part[((i64)n * nblk + blockIdx.x) * 2 + 0] = s[0];
+    part[((i64)n * nblk + blockIdx.x) * 2 + 1] = s[1];
+  }
+}
+
+// mean_rstd[n] = (mean, rstd) from `count` partial (sum, sumsq) pairs per sample; fp64, fixed order.
+__global__ __launch_bounds__(64) void gn_stats_finalize_kernel(const float* __restrict__ part,
+                                                                 float* __restrict__ mean_rstd, int count, double M,
+                                                                 double eps) {
+  const int n = blockIdx.x;
+  const float* p = part + (i64)n * count * 2;
+  double s = 0.0, ss = 0.0;
+  for (int k = threadIdx.x; k < count; k += 64) {
+    s += (double)p[2 * k];
+    ss += (double)p[2 * k + 1];
+  }
+  s = wave_sum_d(s);
+  ss = wave_sum_d(ss);
+  if (threadIdx.x == 0) {
+    const double mean = s / M;
+    double var = ss / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_rstd[2 * n + 0] = (float)mean;
+    mean_rstd[2 * n + 1] = (float)(1.0 / sqrt(var + eps));
+  }
+}
+
+extern "C" long long seg3d_gn_stats_count(long long M) { return (M + GN_STATS_CHUNK - 1) / GN_STATS_CHUNK; }
+
+// y [N][M] raw values -> part [N][seg3d_gn_stats_count(M)][2]
+extern "C" int seg3d_gn_stats_partial(const float* y, float* part, int N, long long M, void* stream) {
+  SEG3D_REQUIRE(y && part && N > 0 && M > 0, "seg3d_gn_stats_partial: bad arguments");
+  const int nblk = (int)seg3d_gn_stats_count(M);
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, y, part, (i64)M, nblk);
+  SEG3D_LAUNCH_CHECK("seg3d_gn_stats_partial");
+  return SEG3D_OK;
+}
+
+extern "C" int seg3d_gn_stats_finalize(const float* part, float* mean_rstd, int N, int count, long long M, float eps,
+                                       void* stream) {
+  SEG3D_REQUIRE(part && mean_rstd && N > 0 && count > 0 && M > 0, "seg3d_gn_stats_finalize: bad arguments");
+  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, part, mean_rstd, count,
+                     (double)M, (double)eps);
+  SEG3D_LAUNCH_CHECK("seg3d_gn_stats_finalize");
+  return SEG3D_OK;
+}
+
+// ---- apply: out = act(gamma*(y-mean)*rstd + beta (+ res)) -------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ res, float* __restrict__ out, i64 S,
+                                                         int C, i64 total_vox, int relu) {
+  if (VEC) {
+    const int CQ = C >> 2;
+    const i64 total = total_vox * CQ;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+      const i64 v = idx / CQ;
+      const int q = (int)(idx - v * CQ);
+      const int n = (int)(v / S);
+      const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
+      const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
+      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * q);
+      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * q);
+      float4 o;
+      o.x = (yv.x - mean) * rstd * g.x + b.x;
+      o.y = (yv.y - mean) * rstd * g.y + b.y;
+      o.z = (yv.z - mean) * rstd * g.z + b.z;
+      o.w = (yv.w - mean) * rstd * g.w + b.w;
+      if (res) {
+        const float4 rv = *reinterpret_cast<const float4*>(res + idx * 4);
+        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+      }
+      if (relu) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+      }
+      *reinterpret_cast<float4*>(out + idx * 4) = o;
+    }
+  } else {
+    const i64 total = total_vox * C;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+      const i64 v = idx / C;
+      const int c = (int)(idx - v * C);
+      const int n = (int)(v / S);
+      const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
+      float o = (y[idx] - mean) * rstd * gamma[c] + beta[c];
+      if (res) o += res[idx];
+      if (relu) o = fmaxf(o, 0.f);
+      out[idx] = o;
+    }
+  }
+}
+
+extern "C" int seg3d_gn_apply(const float* y, const float* mean_rstd, const float* gamma, const float* beta,
+                              const float* res, float* out, int N, long long S, int C, int relu, void* stream) {
+  SEG3D_REQUIRE(y && mean_rstd && gamma && beta && out && N > 0 && S > 0 && C > 0, "seg3d_gn_apply: bad arguments");
+  const i64 total_vox = (i64)N * S;
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 3) == 0) {
+    hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(seg3d_ew_grid(total_vox * (C / 4), 256)), dim3(256), 0, s, y, mean_rstd,
+                       gamma, beta, res, out, (i64)S, C, total_vox, relu);
+  } else {
+    hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(seg3d_ew_grid(total_vox * C, 256)), dim3(256), 0, s, y, mean_rstd,
+                       gamma, beta, res, out, (i64)S, C, total_vox, relu);
+  }
+  SEG3D_LAUNCH_CHECK("seg3d_gn_apply");
+  return SEG3D_OK;
+}
+
+// ---- backward reduce: per (n, c) partial A = sum g, B = sum g*xhat, X = sum xhat ---------------------------------
+#define GN_BWD_VPB 2048  // voxels per workgroup
+
+// fast path: C % 4 == 0 and (C/4) divides 256: thread = (channel quad, voxel lane)
+__global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __restrict__ dout,
+                                                                  const float* __restrict__ out,
+                                                                  const float* __restrict__ y,
+                                                                  const float* __restrict__ mean_rstd,
+                                                                  float* __restrict__ part, i64 S, int C, int nblk,
+                                                                  int relu) {
+  __shared__ float red[256 * 12];
+  const int n = blockIdx.y;
+  const int CQ = C >> 2, VL = 256 / CQ;
+  const int q = threadIdx.x % CQ, vl = threadIdx.x / CQ;
+  const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
+  const i64 s0 = (i64)blockIdx.x * GN_BWD_VPB;
+  i64 s1 = s0 + GN_BWD_VPB;
+  if (s1 > S) s1 = S;
+  float a[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0}, xx[4] = {0, 0, 0, 0};
+  for (i64 sv = s0 + vl; sv < s1; sv += VL) {
+    const i64 off = ((i64)n * S + sv) * C + 4 * q;
+    float4 g = *reinterpret_cast<const float4*>(dout + off);
+    const float4 yv = *reinterpret_cast<const float4*>(y + off);
+    if (relu) {
+      const float4 o = *reinterpret_cast<const float4*>(out + off);
+      g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+    }
+    const float x0 = (yv.x - mean) * rstd, x1 = (yv.y - mean) * rstd, x2 = (yv.z - mean) * rstd, x3 = (yv.w - mean) * rstd;
+    a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
+    bb[0] += g.x * x0; bb[1] += g.y * x1; bb[2] += g.z * x2; bb[3] += g.w * x3;
+    xx[0] += x0; xx[1] += x1; xx[2] += x2; xx[3] += x3;
+  }
+  float* r = red + threadIdx.x * 12;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { r[k] = a[k]; r[4 + k] = bb[k]; r[8 + k] = xx[k]; }
+  __syncthreads();
+  if (vl == 0) {
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = r[k];
+    for (int j = 1; j < VL; ++j) {
+      const float* o = red + (j * CQ + q) * 12;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[k] += o[k];
+    }
+    // part[n][blk][c][3]
+    float* dst = part + (((i64)n * nblk + blockIdx.x) * C + 4 * q) * 3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { dst[3 * k + 0] = acc[k]; dst[3 * k + 1] = acc[4 + k]; dst[3 * k + 2] = acc[8 + k]; }
+  }
+}
+
+// small-C path (C <= 16, e.g. the num_classes-channel head): thread = voxel, channels in registers
+#define GN_SMALLC 16
+__global__ __launch_bounds__(256) void gn_bwd_reduce_small_kernel(const float* __restrict__ dout,
+                                                                    const float* __restrict__ out,
+                                                                    const float* __restrict__ y,
+                                                                    const float* __restrict__ mean_rstd,
+                                                                    float* __restrict__ part, i64 S, int C, int nblk,
+                                                                    int relu) {
+  __shared__ float red[4 * 3];
+  const int n = blockIdx.y;
+  const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
+  const i64 s0 = (i64)blockIdx.x * GN_BWD_VPB;
+  i64 s1 = s0 + GN_BWD_VPB;
+  if (s1 > S) s1 = S;
+  float a[GN_SMALLC], bb[GN_SMALLC], xx[GN_SMALLC];
+#pragma unroll
+  for (int c = 0; c < GN_SMALLC; ++c) { a[c] = 0.f; bb[c] = 0.f; xx[c] = 0.f; }
+  for (i64 sv = s0 + threadIdx.x; sv < s1; sv += 256) {
+    const i64 off = ((i64)n * S + sv) * C;
+#pragma unroll
+    for (int c = 0; c < GN_SMALLC; ++c) {
+      if (c < C) {
+        float g = dout[off + c];
+        if (relu && !(out[off + c] > 0.f)) g = 0.f;
+        const float xh = (y[off + c] - mean) * rstd;
+        a[c] += g;
+        bb[c] += g * xh;
+        xx[c] += xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < GN_SMALLC; ++c) {
+    if (c < C) {  // uniform
+      float v[3] = {a[c], bb[c], xx[c]};
+      block_sum_256<3>(v, red);
+      if (threadIdx.x == 0) {
+        float* dst = part + (((i64)n * nblk + blockIdx.x) * C + c) * 3;
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+      }
+    }
+  }
+}
+
+extern "C" long long seg3d_gn_bwd_blocks(long long S) { return (S + GN_BWD_VPB - 1) / GN_BWD_VPB; }
+
+static bool gn_vec_ok(int C) { return (C & 3) == 0 && (C >> 2) <= 256 && (256 % (C >> 2)) == 0; }
+
+// part: [N][seg3d_gn_bwd_blocks(S)][C][3]
+extern "C" int seg3d_gn_bwd_reduce(const float* dout, const float* out, const float* y, const float* mean_rstd,
+                                   float* part, int N, long long S, int C, int relu, void* stream) {
+  SEG3D_REQUIRE(dout && y && mean_rstd && part && N > 0 && S > 0 && C > 0, "seg3d_gn_bwd_reduce: bad arguments");
+  SEG3D_REQUIRE(!relu || out, "seg3d_gn_bwd_reduce: relu mask needs the forward output");
+  const int nblk = (int)seg3d_gn_bwd_blocks(S);
+  hipStream_t s = (hipStream_t)stream;
+  if (gn_vec_ok(C)) {
+    hipLaunchKernelGGL(gn_bwd_reduce_vec_kernel, dim3(nblk, N), dim3(256), 0, s, dout, out, y, mean_rstd, part, (i64)S, C,
+                       nblk, relu);
+  } else if (C <= GN_SMALLC) {
+    hipLaunchKernelGGL(gn_bwd_reduce_small_kernel, dim3(nblk, N), dim3(256), 0, s, dout, out, y, mean_rstd, part, (i64)S,
+                       C, nblk, relu);
+  } else {
+    SEG3D_UNSUPPORTED("seg3d_gn_bwd_reduce: unsupported channel count %d (need C<=16 or C%%4==0 with C/4 | 256)", C);
+  }
+  SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_reduce");
+  return SEG3D_OK;
+}
+
+// finalize: one workgroup per sample sums the partial slabs (fp64), writes abx[n][c][3] and s12[n][2]
+__global__ __launch_bounds__(256) void gn_bwd_finalize_sample_kernel(const float* __restrict__ part,
+                                                                       const float* __restrict__ gamma,
+                                                                       float* __restrict__ abx, float* __restrict__ s12,
+                                                                       int C, int nblk, double M) {
+  __shared__ double red[2 * 4];
+  const int n = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double A = 0.0, B = 0.0, X = 0.0;
+    const float* p = part + ((i64)n * nblk * C + c) * 3;
+    for (int k = 0; k < nblk; ++k) {
+      A += (double)p[(i64)k * C * 3 + 0];
+      B += (double)p[(i64)k * C * 3 + 1];
+      X += (double)p[(i64)k * C * 3 + 2];
+    }
+    float* d = abx + ((i64)n * C + c) * 3;
+    d[0] = (float)A; d[1] = (float)B; d[2] = (float)X;
+    s1 += (double)gamma[c] * A;
+    s2 += (double)gamma[c] * B;
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s12[2 * n + 0] = (float)((red[0] + red[1] + red[2] + red[3]) / M);
+    s12[2 * n + 1] = (float)((red[4] + red[5] + red[6] + red[7]) / M);
+  }
+}
+
+// dgamma[c] = sum_n B, dbeta[c] = sum_n A, dbias[c] = sum_n rstd_n (gamma_c A - S s1_n - s2_n X)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_param_kernel(const float* __restrict__ abx,
+                                                                      const float* __restrict__ s12,
+                                                                      const float* __restrict__ mean_rstd,
+                                                                      const float* __restrict__ gamma,
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                      float* __restrict__ dbias, int N, int C, double S) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double dg = 0.0, db = 0.0, dc = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* d = abx + ((i64)n * C + c) * 3;
+    const double A = d[0], B = d[1], X = d[2];
+    dg += B;
+    db += A;
+    dc += (double)mean_rstd[2 * n + 1] * ((double)gamma[c] * A - S * (double)s12[2 * n] - (double)s12[2 * n + 1] * X);
+  }
+  dgamma[c] = (float)dg;
+  dbeta[c] = (float)db;
+  if (dbias) dbias[c] = (float)dc;
+}
+
+// abx: [N][C][3] scratch, s12: [N][2]
+extern "C" int seg3d_gn_bwd_finalize(const float* part, const float* gamma, const float* mean_rstd, float* abx, float* s12,
+                                     float* dgamma, float* dbeta, float* dbias, int N, long long S, int C, void* stream) {
+  SEG3D_REQUIRE(part && gamma && mean_rstd && abx && s12 && dgamma && dbeta && N > 0 && S > 0 && C > 0,
+                "seg3d_gn_bwd_finalize: bad arguments");
+  const int nblk = (int)seg3d_gn_bwd_blocks(S);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_bwd_finalize_sample_kernel, dim3(N), dim3(256), 0, s, part, gamma, abx, s12, C, nblk,
+                     (double)S * (double)C);
+  SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_finalize(sample)");
+  hipLaunchKernelGGL(gn_bwd_finalize_param_kernel, dim3(seg3d_cdiv(C, 256)), dim3(256), 0, s, abx, s12, mean_rstd, gamma,
+                     dgamma, dbeta, dbias, N, C, (double)S);
+  SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_finalize(param)");
+  return SEG3D_OK;
+}
+
+// ---- backward apply: dy = rstd (gamma g - s1 - xhat s2),  dres = g -----------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                             const float* __restrict__ y,
+                                                             const float* __restrict__ mean_rstd,
+                                                             const float* __restrict__ s12,
+                                                             const float* __restrict__ gamma, float* __restrict__ dy,
+                                                             float* __restrict__ dres, i64 S, int C, i64 total_vox,
+                                                             int relu) {
+  if (VEC) {
+    const int CQ = C >> 2;
+    const i64 total = total_vox * CQ;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+      const i64 v = idx / CQ;
+      const int q = (int)(idx - v * CQ);
+      const int n = (int)(v / S);
+      const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
+      const float s1 = s12[2 * n], s2 = s12[2 * n + 1];
+      float4 g = *reinterpret_cast<const float4*>(dout + idx * 4);
+      const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
+      const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * q);
+      if (relu) {
+        const float4 o = *reinterpret_cast<const float4*>(out + idx * 4);
+        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      float4 d;
+      d.x = rstd * (gm.x * g.x - s1 - (yv.x - mean) * rstd * s2);
+      d.y = rstd * (gm.y * g.y - s1 - (yv.y - mean) * rstd * s2);
+      d.z = rstd * (gm.z * g.z - s1 - (yv.z - mean) * rstd * s2);
+      d.w = rstd * (gm.w * g.w - s1 - (yv.w - mean) * rstd * s2);
+      *reinterpret_cast<float4*>(dy + idx * 4) = d;
+      if (dres) *reinterpret_cast<float4*>(dres + idx * 4) = g;
+    }
+  } else {
+    const i64 total = total_vox * C;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+      const i64 v = idx / C;
+      const int c = (int)(idx - v * C);
+      const int n = (int)(v / S);
+      const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
+      float g = dout[idx];
+      if (relu && !(out[idx] > 0.f)) g = 0.f;
+      dy[idx] = rstd * (gamma[c] * g - s12[2 * n] - (y[idx] - mean) * rstd * s12[2 * n + 1]);
+      if (dres) dres[idx] = g;
+    }
+  }
+}
+
+extern "C" int seg3d_gn_bwd_apply(const float* dout, const float* out, const float* y, const float* mean_rstd,
+                                  const float* s12, const float* gamma, float* dy, float* dres, int N, long long S, int C,
+                                  int relu, void* stream) {
+  SEG3D_REQUIRE(dout && y && mean_rstd && s12 && gamma && dy && N > 0 && S > 0 && C > 0, "seg3d_gn_bwd_apply: bad arguments");
+  SEG3D_REQUIRE(!relu || out, "seg3d_gn_bwd_apply: relu mask needs the forward output");
+  const i64 total_vox = (i64)N * S;
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 3) == 0) {
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), dim3(seg3d_ew_grid(total_vox * (C / 4), 256)), dim3(256), 0, s, dout, out,
+                       y, mean_rstd, s12, gamma, dy, dres, (i64)S, C, total_vox, relu);
+  } else {
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<false>), dim3(seg3d_ew_grid(total_vox * C, 256)), dim3(256), 0, s, dout, out, y,
+                       mean_rstd, s12, gamma, dy, dres, (i64)S, C, total_vox, relu);
+  }
+  SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_apply");
+  return SEG3D_OK;
+}

@@ -1,0 +1,152 @@
+// layout.hip -- NCDHW <-> NDHWC conversion, channel-slice copies and weight packers.
+//
+// The reference keeps tensors NCDHW (utils/image_tools.py:274-294 builds [C,z,y,x] from sitk arrays) and
+// conv weights as [Cout,Cin,kD,kH,kW] (ConvTranspose3d: [Cin,Cout,kD,kH,kW]; network/module/vnet_upblock.py:11).
+// The HIP engine computes in NDHWC with tap-major packed weights; these kernels are the bridges. They are
+// HBM-bound byte movers: one read + one write per element, 16-byte accesses on the contiguous side.
+#include "seg3d_common.h"
+#include "seg3d_hip.h"
+
+// ---- NCDHW -> NDHWC : out[n][s][c] = in[n][c][s] ------------------------------------------------
+// A 64(s) x 16(c)-ish LDS transpose would be the classic form; C is tiny here (1..5 at the API edge), so each
+// thread handles one voxel and loops over channels: reads are coalesced per channel plane, writes are C*4 B per lane.
+__global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               int C, i64 S, i64 total_vox) {
+  for (i64 v = (i64)blockIdx.x * 256 + threadIdx.x; v < total_vox; v += (i64)gridDim.x * 256) {
+    i64 n = v / S, s = v - n * S;
+    const float* src = in + n * C * S + s;
+    float* dst = out + v * C;
+    for (int c = 0; c < C; ++c) dst[c] = src[(i64)c * S];
+  }
+}
+
+__global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               int C, i64 S, i64 total_vox) {
+  for (i64 v = (i64)blockIdx.x * 256 + threadIdx.x; v < total_vox; v += (i64)gridDim.x * 256) {
+    i64 n = v / S, s = v - n * S;
+    const float* src = in + v * C;
+    float* dst = out + n * C * S + s;
+    for (int c = 0; c < C; ++c) dst[(i64)c * S] = src[c];
+  }
+}
+
+extern "C" int seg3d_ncdhw_to_ndhwc(const float* in, float* out, int N, int C, long long S, void* stream) {
+  SEG3D_REQUIRE(in && out && N > 0 && C > 0 && S > 0, "seg3d_ncdhw_to_ndhwc: bad arguments");
+  i64 total = (i64)N * S;
+  hipLaunchKernelGGL(ncdhw_to_ndhwc_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, C, (i64)S, total);
+  SEG3D_LAUNCH_CHECK("seg3d_ncdhw_to_ndhwc");
+  return SEG3D_OK;
+}
+
+extern "C" int seg3d_ndhwc_to_ncdhw(const float* in, float* out, int N, int C, long long S, void* stream) {
+  SEG3D_REQUIRE(in && out && N > 0 && C > 0 && S > 0, "seg3d_ndhwc_to_ncdhw: bad arguments");
+  i64 total = (i64)N * S;
+  hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, C, (i64)S, total);
+  SEG3D_LAUNCH_CHECK("seg3d_ndhwc_to_ncdhw");
+  return SEG3D_OK;
+}
+
+// ---- channel-slice copy: dst[v][dst_off + c] = src[v][src_off + c], c < C -----------------------
+// Used for torch.cat((up, skip), 1) (network/module/vnet_upblock.py:21) and its backward split.
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              i64 nvox, int C, int src_ld, int src_off, int dst_ld,
+                                                              int dst_off) {
+  if ((C & 3) == 0 && (src_ld & 3) == 0 && (dst_ld & 3) == 0 && (src_off & 3) == 0 && (dst_off & 3) == 0) {
+    const int CQ = C >> 2;
+    i64 total = nvox * CQ;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+      i64 v = idx / CQ;
+      int q = (int)(idx - v * CQ);
+      float4 t = *reinterpret_cast<const float4*>(src + v * src_ld + src_off + 4 * q);
+      *reinterpret_cast<float4*>(dst + v * dst_ld + dst_off + 4 * q) = t;
+    }
+  } else {
+    i64 total = nvox * C;
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+      i64 v = idx / C;
+      int c = (int)(idx - v * C);
+      dst[v * dst_ld + dst_off + c] = src[v * src_ld + src_off + c];
+    }
+  }
+}
+
+extern "C" int seg3d_copy_channels(const float* src, float* dst, long long nvox, int C, int src_ld, int src_off,
+                                   int dst_ld, int dst_off, void* stream) {
+  SEG3D_REQUIRE(src && dst && nvox > 0 && C > 0, "seg3d_copy_channels: bad arguments");
+  SEG3D_REQUIRE(src_off + C <= src_ld && dst_off + C <= dst_ld, "seg3d_copy_channels: slice exceeds row pitch");
+  i64 work = (i64)nvox * ((C & 3) ? C : C / 4);
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(seg3d_ew_grid(work, 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     (i64)nvox, C, src_ld, src_off, dst_ld, dst_off);
+  SEG3D_LAUNCH_CHECK("seg3d_copy_channels");
+  return SEG3D_OK;
+}
+
+// ---- weight packers ------------------------------------------------------------------------------
+// A weight tensor is described as W(a, b, t) = w[a*sa + b*sb + t] with a = reduction channel (A of them),
+// b = output channel (B of them), t = tap (T of them); `flip` reads tap T-1-t (dgrad of a 3x3x3 conv).
+//   Conv3d fwd      w[co][ci][t] : a=ci sa=T       b=co sb=Cin*T
+//   Conv3d k3 dgrad             : a=co sa=Cin*T   b=ci sb=T        flip=1
+//   ConvT fwd       w[ci][co][t] : a=ci sa=Cout*T  b=co sb=T
+// tap-major pack (direct kernels):  wp[t][a][bp]            bp padded to BP (multiple of 4), zeros beyond B
+__global__ __launch_bounds__(256) void pack_tapmajor_kernel(const float* __restrict__ w, float* __restrict__ wp, int A,
+                                                              int B, int BP, int T, i64 sa, i64 sb, int flip) {
+  i64 total = (i64)T * A * BP;
+  for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+    int b = (int)(idx % BP);
+    i64 r = idx / BP;
+    int a = (int)(r % A);
+    int t = (int)(r / A);
+    float v = 0.f;
+    if (b < B) v = w[a * sa + b * sb + (flip ? T - 1 - t : t)];
+    wp[idx] = v;
+  }
+}
+
+extern "C" int seg3d_pack_weights_tapmajor(const float* w, float* wp, int A, int B, int BP, int T, long long sa,
+                                           long long sb, int flip, void* stream) {
+  SEG3D_REQUIRE(w && wp && A > 0 && B > 0 && T > 0 && BP >= B && (BP % 4) == 0, "seg3d_pack_weights_tapmajor: bad arguments");
+  i64 total = (i64)T * A * BP;
+  hipLaunchKernelGGL(pack_tapmajor_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, A,
+                     B, BP, T, (i64)sa, (i64)sb, flip);
+  SEG3D_LAUNCH_CHECK("seg3d_pack_weights_tapmajor");
+  return SEG3D_OK;
+}
+
+// MFMA pack (conv_mfma.hip): wp[bb][ab][t][h][j][r] = W(a = ab*8 + h*4 + r, b = bb*32 + j, t), zero padded.
+// One (bb, ab) chunk = T*2*32*4 floats is exactly the LDS image a workgroup stages per K-chunk, so staging is
+// a straight 16-byte copy.
+__global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, float* __restrict__ wp, int A,
+                                                          int B, int AB, int BB, int T, i64 sa, i64 sb, int flip) {
+  i64 total = (i64)BB * AB * T * 256;
+  for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+    int r = (int)(idx & 3);
+    int j = (int)((idx >> 2) & 31);
+    int h = (int)((idx >> 7) & 1);
+    i64 rest = idx >> 8;
+    int t = (int)(rest % T);
+    rest /= T;
+    int ab = (int)(rest % AB);
+    int bb = (int)(rest / AB);
+    int a = ab * 8 + h * 4 + r, b = bb * 32 + j;
+    float v = 0.f;
+    if (a < A && b < B) v = w[a * sa + b * sb + (flip ? T - 1 - t : t)];
+    wp[idx] = v;
+  }
+}
+
+extern "C" int seg3d_pack_weights_mfma(const float* w, float* wp, int A, int B, int T, long long sa, long long sb,
+                                       int flip, void* stream) {
+  SEG3D_REQUIRE(w && wp && A > 0 && B > 0 && T > 0, "seg3d_pack_weights_mfma: bad arguments");
+  int AB = (A + 7) / 8, BB = (B + 31) / 32;
+  i64 total = (i64)BB * AB * T * 256;
+  hipLaunchKernelGGL(pack_mfma_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, A, B,
+                     AB, BB, T, (i64)sa, (i64)sb, flip);
+  SEG3D_LAUNCH_CHECK("seg3d_pack_weights_mfma");
+  return SEG3D_OK;
+}
+
+extern "C" long long seg3d_packed_mfma_floats(int A, int B, int T) {
+  return (long long)((B + 31) / 32) * ((A + 7) / 8) * T * 256;
+}

@@ -1,0 +1,84 @@
+// seg3d_common.h -- shared helpers for the gfx950 (MI355X / CDNA4) segmentation kernels.
+// All kernels in this library work on NDHWC fp32 activations ("voxel rows" of C floats) unless a
+// function says otherwise; see DESIGN.md for the HBM layout of every buffer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#define SEG3D_OK 0
+#define SEG3D_ERR_INVALID (-1)
+#define SEG3D_ERR_LAUNCH (-2)
+#define SEG3D_ERR_UNSUPPORTED (-3)
+
+// thread-local error string, read back through seg3d_last_error()
+void seg3d_set_error(const char* fmt, ...);
+
+#define SEG3D_REQUIRE(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      seg3d_set_error(__VA_ARGS__);         \
+      return SEG3D_ERR_INVALID;             \
+    }                                       \
+  } while (0)
+
+#define SEG3D_UNSUPPORTED(...)              \
+  do {                                      \
+    seg3d_set_error(__VA_ARGS__);           \
+    return SEG3D_ERR_UNSUPPORTED;           \
+  } while (0)
+
+#define SEG3D_LAUNCH_CHECK(name)                                                     \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      seg3d_set_error("%s: kernel launch failed: %s", name, hipGetErrorString(e__)); \
+      return SEG3D_ERR_LAUNCH;                                                       \
+    }                                                                                \
+  } while (0)
+
+typedef long long i64;
+
+static inline int seg3d_cdiv(i64 a, i64 b) { return (int)((a + b - 1) / b); }
+static inline int seg3d_round_up(int a, int b) { return ((a + b - 1) / b) * b; }
+
+// number of workgroups for a grid-stride elementwise kernel: enough to fill 256 CUs x 8 blocks
+static inline int seg3d_ew_grid(i64 work_items, int block) {
+  i64 g = (work_items + block - 1) / block;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#ifdef __HIPCC__
+// ---- wave64 / workgroup reductions -------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum NV values over a 256-thread workgroup. Result valid in thread 0. `red` must hold 4*NV floats.
+template <int NV>
+__device__ __forceinline__ void block_sum_256(float (&v)[NV], float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[wave * NV + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = red[k] + red[NV + k] + red[2 * NV + k] + red[3 * NV + k];
+  }
+}
+#endif

@@ -1,0 +1,138 @@
+"""ctypes binding of libseg3d_hip.so -- the only compute backend of this package.
+
+There is deliberately no CPU or eager-PyTorch fallback: if the shared library is missing or a tensor is not on a
+HIP device, the ops raise.  (The CPU restatement used to check results lives in /oracle and is test-only.)
+The C ABI is declared in include/seg3d_hip.h.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.environ.get('SEG3D_HIP_LIB', os.path.join(_PKG_ROOT, 'lib', 'libseg3d_hip.so'))
+
+_c_int, _c_ll, _c_f, _c_p = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); keep in sync with include/seg3d_hip.h (tests/test_abi.py checks every symbol)
+_SIGNATURES = {
+    'seg3d_last_error': (ctypes.c_char_p, []),
+    'seg3d_abi_version': (_c_int, []),
+    'seg3d_target_arch': (ctypes.c_char_p, []),
+    'seg3d_device_count': (_c_int, []),
+    'seg3d_ncdhw_to_ndhwc': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
+    'seg3d_ndhwc_to_ncdhw': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
+    'seg3d_copy_channels': (_c_int, [_c_p, _c_p, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    'seg3d_pack_weights_tapmajor': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p]),
+    'seg3d_pack_weights_mfma': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p]),
+    'seg3d_packed_mfma_floats': (_c_ll, [_c_int, _c_int, _c_int]),
+    'seg3d_conv3d_fwd_direct': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p]),
+    'seg3d_convT3d_k2s2_fwd_direct': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 6 + [_c_p]),
+    'seg3d_wgrad_direct_workspace_floats': (_c_ll, [_c_int] * 7),
+    'seg3d_wgrad_direct': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 8 + [ctypes.POINTER(_c_int), _c_p]),
+    'seg3d_wgrad_reduce': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p]),
+    'seg3d_conv3d_k3_mfma_stats_count': (_c_ll, [_c_int] * 5),
+    'seg3d_conv3d_k3_mfma_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
+    'seg3d_conv3d_k3_mfma_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
+    'seg3d_conv3d_k3_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_p]),
+    'seg3d_gn_stats_count': (_c_ll, [_c_ll]),
+    'seg3d_gn_stats_partial': (_c_int, [_c_p, _c_p, _c_int, _c_ll, _c_p]),
+    'seg3d_gn_stats_finalize': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
+    'seg3d_gn_apply': (_c_int, [_c_p] * 6 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
+    'seg3d_gn_bwd_blocks': (_c_ll, [_c_ll]),
+    'seg3d_gn_bwd_reduce': (_c_int, [_c_p] * 5 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
+    'seg3d_gn_bwd_finalize': (_c_int, [_c_p] * 8 + [_c_int, _c_ll, _c_int, _c_p]),
+    'seg3d_gn_bwd_apply': (_c_int, [_c_p] * 8 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
+    'seg3d_softmax_fwd': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
+    'seg3d_softmax_bwd': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
+    'seg3d_dice_blocks': (_c_ll, [_c_ll]),
+    'seg3d_dice_fwd': (_c_int, [_c_p] * 6 + [_c_int, _c_int, _c_ll, _c_p]),
+    'seg3d_dice_bwd': (_c_int, [_c_p] * 6 + [_c_int, _c_int, _c_ll, _c_p]),
+    'seg3d_focal_blocks': (_c_ll, [_c_ll]),
+    'seg3d_focal_fwd': (_c_int, [_c_p] * 5 + [_c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_f, _c_int, _c_p]),
+    'seg3d_focal_bwd': (_c_int, [_c_p] * 5 + [_c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_f, _c_int, _c_p]),
+    'seg3d_adam_step': (_c_int, [_c_p] * 4 + [_c_ll, _c_int] + [_c_f] * 6 + [_c_p]),
+    'seg3d_patch_stats_blocks': (_c_ll, [_c_int] * 3),
+    'seg3d_patch_gather_normalize': (_c_int, [_c_p] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_f, _c_p]),
+    'seg3d_patch_scatter_accumulate': (_c_int, [_c_p] * 4 + [_c_int] * 14 + [_c_p]),
+    'seg3d_finalize_argmax': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
+}
+
+_lib = None
+
+
+class Seg3dEngineError(RuntimeError):
+    pass
+
+
+def symbols():
+    """names of all bound C-ABI entry points"""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """load (once) and return the ctypes handle; raises if the HIP library has not been built"""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise Seg3dEngineError(
+                'libseg3d_hip.so not found at {} -- build it with `python __graft_entry__.py` '
+                '(segmentation3d has no CPU fallback)'.format(LIB_PATH))
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.seg3d_abi_version() != 1:
+            raise Seg3dEngineError('libseg3d_hip.so ABI version mismatch')
+        _lib = handle
+    return _lib
+
+
+def last_error():
+    return lib().seg3d_last_error().decode('utf-8', 'replace')
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream (so launches are captured by torch.cuda.graph and ordered with torch ops)"""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor):
+            raise TypeError('expected a torch.Tensor, got {}'.format(type(t)))
+        if not t.is_cuda:
+            raise Seg3dEngineError(
+                'segmentation3d HIP engine needs tensors on a ROCm device (got device={}); '
+                'there is no CPU path in this package'.format(t.device))
+        if t.dtype != torch.float32 and t.dtype not in (torch.int32, torch.int8, torch.float64):
+            raise TypeError('unsupported dtype {}'.format(t.dtype))
+
+
+def call(name, *args):
+    """invoke an int-returning entry point; raise with the library's message on failure"""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        msg = last_error()
+        if rc == -3:
+            raise NotImplementedError(msg)
+        if rc == -1:
+            raise ValueError(msg)
+        raise Seg3dEngineError('{} failed (code {}): {}'.format(name, rc, msg))
+    return rc
+
+
+def query(name, *args):
+    """invoke a size/count helper (returns a number)"""
+    return int(getattr(lib(), name)(*args))

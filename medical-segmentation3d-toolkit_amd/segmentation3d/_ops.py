@@ -1,0 +1,494 @@
+"""Autograd-visible operators of the HIP engine.
+
+Every operator here enqueues hand-written gfx950 kernels from libseg3d_hip.so on torch's current stream; torch is
+used for device memory (caching allocator), streams and the autograd graph only.  Activations travel between
+operators as *logical* NCDHW tensors whose memory is NDHWC (a permuted view of a contiguous [N,D,H,W,C] buffer), so
+module boundaries keep the reference's tensor shapes while the kernels see channels-last rows.
+
+Fused unit (the reference's `ConvGnRelu3`, network/module/conv_gn_relu3.py:4-20, and the GN+ReLU tails of
+InputBlock/DownBlock/UpBlock/OutputBlock):   out = act( GN_1(conv(x) + b) [+ residual] )
+"""
+import ctypes
+
+import torch
+
+from . import _engine as E
+
+GN_EPS = 1e-5  # nn.GroupNorm default (network/module/conv_gn_relu3.py:11)
+
+# conv kinds: (ksize, stride, ntaps, transposed)
+_KINDS = {'k3': (3, 1, 27, False), 'k2s2': (2, 2, 8, False), 'k1': (1, 1, 1, False), 'convT': (2, 2, 8, True)}
+
+# set to True to force the VALU kernels everywhere (used by tests to cross-check the MFMA path)
+FORCE_DIRECT = False
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# layout helpers
+# ------------------------------------------------------------------------------------------------------------------
+def to_ndhwc(x):
+    """logical NCDHW tensor -> contiguous [N,D,H,W,C] fp32 tensor (zero-copy when the memory is already NDHWC)"""
+    E.require_device(x)
+    if x.dim() != 5:
+        raise ValueError('expected a 5-D [N,C,D,H,W] tensor, got shape {}'.format(tuple(x.shape)))
+    if x.dtype != torch.float32:
+        raise TypeError('segmentation3d HIP engine computes in float32, got {}'.format(x.dtype))
+    xp = x.permute(0, 2, 3, 4, 1)
+    if xp.is_contiguous():
+        return xp
+    N, C, D, H, W = x.shape
+    xc = x.contiguous()
+    out = torch.empty((N, D, H, W, C), dtype=torch.float32, device=x.device)
+    E.call('seg3d_ncdhw_to_ndhwc', E.ptr(xc), E.ptr(out), N, C, D * H * W, E.stream_ptr())
+    return out
+
+
+def from_ndhwc(t):
+    """contiguous [N,D,H,W,C] -> logical NCDHW view (no copy)"""
+    return t.permute(0, 4, 1, 2, 3)
+
+
+def to_ncdhw_contiguous(t_ndhwc):
+    """[N,D,H,W,C] contiguous -> [N,C,D,H,W] contiguous via the HIP layout kernel"""
+    N, D, H, W, C = t_ndhwc.shape
+    out = torch.empty((N, C, D, H, W), dtype=torch.float32, device=t_ndhwc.device)
+    E.call('seg3d_ndhwc_to_ncdhw', E.ptr(t_ndhwc), E.ptr(out), N, C, D * H * W, E.stream_ptr())
+    return out
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# convolution primitives on NDHWC buffers (no autograd)
+# ------------------------------------------------------------------------------------------------------------------
+def _pack_tapmajor(w, A, B, T, sa, sb, flip=0):
+    BP = (B + 3) // 4 * 4
+    wp = _empty((T, A, BP), w)
+    E.call('seg3d_pack_weights_tapmajor', E.ptr(w), E.ptr(wp), A, B, BP, T, sa, sb, flip, E.stream_ptr())
+    return wp
+
+
+def _pack_mfma(w, A, B, T, sa, sb, flip=0):
+    n = E.query('seg3d_packed_mfma_floats', A, B, T)
+    wp = _empty((n,), w)
+    E.call('seg3d_pack_weights_mfma', E.ptr(w), E.ptr(wp), A, B, T, sa, sb, flip, E.stream_ptr())
+    return wp
+
+
+def _use_mfma(cin, cout):
+    """3x3x3 layers go to the matrix cores when both channel counts are MFMA-shaped (every C->C layer of vnet/vbnet)"""
+    return (not FORCE_DIRECT) and cin % 4 == 0 and cin >= 8 and cout >= 8
+
+
+def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats):
+    """y[v][b] = bias[b] + sum_{t,a} x[v + t - 1][a] W(a,b,t);  returns (y, stats_partial or None)"""
+    N, D, H, W_, Cin = xn.shape
+    assert Cin == A
+    y = _empty((N, D, H, W_, B), xn)
+    if _use_mfma(A, B):
+        wp = _pack_mfma(w, A, B, 27, sa, sb, flip)
+        stats = None
+        if want_stats:
+            cnt = E.query('seg3d_conv3d_k3_mfma_stats_count', N, D, H, W_, B)
+            stats = _empty((N, cnt, 2), xn)
+        E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
+               E.stream_ptr())
+        return y, stats
+    wp = _pack_tapmajor(w, A, B, 27, sa, sb, flip)
+    E.call('seg3d_conv3d_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, A, B, 3, 1, E.stream_ptr())
+    return y, None
+
+
+def conv_forward(xn, w, bias, kind, want_stats=False):
+    """xn: [N,D,H,W,Cin] contiguous; w in the reference layout; returns (y NDHWC, stats_partial or None)"""
+    ks, stride, T, transposed = _KINDS[kind]
+    N, D, H, W_, Cin = xn.shape
+    if kind == 'k3':
+        Cout = w.shape[0]
+        _check_w(w, (Cout, Cin, 3, 3, 3), kind)
+        return _conv_k3_generic(xn, w, bias, Cin, Cout, 27, Cin * 27, 0, want_stats)
+    if kind == 'k2s2':
+        Cout = w.shape[0]
+        _check_w(w, (Cout, Cin, 2, 2, 2), kind)
+        if D % 2 or H % 2 or W_ % 2:
+            raise ValueError('Conv3d k2 s2 needs even spatial dims, got {}'.format((D, H, W_)))
+        wp = _pack_tapmajor(w, Cin, Cout, 8, 8, Cin * 8)
+        y = _empty((N, D // 2, H // 2, W_ // 2, Cout), xn)
+        E.call('seg3d_conv3d_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout, 2, 2,
+               E.stream_ptr())
+        return y, None
+    if kind == 'k1':
+        Cout = w.shape[0]
+        _check_w(w, (Cout, Cin, 1, 1, 1), kind)
+        wp = _pack_tapmajor(w, Cin, Cout, 1, 1, Cin)
+        y = _empty((N, D, H, W_, Cout), xn)
+        E.call('seg3d_conv3d_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout, 1, 1,
+               E.stream_ptr())
+        return y, None
+    if kind == 'convT':
+        Cout = w.shape[1]
+        _check_w(w, (Cin, Cout, 2, 2, 2), kind)
+        wp = _pack_tapmajor(w, Cin, Cout, 8, Cout * 8, 8)
+        y = _empty((N, 2 * D, 2 * H, 2 * W_, Cout), xn)
+        E.call('seg3d_convT3d_k2s2_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout,
+               E.stream_ptr())
+        return y, None
+    raise ValueError('unknown conv kind {}'.format(kind))
+
+
+def _check_w(w, shape, kind):
+    if tuple(w.shape) != tuple(shape):
+        raise ValueError('weight shape {} does not match {} for conv kind {}'.format(tuple(w.shape), shape, kind))
+    if not w.is_contiguous():
+        raise ValueError('conv weights must be contiguous')
+
+
+def conv_dgrad(dyn, w, kind):
+    """gradient w.r.t. the conv input; dyn: [N,Do,Ho,Wo,Cout] contiguous"""
+    N, D, H, W_, _ = dyn.shape
+    if kind == 'k3':
+        Cout, Cin = w.shape[0], w.shape[1]
+        # dx[v][ci] = sum_{t',co} dy[v + t' - 1][co] w[co][ci][26 - t']
+        dx, _ = _conv_k3_generic(dyn, w, None, Cout, Cin, Cin * 27, 27, 1, False)
+        return dx
+    if kind == 'k2s2':
+        Cout, Cin = w.shape[0], w.shape[1]
+        # dx[2v + t][ci] = sum_co dy[v][co] w[co][ci][t]  == transposed conv of dy
+        wp = _pack_tapmajor(w, Cout, Cin, 8, Cin * 8, 8)
+        dx = _empty((N, 2 * D, 2 * H, 2 * W_, Cin), dyn)
+        E.call('seg3d_convT3d_k2s2_fwd_direct', E.ptr(dyn), E.ptr(wp), None, E.ptr(dx), N, D, H, W_, Cout, Cin,
+               E.stream_ptr())
+        return dx
+    if kind == 'k1':
+        Cout, Cin = w.shape[0], w.shape[1]
+        wp = _pack_tapmajor(w, Cout, Cin, 1, Cin, 1)
+        dx = _empty((N, D, H, W_, Cin), dyn)
+        E.call('seg3d_conv3d_fwd_direct', E.ptr(dyn), E.ptr(wp), None, E.ptr(dx), N, D, H, W_, Cout, Cin, 1, 1,
+               E.stream_ptr())
+        return dx
+    if kind == 'convT':
+        Cin, Cout = w.shape[0], w.shape[1]
+        # dx[i][ci] = sum_{t,co} dy[2i + t][co] w[ci][co][t]  == k2 s2 conv of dy
+        wp = _pack_tapmajor(w, Cout, Cin, 8, 8, Cout * 8)
+        dx = _empty((N, D // 2, H // 2, W_ // 2, Cin), dyn)
+        E.call('seg3d_conv3d_fwd_direct', E.ptr(dyn), E.ptr(wp), None, E.ptr(dx), N, D, H, W_, Cout, Cin, 2, 2,
+               E.stream_ptr())
+        return dx
+    raise ValueError('unknown conv kind {}'.format(kind))
+
+
+def _wgrad_direct(P, Q, CA, CB, ks, stride, T, out_shape, sa, sb):
+    N, Dp, Hp, Wp, _ = P.shape
+    _, Dq, Hq, Wq, _ = Q.shape
+    nfl = E.query('seg3d_wgrad_direct_workspace_floats', N, Dq, Hq, Wq, CA, CB, T)
+    part = _empty((nfl,), P)
+    chunks = ctypes.c_int(0)
+    E.call('seg3d_wgrad_direct', E.ptr(P), E.ptr(Q), E.ptr(part), N, Dp, Hp, Wp, CA, CB, ks, stride,
+           ctypes.byref(chunks), E.stream_ptr())
+    dw = _empty(out_shape, P)
+    E.call('seg3d_wgrad_reduce', E.ptr(part), E.ptr(dw), chunks.value, T, CA, CB, sa, sb, E.stream_ptr())
+    return dw
+
+
+def conv_wgrad(xn, dyn, w_shape, kind):
+    """gradient w.r.t. the weight, returned in the reference layout `w_shape`"""
+    N, D, H, W_, Cin_x = xn.shape
+    if kind == 'k3':
+        Cout, Cin = w_shape[0], w_shape[1]
+        if _use_mfma(Cin, Cout) and Cout % 4 == 0:
+            nfl = E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W_, Cin, Cout)
+            ws = _empty((nfl,), xn)
+            dw = _empty(w_shape, xn)
+            E.call('seg3d_conv3d_k3_mfma_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(dw), E.ptr(ws), N, D, H, W_, Cin, Cout,
+                   E.stream_ptr())
+            return dw
+        return _wgrad_direct(xn, dyn, Cin, Cout, 3, 1, 27, w_shape, 27, Cin * 27)
+    if kind == 'k2s2':
+        Cout, Cin = w_shape[0], w_shape[1]
+        return _wgrad_direct(xn, dyn, Cin, Cout, 2, 2, 8, w_shape, 8, Cin * 8)
+    if kind == 'k1':
+        Cout, Cin = w_shape[0], w_shape[1]
+        return _wgrad_direct(xn, dyn, Cin, Cout, 1, 1, 1, w_shape, 1, Cin)
+    if kind == 'convT':
+        Cin, Cout = w_shape[0], w_shape[1]
+        # dW(t, a=co, b=ci) = sum_i dy[2i + t][co] x[i][ci]  -> w[ci][co][t]
+        return _wgrad_direct(dyn, xn, Cout, Cin, 2, 2, 8, w_shape, 8, Cout * 8)
+    raise ValueError('unknown conv kind {}'.format(kind))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GroupNorm(1, C) primitives on NDHWC buffers (no autograd)
+# ------------------------------------------------------------------------------------------------------------------
+def gn_stats(yn, stats_partial=None, eps=GN_EPS):
+    """(mean, rstd) per sample over all C*D*H*W elements -> [N,2]"""
+    N = yn.shape[0]
+    M = yn[0].numel()
+    if stats_partial is None:
+        cnt = E.query('seg3d_gn_stats_count', M)
+        stats_partial = _empty((N, cnt, 2), yn)
+        E.call('seg3d_gn_stats_partial', E.ptr(yn), E.ptr(stats_partial), N, M, E.stream_ptr())
+    cnt = stats_partial.shape[1]
+    mean_rstd = _empty((N, 2), yn)
+    E.call('seg3d_gn_stats_finalize', E.ptr(stats_partial), E.ptr(mean_rstd), N, cnt, M, float(eps), E.stream_ptr())
+    return mean_rstd
+
+
+def gn_apply(yn, mean_rstd, gamma, beta, resn, relu):
+    N, D, H, W_, C = yn.shape
+    out = torch.empty_like(yn)
+    E.call('seg3d_gn_apply', E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta), E.ptr(resn), E.ptr(out), N,
+           D * H * W_, C, int(relu), E.stream_ptr())
+    return out
+
+
+def gn_backward(doutn, outn, yn, mean_rstd, gamma, relu, want_dres, want_dbias=True):
+    """returns (dy, dres or None, dgamma, dbeta, dbias or None)"""
+    N, D, H, W_, C = yn.shape
+    S = D * H * W_
+    nblk = E.query('seg3d_gn_bwd_blocks', S)
+    part = _empty((N, nblk, C, 3), yn)
+    E.call('seg3d_gn_bwd_reduce', E.ptr(doutn), E.ptr(outn if relu else None), E.ptr(yn), E.ptr(mean_rstd), E.ptr(part), N,
+           S, C, int(relu), E.stream_ptr())
+    abx = _empty((N, C, 3), yn)
+    s12 = _empty((N, 2), yn)
+    dgamma = _empty((C,), yn)
+    dbeta = _empty((C,), yn)
+    dbias = _empty((C,), yn) if want_dbias else None
+    E.call('seg3d_gn_bwd_finalize', E.ptr(part), E.ptr(gamma), E.ptr(mean_rstd), E.ptr(abx), E.ptr(s12), E.ptr(dgamma),
+           E.ptr(dbeta), E.ptr(dbias), N, S, C, E.stream_ptr())
+    dy = torch.empty_like(yn)
+    dres = torch.empty_like(yn) if want_dres else None
+    E.call('seg3d_gn_bwd_apply', E.ptr(doutn), E.ptr(outn if relu else None), E.ptr(yn), E.ptr(mean_rstd), E.ptr(s12),
+           E.ptr(gamma), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), E.stream_ptr())
+    return dy, dres, dgamma, dbeta, dbias
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# autograd functions
+# ------------------------------------------------------------------------------------------------------------------
+class ConvGnActFunction(torch.autograd.Function):
+    """out = act(GroupNorm_1(conv(x) + bias) [+ residual]); conv kind in {'k3','k2s2','k1','convT'}"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, residual, kind, relu, eps):
+        E.require_device(x, weight, bias, gamma, beta, residual)
+        xn = to_ndhwc(x)
+        w = weight.detach()
+        yn, partial = conv_forward(xn, w, None if bias is None else bias.detach(), kind, want_stats=True)
+        mean_rstd = gn_stats(yn, partial, eps)
+        resn = None
+        if residual is not None:
+            resn = to_ndhwc(residual)
+            if resn.shape != yn.shape:
+                raise ValueError('residual shape {} does not match conv output {}'.format(tuple(residual.shape),
+                                                                                          tuple(from_ndhwc(yn).shape)))
+        outn = gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), resn, relu)
+        ctx.kind, ctx.relu = kind, bool(relu)
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.w_shape = tuple(weight.shape)
+        ctx.save_for_backward(xn, w, gamma.detach(), yn, outn, mean_rstd)
+        return from_ndhwc(outn)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xn, w, gamma, yn, outn, mean_rstd = ctx.saved_tensors
+        dn = to_ndhwc(dout)
+        dy, dres, dgamma, dbeta, dbias = gn_backward(dn, outn, yn, mean_rstd, gamma, ctx.relu,
+                                                     want_dres=ctx.has_res and ctx.needs_input_grad[5],
+                                                     want_dbias=ctx.has_bias)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = from_ndhwc(conv_dgrad(dy, w, ctx.kind))
+        dw = conv_wgrad(xn, dy, ctx.w_shape, ctx.kind) if ctx.needs_input_grad[1] else None
+        return (dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta,
+                from_ndhwc(dres) if dres is not None else None, None, None, None)
+
+
+def conv_gn_act(x, weight, bias, gamma, beta, residual=None, kind='k3', relu=True, eps=GN_EPS):
+    return ConvGnActFunction.apply(x, weight, bias, gamma, beta, residual, kind, relu, eps)
+
+
+class ConvFunction(torch.autograd.Function):
+    """plain convolution + bias (nn.Conv3d / nn.ConvTranspose3d called on their own)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, kind):
+        E.require_device(x, weight, bias)
+        xn = to_ndhwc(x)
+        w = weight.detach()
+        yn, _ = conv_forward(xn, w, None if bias is None else bias.detach(), kind)
+        ctx.kind, ctx.has_bias, ctx.w_shape = kind, bias is not None, tuple(weight.shape)
+        ctx.save_for_backward(xn, w)
+        return from_ndhwc(yn)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xn, w = ctx.saved_tensors
+        dn = to_ndhwc(dout)
+        dx = from_ndhwc(conv_dgrad(dn, w, ctx.kind)) if ctx.needs_input_grad[0] else None
+        dw = conv_wgrad(xn, dn, ctx.w_shape, ctx.kind) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dn.reshape(-1, dn.shape[-1]).sum(0)  # plumbing-only path (bias of a bare conv); fused path uses gn_bwd
+        return dx, dw, db, None
+
+
+def conv(x, weight, bias, kind):
+    return ConvFunction.apply(x, weight, bias, kind)
+
+
+class GroupNormFunction(torch.autograd.Function):
+    """GroupNorm(1, C) [+ ReLU] on its own (nn.GroupNorm called outside the fused unit)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, relu, eps):
+        E.require_device(x, gamma, beta)
+        yn = to_ndhwc(x)
+        mean_rstd = gn_stats(yn, None, eps)
+        outn = gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), None, relu)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(yn, outn, mean_rstd, gamma.detach())
+        return from_ndhwc(outn)
+
+    @staticmethod
+    def backward(ctx, dout):
+        yn, outn, mean_rstd, gamma = ctx.saved_tensors
+        dn = to_ndhwc(dout)
+        dy, _, dgamma, dbeta, _ = gn_backward(dn, outn, yn, mean_rstd, gamma, ctx.relu, want_dres=False, want_dbias=False)
+        return from_ndhwc(dy), dgamma, dbeta, None, None
+
+
+def group_norm(x, gamma, beta, relu=False, eps=GN_EPS):
+    return GroupNormFunction.apply(x, gamma, beta, relu, eps)
+
+
+class CatChannelsFunction(torch.autograd.Function):
+    """torch.cat((a, b), 1) written straight into one NDHWC buffer (network/module/vnet_upblock.py:21)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        E.require_device(a, b)
+        an, bn = to_ndhwc(a), to_ndhwc(b)
+        if an.shape[:4] != bn.shape[:4]:
+            raise ValueError('cat: spatial shapes differ: {} vs {}'.format(tuple(a.shape), tuple(b.shape)))
+        N, D, H, W_, Ca = an.shape
+        Cb = bn.shape[4]
+        out = _empty((N, D, H, W_, Ca + Cb), an)
+        nvox = N * D * H * W_
+        E.call('seg3d_copy_channels', E.ptr(an), E.ptr(out), nvox, Ca, Ca, 0, Ca + Cb, 0, E.stream_ptr())
+        E.call('seg3d_copy_channels', E.ptr(bn), E.ptr(out), nvox, Cb, Cb, 0, Ca + Cb, Ca, E.stream_ptr())
+        ctx.ca, ctx.cb = Ca, Cb
+        return from_ndhwc(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dn = to_ndhwc(dout)
+        N, D, H, W_, C = dn.shape
+        nvox = N * D * H * W_
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            dan = _empty((N, D, H, W_, ctx.ca), dn)
+            E.call('seg3d_copy_channels', E.ptr(dn), E.ptr(dan), nvox, ctx.ca, C, 0, ctx.ca, 0, E.stream_ptr())
+            da = from_ndhwc(dan)
+        if ctx.needs_input_grad[1]:
+            dbn = _empty((N, D, H, W_, ctx.cb), dn)
+            E.call('seg3d_copy_channels', E.ptr(dn), E.ptr(dbn), nvox, ctx.cb, C, ctx.ca, ctx.cb, 0, E.stream_ptr())
+            db = from_ndhwc(dbn)
+        return da, db
+
+
+def cat_channels(a, b):
+    return CatChannelsFunction.apply(a, b)
+
+
+class SoftmaxFunction(torch.autograd.Function):
+    """nn.Softmax(dim=1); emits a contiguous NCDHW tensor (the plugin API's output layout)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        E.require_device(x)
+        xn = to_ndhwc(x)
+        N, D, H, W_, C = xn.shape
+        probs = _empty((N, C, D, H, W_), xn)
+        E.call('seg3d_softmax_fwd', E.ptr(xn), E.ptr(probs), N, C, D * H * W_, E.stream_ptr())
+        ctx.save_for_backward(probs)
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        (probs,) = ctx.saved_tensors
+        N, C, D, H, W_ = probs.shape
+        dp = dprobs.contiguous()
+        din = _empty((N, D, H, W_, C), probs)
+        E.call('seg3d_softmax_bwd', E.ptr(probs), E.ptr(dp), E.ptr(din), N, C, D * H * W_, E.stream_ptr())
+        return from_ndhwc(din)
+
+
+def softmax_channels(x):
+    return SoftmaxFunction.apply(x)
+
+
+class DiceLossFunction(torch.autograd.Function):
+    """MultiDiceLoss.forward (loss/multi_dice_loss.py:24-43) as one fused reduction + one elementwise backward"""
+
+    @staticmethod
+    def forward(ctx, probs, target, weights):
+        E.require_device(probs, target, weights)
+        p = probs.contiguous()
+        t = target.contiguous().float()
+        N, C = p.shape[0], p.shape[1]
+        S = p[0, 0].numel()
+        if t.numel() != N * S:
+            raise ValueError('target shape {} does not match input {}'.format(tuple(target.shape), tuple(probs.shape)))
+        nblk = E.query('seg3d_dice_blocks', S)
+        part = _empty((N, nblk, C, 3), p)
+        sums = _empty((N, C, 2), p)
+        loss = _empty((1,), p)
+        E.call('seg3d_dice_fwd', E.ptr(p), E.ptr(t), E.ptr(weights), E.ptr(part), E.ptr(sums), E.ptr(loss), N, C, S,
+               E.stream_ptr())
+        ctx.save_for_backward(p, t, sums, weights)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, t, sums, weights = ctx.saved_tensors
+        N, C = p.shape[0], p.shape[1]
+        S = p[0, 0].numel()
+        g = gout.contiguous().reshape(1).float()
+        dp = torch.empty_like(p)
+        E.call('seg3d_dice_bwd', E.ptr(p), E.ptr(t), E.ptr(sums), E.ptr(weights), E.ptr(g), E.ptr(dp), N, C, S,
+               E.stream_ptr())
+        return dp, None, None
+
+
+class FocalLossFunction(torch.autograd.Function):
+    """FocalLoss.forward (loss/focal_loss.py:27-61); probs viewed as [N][C][S] through strides (sn, sc, ss)"""
+
+    @staticmethod
+    def forward(ctx, probs, target, alpha, gamma, size_average, N, C, S, sn, sc, ss):
+        E.require_device(probs, target, alpha)
+        p = probs.contiguous()
+        t = target.contiguous().float()
+        total = N * S
+        if t.numel() != total:
+            raise ValueError('target has {} elements, expected {}'.format(t.numel(), total))
+        nblk = E.query('seg3d_focal_blocks', total)
+        part = _empty((nblk,), p)
+        loss = _empty((1,), p)
+        E.call('seg3d_focal_fwd', E.ptr(p), E.ptr(t), E.ptr(alpha), E.ptr(part), E.ptr(loss), N, C, S, sn, sc, ss,
+               float(gamma), int(bool(size_average)), E.stream_ptr())
+        ctx.save_for_backward(p, t, alpha)
+        ctx.cfg = (float(gamma), int(bool(size_average)), N, C, S, sn, sc, ss)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, t, alpha = ctx.saved_tensors
+        gamma, size_average, N, C, S, sn, sc, ss = ctx.cfg
+        g = gout.contiguous().reshape(1).float()
+        dp = torch.empty_like(p)
+        E.call('seg3d_focal_bwd', E.ptr(p), E.ptr(t), E.ptr(alpha), E.ptr(g), E.ptr(dp), N, C, S, sn, sc, ss, gamma,
+               size_average, E.stream_ptr())
+        return (dp,) + (None,) * 10

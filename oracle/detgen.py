@@ -1,0 +1,72 @@
+"""ORACLE helper -- deterministic, RNG-library-independent tensor generator.
+
+Golden fixtures hold only outputs; inputs and weights are regenerated from (seed, name) on both sides (the build
+container that imports the reference, and the GPU box that does not have it) with this counter-based generator, so
+58 MB of weights never need to be committed.  splitmix64 over the element index -> two uniforms -> Box-Muller normal.
+"""
+import hashlib
+
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    with np.errstate(over='ignore'):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        return z ^ (z >> np.uint64(31))
+
+
+def _key(seed, name):
+    h = hashlib.sha256('{}:{}'.format(seed, name).encode()).digest()
+    return np.uint64(int.from_bytes(h[:8], 'little'))
+
+
+def uniform(seed, name, shape):
+    """float64 uniforms in (0, 1)"""
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        bits = _splitmix64(idx * np.uint64(2) + _key(seed, name))
+    u = ((bits >> np.uint64(11)).astype(np.float64) + 0.5) / float(1 << 53)
+    return u.reshape(shape)
+
+
+def normal(seed, name, shape, std=1.0, mean=0.0):
+    """float32 normal(mean, std)"""
+    u1 = uniform(seed, name + '/u1', shape)
+    u2 = uniform(seed, name + '/u2', shape)
+    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return (mean + std * z).astype(np.float32)
+
+
+def labels(seed, name, shape, num_classes):
+    """float32 class ids in {0..C-1} with blocky structure (4x4x4 cells) so classes form blobs, ~uniform classes"""
+    shape = tuple(shape)
+    cells = tuple((s + 3) // 4 for s in shape[-3:])
+    u = uniform(seed, name, shape[:-3] + cells)
+    ids = np.minimum((u * num_classes).astype(np.int64), num_classes - 1)
+    for ax in (-3, -2, -1):
+        ids = np.repeat(ids, 4, axis=ax)
+    sl = tuple(slice(None) for _ in shape[:-3]) + tuple(slice(0, s) for s in shape[-3:])
+    return ids[sl].astype(np.float32)
+
+
+def state_dict_like(shapes, seed, gain_sqrt2=True):
+    """deterministic weights for a dict name -> shape: conv weights ~ kaiming-normal(fan_in), biases ~ N(0, 0.1),
+    GroupNorm weight ~ N(1, 0.1), GroupNorm bias ~ N(0, 0.1) (non-trivial affine so parity tests exercise it)"""
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        if name.endswith('.weight') and len(shape) == 5:
+            fan_in = shape[1] * int(np.prod(shape[2:]))
+            std = (2.0 ** 0.5 if gain_sqrt2 else 1.0) / np.sqrt(fan_in)
+            out[name] = normal(seed, name, shape, std=std)
+        elif name.endswith('.weight'):
+            out[name] = normal(seed, name, shape, std=0.1, mean=1.0)
+        else:
+            out[name] = normal(seed, name, shape, std=0.1)
+    return out

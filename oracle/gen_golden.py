@@ -1,0 +1,239 @@
+"""Generate tests/golden/* by running the REAL reference code (build container only).
+
+    PYTHONPATH=/root/reference python oracle/gen_golden.py
+
+The reference (qinliuliuqin/Medical-Segmentation3d-Toolkit, mounted read-only at /root/reference) is imported, fed
+deterministic inputs/weights from oracle/detgen.py, and only its OUTPUTS are stored (small .npz / .json).  The GPU box
+never sees the reference: tests regenerate the same inputs with detgen and compare against these fixtures.
+Nothing from the reference's source is copied; `image_partition_by_fixed_size` cannot be imported (its module
+imports SimpleITK), so its function body is executed in place via `ast` on a duck-typed image object.
+"""
+import ast
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+if REF not in sys.path:
+    sys.path.insert(0, REF)
+from oracle import detgen  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+torch.set_num_threads(8)
+
+
+def _load_sd(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = detgen.state_dict_like(shapes, seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return shapes
+
+
+def _grads(module):
+    return {k: p.grad.detach().numpy().copy() for k, p in module.named_parameters()}
+
+
+def gen_blocks():
+    from segmentation3d.network.module.conv_gn_relu3 import ConvGnRelu3, BottConvGnRelu3
+    from segmentation3d.network.module.residual_block3 import ResidualBlock3, BottResidualBlock3
+    from segmentation3d.network.module.vnet_inblock import InputBlock
+    from segmentation3d.network.module.vnet_downblock import DownBlock
+    from segmentation3d.network.module.vnet_upblock import UpBlock
+    from segmentation3d.network.module.vnet_outblock import OutputBlock
+
+    cases = {
+        # name: (constructor, input shapes)
+        'convgnrelu_k3_1_16': (lambda: ConvGnRelu3(1, 16, 3, 1, 1), [(2, 1, 8, 12, 16)]),
+        'convgnrelu_k3_16_16_noact': (lambda: ConvGnRelu3(16, 16, 3, 1, 1, do_act=False), [(2, 16, 8, 8, 8)]),
+        'convgnrelu_k3_32_32': (lambda: ConvGnRelu3(32, 32, 3, 1, 1), [(1, 32, 8, 8, 16)]),
+        'convgnrelu_k2s2_16_32': (lambda: ConvGnRelu3(16, 32, 2, 2, 0), [(2, 16, 8, 8, 8)]),
+        'bottconv_32': (lambda: BottConvGnRelu3(32, 32, 3, 1, 1, 4), [(1, 32, 8, 8, 8)]),
+        'resblock_16_x2': (lambda: ResidualBlock3(16, 3, 1, 1, 2), [(2, 16, 8, 8, 8)]),
+        'bottresblock_32_x2': (lambda: BottResidualBlock3(32, 3, 1, 1, 4, 2), [(1, 32, 8, 8, 8)]),
+        'inblock_1': (lambda: InputBlock(1, 16), [(2, 1, 16, 16, 16)]),
+        'inblock_4': (lambda: InputBlock(4, 16), [(1, 4, 8, 8, 8)]),
+        'downblock_16_x1': (lambda: DownBlock(16, 1), [(2, 16, 8, 8, 8)]),
+        'downblock_32_x2_bott': (lambda: DownBlock(32, 2, compression=True), [(1, 32, 8, 8, 8)]),
+        'upblock_64_32_x1': (lambda: UpBlock(64, 32, 1), [(1, 64, 4, 4, 4), (1, 16, 8, 8, 8)]),
+        'upblock_64_64_x2_bott': (lambda: UpBlock(64, 64, 2, compression=True), [(1, 64, 4, 4, 4), (1, 32, 8, 8, 8)]),
+        'outblock_32_2': (lambda: OutputBlock(32, 2), [(1, 32, 8, 8, 8)]),
+        'outblock_32_5': (lambda: OutputBlock(32, 5), [(2, 32, 8, 8, 8)]),
+    }
+    for name, (ctor, in_shapes) in cases.items():
+        m = ctor()
+        _load_sd(m, seed=11)
+        ins = [torch.from_numpy(detgen.normal(12, '{}/in{}'.format(name, i), s)).requires_grad_(True)
+               for i, s in enumerate(in_shapes)]
+        out = m(*ins)
+        gout = torch.from_numpy(detgen.normal(13, name + '/gout', tuple(out.shape)))
+        out.backward(gout)
+        data = {'out': out.detach().numpy()}
+        for i, t in enumerate(ins):
+            data['din{}'.format(i)] = t.grad.numpy()
+        for k, g in _grads(m).items():
+            data['dparam/' + k] = g
+        np.savez_compressed(os.path.join(OUT, 'block_{}.npz'.format(name)), **data)
+        print('block', name, tuple(out.shape))
+
+
+def gen_nets():
+    from segmentation3d.network import vnet, vbnet
+    from segmentation3d.loss.multi_dice_loss import MultiDiceLoss
+    from segmentation3d.loss.focal_loss import FocalLoss
+    for plugin_name, plugin in (('vnet', vnet), ('vbnet', vbnet)):
+        for cin, ncls in ((1, 2), (1, 5), (4, 4)):
+            net = plugin.SegmentationNet(cin, ncls)
+            _load_sd(net, seed=21)
+            tag = '{}_{}_{}'.format(plugin_name, cin, ncls)
+            x = torch.from_numpy(detgen.normal(22, tag + '/x', (1, cin, 32, 32, 32)))
+            t = torch.from_numpy(detgen.labels(23, tag + '/t', (1, 1, 32, 32, 32), ncls))
+            data = {}
+            for loss_name in ('dice', 'focal'):
+                net.zero_grad()
+                probs = net(x)
+                if loss_name == 'dice':
+                    w = [1.0 + 0.5 * i for i in range(ncls)]
+                    loss = MultiDiceLoss(weights=w, num_class=ncls, use_gpu=False)(probs, t)
+                else:
+                    loss = FocalLoss(class_num=ncls, alpha=None, gamma=2, use_gpu=False)(probs, t)
+                loss.backward()
+                data['loss_' + loss_name] = np.float32(loss.item())
+                g = _grads(net)
+                data['gradnorm_' + loss_name] = np.array([np.sqrt((g[k].astype(np.float64) ** 2).sum()) for k in sorted(g)],
+                                                         dtype=np.float64)
+                data['grad_' + loss_name + '/in_block.conv.weight'] = g['in_block.conv.weight']
+                data['grad_' + loss_name + '/out_block.conv2.weight'] = g['out_block.conv2.weight']
+                data['grad_' + loss_name + '/up_32.up_conv.weight'] = g['up_32.up_conv.weight']
+                data['grad_' + loss_name + '/down_32.down_conv.bias'] = g['down_32.down_conv.bias']
+            data['probs'] = probs.detach().numpy()
+            data['param_names'] = np.array(sorted(g))
+            np.savez_compressed(os.path.join(OUT, 'net_{}.npz'.format(tag)), **data)
+            print('net', tag, float(data['loss_dice']), float(data['loss_focal']))
+
+
+def gen_losses():
+    from segmentation3d.loss.multi_dice_loss import MultiDiceLoss
+    from segmentation3d.loss.focal_loss import FocalLoss
+    cases = []
+    for C, shape in ((2, (2, 2, 6, 8, 10)), (5, (2, 5, 4, 8, 8)), (3, (1, 3, 8, 8, 8))):
+        logits = detgen.normal(31, 'loss/logits{}'.format(C), shape, std=2.0)
+        e = np.exp(logits - logits.max(1, keepdims=True))
+        probs = (e / e.sum(1, keepdims=True)).astype(np.float32)
+        target = detgen.labels(32, 'loss/t{}'.format(C), (shape[0], 1) + shape[2:], C)
+        cases.append(('rand{}'.format(C), C, probs, target))
+    # tie / threshold cases: probabilities exactly 1/C, an empty class, an all-background target
+    C = 2
+    p = np.full((1, 2, 4, 4, 4), 0.5, dtype=np.float32)
+    p[0, 0, :2] = 0.75
+    p[0, 1, :2] = 0.25
+    t = np.zeros((1, 1, 4, 4, 4), dtype=np.float32)
+    t[0, 0, 2:] = 1.0
+    cases.append(('ties2', 2, p, t))
+    C = 4
+    p = np.full((2, 4, 4, 4, 4), 0.25, dtype=np.float32)
+    p[:, 0, 1] = 0.4
+    p[:, 1, 1] = 0.3
+    p[:, 2, 1] = 0.2
+    p[:, 3, 1] = 0.1
+    t = np.zeros((2, 1, 4, 4, 4), dtype=np.float32)     # all background: classes 1..3 empty
+    cases.append(('allbg4', 4, p, t))
+    for name, C, probs, target in cases:
+        data = {'probs': probs, 'target': target}
+        for wname, w in (('uniform', [1.0] * C), ('ramp', [1.0 + i for i in range(C)])):
+            pt = torch.from_numpy(probs).clone().requires_grad_(True)
+            loss = MultiDiceLoss(weights=w, num_class=C, use_gpu=False)(pt, torch.from_numpy(target))
+            loss.backward()
+            data['dice_{}'.format(wname)] = np.float32(loss.item())
+            data['dice_{}_grad'.format(wname)] = pt.grad.numpy()
+        for gname, gamma, alpha in (('g2', 2, None), ('g0', 0, None), ('g1p5_alpha', 1.5, [1.0 + i for i in range(C)])):
+            pt = torch.from_numpy(probs).clone().requires_grad_(True)
+            loss = FocalLoss(class_num=C, alpha=alpha, gamma=gamma, use_gpu=False)(pt, torch.from_numpy(target))
+            loss.backward()
+            data['focal_{}'.format(gname)] = np.float32(loss.item())
+            data['focal_{}_grad'.format(gname)] = pt.grad.numpy()
+        # size_average=False and the 2-D [sample, class] form
+        p2 = torch.from_numpy(probs).movedim(1, -1).reshape(-1, C).clone().requires_grad_(True)
+        loss = FocalLoss(class_num=C, gamma=2, size_average=False, use_gpu=False)(p2, torch.from_numpy(target).reshape(-1))
+        loss.backward()
+        data['focal_2d_sum'] = np.float32(loss.item())
+        data['focal_2d_sum_grad'] = p2.grad.numpy()
+        np.savez_compressed(os.path.join(OUT, 'loss_{}.npz'.format(name)), **data)
+        print('loss', name, {k: float(v) for k, v in data.items() if np.ndim(v) == 0})
+
+
+class _DuckImage(object):
+    def __init__(self, size, spacing):
+        self._size, self._spacing = tuple(size), tuple(spacing)
+
+    def GetSize(self):
+        return self._size
+
+    def GetSpacing(self):
+        return self._spacing
+
+    def GetOrigin(self):
+        return (0.0, 0.0, 0.0)
+
+
+def gen_partitions():
+    src = open(os.path.join(REF, 'segmentation3d', 'utils', 'image_tools.py')).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'image_partition_by_fixed_size'][0]
+    ns = {'np': np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'image_tools.py', 'exec'), ns)  # runs in memory only
+    ref_fn = ns['image_partition_by_fixed_size']
+    cases = {
+        'vol512x512x400_96_48': ((512, 512, 400), (1.0, 1.0, 1.0), None, (96, 96, 96), (48, 48, 48)),
+        'vol128_96_48': ((128, 128, 128), (1.0, 1.0, 1.0), None, (96, 96, 96), (48, 48, 48)),
+        'vol128_mm_spacing0p8': ((128, 160, 96), (0.8, 0.8, 0.8), None, (64.0, 64.0, 48.0), (32.0, 32.0, 24.0)),
+        'vol_aniso': ((112, 96, 80), (0.5, 1.0, 2.0), None, (40.0, 50.0, 96.0), (20.0, 25.0, 48.0)),
+        'bbox_inside': ((256, 256, 192), (1.0, 1.0, 1.0), ((37, 50, 20), (200, 190, 150)), (96, 96, 96), (48, 48, 48)),
+        'bbox_near_edge': ((128, 128, 128), (1.0, 1.0, 1.0), ((60, 70, 90), (128, 128, 128)), (64, 64, 64), (32, 32, 32)),
+        'box_larger_than_volume': ((64, 64, 64), (1.0, 1.0, 1.0), None, (96, 96, 96), (48, 48, 48)),
+        'stride_larger_than_box': ((160, 160, 160), (1.0, 1.0, 1.0), None, (64, 64, 64), (80, 80, 80)),
+    }
+    out = {}
+    for name, (size, spacing, bbox, psize, pstride) in cases.items():
+        s0 = [0, 0, 0] if bbox is None else list(bbox[0])
+        e0 = list(size) if bbox is None else list(bbox[1])
+        starts, ends = ref_fn(_DuckImage(size, spacing), list(s0), list(e0), list(psize), list(pstride), 16)
+        out[name] = {'size': list(size), 'spacing': list(spacing), 'bbox_start': s0, 'bbox_end': e0,
+                     'partition_size': list(psize), 'partition_stride': list(pstride), 'max_stride': 16,
+                     'starts': [[int(v) for v in s] for s in starts], 'ends': [[int(v) for v in e] for e in ends]}
+        print('partition', name, len(starts))
+    with open(os.path.join(OUT, 'partitions.json'), 'w') as f:
+        json.dump(out, f)
+
+
+def gen_shapes():
+    from segmentation3d.network import vnet, vbnet
+    out = {}
+    for plugin_name, plugin in (('vnet', vnet), ('vbnet', vbnet)):
+        for cin, ncls in ((1, 2), (1, 5), (4, 4)):
+            net = plugin.SegmentationNet(cin, ncls)
+            out['{}_{}_{}'.format(plugin_name, cin, ncls)] = {
+                'keys': [[k, list(v.shape)] for k, v in net.state_dict().items()],
+                'num_params': int(sum(p.numel() for p in net.parameters())), 'max_stride': int(net.max_stride())}
+    with open(os.path.join(OUT, 'state_dict_shapes.json'), 'w') as f:
+        json.dump(out, f)
+    print('shapes', {k: v['num_params'] for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ['blocks', 'nets', 'losses', 'partitions', 'shapes']
+    if 'blocks' in which:
+        gen_blocks()
+    if 'nets' in which:
+        gen_nets()
+    if 'losses' in which:
+        gen_losses()
+    if 'partitions' in which:
+        gen_partitions()
+    if 'shapes' in which:
+        gen_shapes()

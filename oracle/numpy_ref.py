@@ -1,0 +1,132 @@
+"""ORACLE (test infrastructure, not product code) -- numpy restatement of the reference's sliding-window host path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Restated from (all relative to /root/reference/segmentation3d):
+  utils/image_tools.py:163-218  image_partition_by_fixed_size   -> partition_by_fixed_size
+  utils/normalizer.py:6-81 + utils/image_tools.py:221-238,472-478 -> fixed_normalize / adaptive_normalize
+  utils/image_tools.py:435-469  add_image_region / add_image_value -> accumulate_patch
+  core/seg_infer.py:313-327,336-339  accumulate loop, 1/count, argmax -> sliding_window_inference
+These reference modules import SimpleITK (absent here), so they cannot be imported; the partition function is pure
+index arithmetic and was pinned by executing the reference's own function body (extracted with `ast`, see
+oracle/gen_golden.py) on duck-typed images -> tests/golden/partition_*.json.  Normalisers / accumulate are a few numpy
+lines restated from the text; they have no reference-generated fixture ("parity unpinned" for those three helpers,
+stated in DESIGN.md) but are exercised against hand-computed cases.
+
+Array convention: a volume with sitk size (X, Y, Z) is a numpy array [Z, Y, X] (image_tools.py:448,465).
+"""
+import math
+
+import numpy as np
+
+
+def partition_by_fixed_size(image_size, image_spacing, bbox_start_voxel, bbox_end_voxel, partition_size,
+                            partition_stride, max_stride):
+    """image_tools.py:163-218.  All triples are (x, y, z).  Returns (start_voxels, end_voxels) lists of [x, y, z]."""
+    image_size = [int(s) for s in image_size]
+    for d in range(3):
+        assert image_size[d] >= max_stride and image_size[d] % max_stride == 0            # :176-177
+    start = [int(v) for v in bbox_start_voxel]
+    end = [int(v) for v in bbox_end_voxel]
+    bbox_size = [min(image_size[d], end[d] - start[d]) for d in range(3)]                # :179
+    for d in range(3):
+        if bbox_size[d] % max_stride != 0:                                                 # :181-182
+            bbox_size[d] = max_stride * (bbox_size[d] // max_stride + 1)
+        bbox_size[d] = min(bbox_size[d], image_size[d])                                    # :183
+        end[d] = start[d] + bbox_size[d]                                                   # :184
+        if end[d] > image_size[d]:                                                         # :185-187
+            end[d] = image_size[d]
+            start[d] = end[d] - bbox_size[d]
+        assert start[d] >= 0
+    box = [int(partition_size[d] / image_spacing[d] + 0.5) for d in range(3)]             # :190
+    for d in range(3):
+        if box[d] % max_stride:                                                            # :192-193
+            box[d] = max_stride * (box[d] // max_stride + 1)
+        box[d] = min(bbox_size[d], box[d])                                                 # :194
+    stride = [int(partition_stride[d] / image_spacing[d] + 0.5) for d in range(3)]        # :196
+    for d in range(3):
+        stride[d] = min(bbox_size[d], stride[d])                                           # :198
+    count = [int(math.ceil((bbox_size[d] - box[d]) / stride[d]) + 1) for d in range(3)]   # :200
+    starts, ends = [], []
+    for ix in range(count[0]):                                                             # x outer, z inner :202-204
+        for iy in range(count[1]):
+            for iz in range(count[2]):
+                s = [start[0] + ix * stride[0], start[1] + iy * stride[1], start[2] + iz * stride[2]]
+                e = [s[d] + box[d] for d in range(3)]
+                for d in range(3):
+                    if e[d] > end[d]:                                                      # clamp the tail :209-213
+                        e[d] = end[d]
+                        s[d] = e[d] - box[d]
+                        assert s[d] >= 0
+                starts.append(s)
+                ends.append(e)
+    return starts, ends
+
+
+def fixed_normalize(roi, mean, stddev, clip=True):
+    """FixedNormalizer.__call__ -> normalize_image(image, mean, std, clip) -- normalizer.py:22-25, image_tools.py:221-238"""
+    out = (roi - mean) / stddev
+    if clip:
+        out[out < -1.0] = -1.0
+        out[out > 1.0] = 1.0
+    return out.astype(roi.dtype)
+
+
+def adaptive_normalize(roi, clip_sigma=3):
+    """AdaptiveNormalizer.normalize -- normalizer.py:55-62 (population std, floor 1e-6, clip +-clip_sigma)"""
+    mean, std = np.mean(roi), np.std(roi)                                                  # image_tools.py:472-478
+    std = max(std, 1e-6)
+    out = (roi - mean) / std
+    out[out < -clip_sigma] = -clip_sigma
+    out[out > clip_sigma] = clip_sigma
+    return out.astype(roi.dtype)
+
+
+def apply_normalizer(roi, normalizer):
+    """normalizer: dict as stored in checkpoints (normalizer.py:36-39,78-81): {'type': 0, mean, stddev, clip} | {'type': 1, clip_sigma}"""
+    if normalizer is None:
+        return roi
+    if normalizer['type'] == 0:
+        return fixed_normalize(roi, normalizer['mean'], normalizer['stddev'], normalizer['clip'])
+    if normalizer['type'] == 1:
+        return adaptive_normalize(roi, normalizer['clip_sigma'])
+    raise ValueError('Unsupported normalization type.')                                    # seg_infer.py:162
+
+
+def accumulate_patch(acc, count, start, end, patch_probs):
+    """add_image_region per class + add_image_value(+1) -- image_tools.py:435-469, seg_infer.py:319-322.
+    acc: [C, Z, Y, X], count: [Z, Y, X], patch_probs: [C, bz, by, bx], start/end: (x, y, z)"""
+    zs, ys, xs = slice(start[2], end[2]), slice(start[1], end[1]), slice(start[0], end[0])
+    for c in range(acc.shape[0]):
+        acc[c, zs, ys, xs] += patch_probs[c]
+    count[zs, ys, xs] += 1.0
+
+
+def finalize(acc, count):
+    """probs *= 1/count; mask = argmax over classes (first maximum), int8 -- seg_infer.py:325-327,336-339"""
+    with np.errstate(divide='ignore', invalid='ignore'):
+        inv = (1.0 / count).astype(np.float32)
+        probs = acc * inv[None]
+    mask = np.argmax(probs, axis=0).astype(np.int8)  # uncovered voxels (count 0 -> NaN) resolve to class 0
+    return probs, mask
+
+
+def sliding_window_inference(volume, net_fn, num_classes, spacing, partition_size, partition_stride, max_stride,
+                             normalizer, double_forward=True):
+    """segmentation_volume's patch loop at model spacing (no resample): seg_infer.py:276-339.
+    volume: float32 [Z, Y, X]; net_fn: array [1,1,bz,by,bx] -> array [1,C,bz,by,bx].
+    double_forward reproduces the reference's two identical forwards + mean (seg_infer.py:230-234)."""
+    Z, Y, X = volume.shape
+    starts, ends = partition_by_fixed_size((X, Y, Z), spacing, [0, 0, 0], [X, Y, Z], partition_size, partition_stride,
+                                           max_stride)
+    acc = np.zeros((num_classes, Z, Y, X), dtype=np.float32)
+    count = np.zeros((Z, Y, X), dtype=np.float32)
+    for s, e in zip(starts, ends):
+        roi = volume[s[2]:e[2], s[1]:e[1], s[0]:e[0]].copy()
+        roi = apply_normalizer(roi, normalizer)
+        p = net_fn(roi[None, None])
+        if double_forward:
+            p = np.mean(np.stack([p, net_fn(roi[None, None])]), axis=0)
+        accumulate_patch(acc, count, s, e, p[0])
+    probs, mask = finalize(acc, count)
+    return probs, mask, (starts, ends)

@@ -114,9 +114,9 @@ long long seg3d_patch_stats_blocks(int bx, int by, int bz);
 int seg3d_patch_gather_normalize(const float* volume, const int* starts_xyz, float* batch, double* workspace,
                                  float* mean_std, int Z, int Y, int X, int bx, int by, int bz, int P, int normalizer_type,
                                  float mean, float stddev, int clip, float clip_sigma, void* stream);
-int seg3d_patch_scatter_accumulate(const float* probs, const int* starts_xyz, float* acc, float* count, int Z, int Y,
-                                   int X, int bx, int by, int bz, int P, int C, int lox, int loy, int loz, int ex, int ey,
-                                   int ez, void* stream);
+int seg3d_patch_scatter_accumulate(const float* probs, const int* starts_xyz, const int* ctl /* device int32[7] */,
+                                   float* acc, float* count, int Z, int Y, int X, int bx, int by, int bz, int C,
+                                   long long max_box_voxels, void* stream);
 int seg3d_finalize_argmax(float* acc, const float* count, signed char* mask, int C, long long voxels, void* stream);
 
 #ifdef __cplusplus

@@ -146,14 +146,17 @@ extern "C" int seg3d_patch_gather_normalize(const float* volume, const int* star
   return SEG3D_OK;
 }
 
-// One thread per volume voxel of the batch's bounding box [lo, hi); patches are applied in list order so the
-// float summation order per voxel equals the reference's sequential loop (no atomics, reproducible).
+// One thread per volume voxel of the batch's bounding box; patches are applied in list order so the float summation
+// order per voxel equals the reference's sequential loop (no atomics, reproducible).  The bounding box and the number
+// of valid patches come from a small DEVICE control block so that a captured hipGraph can be replayed for every
+// batch with unchanged kernel arguments:  ctl = {lo_x, lo_y, lo_z, extent_x, extent_y, extent_z, n_valid}.
 __global__ __launch_bounds__(256) void patch_scatter_accumulate_kernel(const float* __restrict__ probs,
                                                                          const int* __restrict__ starts,
+                                                                         const int* __restrict__ ctl,
                                                                          float* __restrict__ acc, float* __restrict__ count,
-                                                                         int Z, int Y, int X, int bx, int by, int bz, int P,
-                                                                         int C, int lox, int loy, int loz, int ex, int ey,
-                                                                         int ez) {
+                                                                         int Z, int Y, int X, int bx, int by, int bz,
+                                                                         int C) {
+  const int lox = ctl[0], loy = ctl[1], loz = ctl[2], ex = ctl[3], ey = ctl[4], ez = ctl[5], P = ctl[6];
   const i64 total = (i64)ex * ey * ez;
   const i64 vol = (i64)Z * Y * X;
   const i64 nv = (i64)bx * by * bz;
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(256) void patch_scatter_accumulate_kernel(const flo
     const int x = lox + (int)(idx % ex);
     const i64 t = idx / ex;
     const int y = loy + (int)(t % ey), z = loz + (int)(t / ey);
+    if (x >= X || y >= Y || z >= Z) continue;
     const i64 v = ((i64)z * Y + y) * X + x;
     for (int p = 0; p < P; ++p) {
       const int lx = x - starts[3 * p], ly = y - starts[3 * p + 1], lz = z - starts[3 * p + 2];
@@ -173,17 +177,16 @@ __global__ __launch_bounds__(256) void patch_scatter_accumulate_kernel(const flo
   }
 }
 
-// probs [P][C][bz][by][bx] -> acc [C][Z][Y][X] += , count [Z][Y][X] += 1; (lo, extent) = bounding box of the batch.
-extern "C" int seg3d_patch_scatter_accumulate(const float* probs, const int* starts, float* acc, float* count, int Z, int Y,
-                                              int X, int bx, int by, int bz, int P, int C, int lox, int loy, int loz, int ex,
-                                              int ey, int ez, void* stream) {
-  SEG3D_REQUIRE(probs && starts && acc && count && P > 0 && C > 0, "seg3d_patch_scatter_accumulate: bad arguments");
-  SEG3D_REQUIRE(lox >= 0 && loy >= 0 && loz >= 0 && ex > 0 && ey > 0 && ez > 0 && lox + ex <= X && loy + ey <= Y &&
-                    loz + ez <= Z,
-                "seg3d_patch_scatter_accumulate: bounding box outside the volume");
-  const i64 total = (i64)ex * ey * ez;
-  hipLaunchKernelGGL(patch_scatter_accumulate_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     probs, starts, acc, count, Z, Y, X, bx, by, bz, P, C, lox, loy, loz, ex, ey, ez);
+// probs [P][C][bz][by][bx] -> acc [C][Z][Y][X] +=, count [Z][Y][X] += 1.  starts_xyz: device int32 [P][3];
+// ctl: device int32 [7] (see kernel); max_box_voxels: host upper bound of the bounding-box volume (sizes the grid).
+extern "C" int seg3d_patch_scatter_accumulate(const float* probs, const int* starts, const int* ctl, float* acc,
+                                              float* count, int Z, int Y, int X, int bx, int by, int bz, int C,
+                                              long long max_box_voxels, void* stream) {
+  SEG3D_REQUIRE(probs && starts && ctl && acc && count && C > 0, "seg3d_patch_scatter_accumulate: bad arguments");
+  SEG3D_REQUIRE(bx > 0 && by > 0 && bz > 0 && bx <= X && by <= Y && bz <= Z && max_box_voxels > 0,
+                "seg3d_patch_scatter_accumulate: bad box");
+  hipLaunchKernelGGL(patch_scatter_accumulate_kernel, dim3(seg3d_ew_grid(max_box_voxels, 256)), dim3(256), 0,
+                     (hipStream_t)stream, probs, starts, ctl, acc, count, Z, Y, X, bx, by, bz, C);
   SEG3D_LAUNCH_CHECK("seg3d_patch_scatter_accumulate");
   return SEG3D_OK;
 }

@@ -55,7 +55,7 @@ _SIGNATURES = {
     'seg3d_adam_step': (_c_int, [_c_p] * 4 + [_c_ll, _c_int] + [_c_f] * 6 + [_c_p]),
     'seg3d_patch_stats_blocks': (_c_ll, [_c_int] * 3),
     'seg3d_patch_gather_normalize': (_c_int, [_c_p] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_f, _c_p]),
-    'seg3d_patch_scatter_accumulate': (_c_int, [_c_p] * 4 + [_c_int] * 14 + [_c_p]),
+    'seg3d_patch_scatter_accumulate': (_c_int, [_c_p] * 5 + [_c_int] * 7 + [_c_ll, _c_p]),
     'seg3d_finalize_argmax': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
 }
 

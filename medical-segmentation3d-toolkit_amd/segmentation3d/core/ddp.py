@@ -1,0 +1,136 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI, overlapped with backward.
+
+Replaces `nn.parallel.DataParallel` (core/seg_train.py:76-78 of the reference), which re-broadcasts the parameters,
+scatters the batch, gathers the outputs and reduces the gradients to GPU 0 every step inside ONE process.  Here
+every rank owns a full replica and its own 4-patch batch; the only exchange is one sum all-reduce of the flat fp32
+gradient buffer (58.3 MB for the 14.56 M-parameter V-Net) per step:
+
+  * gradients live in ONE contiguous buffer (FusedAdam's flat layout), so a bucket is just a slice -- no packing;
+  * buckets are cut in reverse parameter order (the decoder/head gradients are produced first in backward) and each
+    bucket's all-reduce is enqueued from a post-accumulate hook as soon as its last gradient has been written, so the
+    transfer overlaps the rest of backward (RCCL runs on its own stream, ordered after the producing kernels);
+  * xGMI is a point-to-point full mesh (7 links/GPU): a few large buckets (default 4 x ~16 MB) keep every link busy
+    without paying per-collective latency 116 times; the 1/world scaling is folded into the Adam kernel.
+GroupNorm(1, C) statistics are per sample, Dice is per sample then batch mean and Focal is a mean over voxels, so with
+equal per-rank batches the averaged gradient equals the global-batch gradient: no other collective is needed.
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradients(object):
+    """one contiguous gradient buffer for a list of parameters (used when the optimizer is not FusedAdam, e.g. the
+    CPU/gloo tests); `p.grad` becomes a view into it"""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.offsets, total = [], 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += p.numel()
+        ref = self.params[0]
+        self.buffer = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        self.attach()
+
+    def attach(self):
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.buffer[off:off + p.numel()].view(p.shape)
+
+    def zero(self):
+        self.buffer.zero_()
+        self.attach()
+
+    def layout(self):
+        return [(p, 0, off, p.numel()) for p, off in zip(self.params, self.offsets)]
+
+
+class GradientReducer(object):
+    """bucketed, backward-overlapped sum all-reduce of flat gradient buffers.
+
+    :param flat_buffers: list of flat gradient tensors (one per parameter group)
+    :param layout: [(param, buffer index, offset, numel)] in buffer order
+    :param num_buckets: buckets per buffer (cut by bytes, aligned to parameter boundaries)
+    """
+
+    def __init__(self, flat_buffers, layout, process_group=None, num_buckets=4):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.buffers = flat_buffers
+        self._buckets = []          # dict(buffer, lo, hi, pending, nparams, work)
+        self._param_bucket = {}
+        for bi, buf in enumerate(flat_buffers):
+            entries = [(p, off, n) for p, b, off, n in layout if b == bi]
+            if not entries:
+                continue
+            total = buf.numel()
+            target = max(1, total // max(1, num_buckets))
+            # walk parameters from the END of the buffer (their gradients arrive first in backward)
+            hi, acc, members = total, 0, []
+            for p, off, n in reversed(entries):
+                members.append(p)
+                acc += n
+                if acc >= target and len(self._buckets_for(bi)) < num_buckets - 1:
+                    self._add_bucket(bi, off, hi, members)
+                    hi, acc, members = off, 0, []
+            if members:
+                self._add_bucket(bi, 0, hi, members)
+        self._handles = []
+        for p in self._param_bucket:
+            self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+        self._active = False
+
+    def _buckets_for(self, bi):
+        return [b for b in self._buckets if b['buffer'] == bi]
+
+    def _add_bucket(self, bi, lo, hi, members):
+        idx = len(self._buckets)
+        self._buckets.append({'buffer': bi, 'lo': lo, 'hi': hi, 'nparams': len(members), 'pending': len(members),
+                              'work': None})
+        for p in members:
+            self._param_bucket[p] = idx
+
+    def bucket_sizes(self):
+        return [b['hi'] - b['lo'] for b in self._buckets]
+
+    # ---- per step ----------------------------------------------------------------------------------------------------
+    def begin_step(self):
+        """call before backward (after zero_grad)"""
+        for b in self._buckets:
+            b['pending'], b['work'] = b['nparams'], None
+        self._active = True
+
+    def _launch(self, b):
+        view = self.buffers[b['buffer']][b['lo']:b['hi']]
+        b['work'] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad_ready(self, param):
+        if not self._active:
+            return
+        b = self._buckets[self._param_bucket[param]]
+        b['pending'] -= 1
+        if b['pending'] == 0 and b['work'] is None:
+            self._launch(b)
+
+    def finish_step(self):
+        """call after backward: reduces buckets whose hooks did not all fire, then waits (stream-ordered on GPUs).
+        Gradients hold the SUM over ranks afterwards; divide by `world_size` (FusedAdam.grad_scale does it in-kernel)."""
+        self._active = False
+        for b in self._buckets:
+            if b['work'] is None:
+                self._launch(b)
+        for b in self._buckets:
+            b['work'].wait()
+            b['work'] = None
+
+    def broadcast_parameters(self, flat_params_or_list, src=0):
+        """make every replica start from rank `src`'s parameters"""
+        tensors = flat_params_or_list if isinstance(flat_params_or_list, (list, tuple)) else [flat_params_or_list]
+        for t in tensors:
+            dist.broadcast(t, src=src, group=self.group)
+
+    def remove_hooks(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

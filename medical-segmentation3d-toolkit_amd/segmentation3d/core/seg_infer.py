@@ -1,0 +1,341 @@
+"""Sliding-window whole-volume inference -- MI355X-native replacement of the patch path of the reference's
+core/seg_infer.py (segmentation_voi :208-246, segmentation_volume :249-350, load_single_model :99-164,
+load_models :167-205).
+
+Reference behaviour: for every partition box, slice the ROI on the host, normalise it, run the net TWICE on a batch
+of one, copy every class map back to the host and `+=` it into a SimpleITK volume through full-volume numpy round
+trips (utils/image_tools.py:446-450); finally multiply by 1/count and arg-max.
+
+Here the volume stays resident in HBM.  `SlidingWindowBatcher` crops + normalises P patches per launch
+(seg3d_patch_gather_normalize), the net runs ONCE per patch (the reference's two forwards are identical in eval mode,
+so their mean is the single result bit for bit), and the class maps are accumulated on the device in list order
+(seg3d_patch_scatter_accumulate, no atomics => the same float summation order as the reference's sequential loop).
+gather -> net -> scatter is captured once into a hipGraph (torch.cuda.CUDAGraph drives hipStreamBeginCapture) and
+replayed per batch; only a 4*(3P+7)-byte control block changes between replays.
+"""
+import importlib
+import os
+import time
+
+import numpy as np
+import torch
+
+from segmentation3d import _engine as E
+from segmentation3d.utils.image3d import Image3d
+from segmentation3d.utils.image_tools import image_partition_by_fixed_size
+from segmentation3d.utils.model_io import get_checkpoint_folder, strip_module_prefix
+from segmentation3d.utils.normalizer import normalizer_from_dict
+
+
+class SlidingWindowBatcher(object):
+    """device-side crop/normalise + accumulate for one resident volume.
+
+    :param volume: float32 device tensor [Z, Y, X]
+    :param starts: list of [x, y, z] patch start voxels (all patches share `box`)
+    :param box: (bx, by, bz) patch size in voxels
+    :param num_classes: C
+    :param normalizer: checkpoint-style dict {'type': 0|1, ...} or None (utils/normalizer.py:36-39,78-81)
+    """
+
+    def __init__(self, volume, starts, box, num_classes, normalizer, max_batch=16):
+        E.require_device(volume)
+        if volume.dim() != 3 or volume.dtype != torch.float32:
+            raise ValueError('volume must be a float32 [Z, Y, X] tensor')
+        self.volume = volume.contiguous()
+        self.Z, self.Y, self.X = (int(s) for s in volume.shape)
+        self.box = tuple(int(b) for b in box)
+        self.C = int(num_classes)
+        self.starts = [[int(v) for v in s] for s in starts]
+        bx, by, bz = self.box
+        for s in self.starts:
+            if s[0] < 0 or s[1] < 0 or s[2] < 0 or s[0] + bx > self.X or s[1] + by > self.Y or s[2] + bz > self.Z:
+                raise ValueError('patch {} with box {} leaves the volume {}'.format(s, self.box, (self.X, self.Y, self.Z)))
+        self.normalizer = normalizer
+        if normalizer is None:
+            self._norm = (-1, 0.0, 1.0, 0, 1.0)
+        elif normalizer['type'] == 0:
+            self._norm = (0, float(normalizer['mean']), float(normalizer['stddev']), int(bool(normalizer['clip'])), 1.0)
+        elif normalizer['type'] == 1:
+            self._norm = (1, 0.0, 1.0, 1, float(normalizer['clip_sigma']))
+        else:
+            raise ValueError('Unsupported normalization type.')
+        dev = volume.device
+        self.acc = torch.zeros((self.C, self.Z, self.Y, self.X), dtype=torch.float32, device=dev)
+        self.count = torch.zeros((self.Z, self.Y, self.X), dtype=torch.float32, device=dev)
+        self.max_batch = int(max_batch)
+        nblk = E.query('seg3d_patch_stats_blocks', bx, by, bz)
+        self._stat_ws = torch.empty((self.max_batch * nblk * 2,), dtype=torch.float64, device=dev)
+        self._mean_std = torch.empty((self.max_batch, 2), dtype=torch.float32, device=dev)
+        # control block on the device: [P][3] starts then {lo xyz, extent xyz, n_valid}
+        self._ctl = torch.zeros((3 * self.max_batch + 7,), dtype=torch.int32, device=dev)
+        self._plan = None
+
+    # ---- control block ---------------------------------------------------------------------------------------------
+    def _control_words(self, idx):
+        P = self.max_batch
+        if not 0 < len(idx) <= P:
+            raise ValueError('batch of {} patches exceeds max_batch={}'.format(len(idx), P))
+        bx, by, bz = self.box
+        sel = np.array([self.starts[k] for k in idx], dtype=np.int32)
+        lo = sel.min(0)
+        hi = sel.max(0) + np.array([bx, by, bz], dtype=np.int32)
+        host = np.zeros((3 * P + 7,), dtype=np.int32)
+        host[:3 * len(idx)] = sel.reshape(-1)
+        host[3 * len(idx):3 * P] = np.tile(sel[0], P - len(idx))  # padding patches: gathered, never scattered
+        host[3 * P:3 * P + 3] = lo
+        host[3 * P + 3:3 * P + 6] = hi - lo
+        host[3 * P + 6] = len(idx)
+        return host
+
+    def set_batch(self, idx):
+        """upload starts / bounding box / valid count of the patches `idx` (synchronous 4*(3P+7)-byte copy)"""
+        self._ctl.copy_(torch.from_numpy(self._control_words(idx)))
+
+    def plan(self, batches):
+        """upload the control blocks of ALL batches in one copy; `select(b)` then switches batch with a stream-ordered
+        device-to-device copy, so the host never has to wait for the GPU between batches"""
+        words = np.stack([self._control_words(idx) for idx in batches])
+        self._plan = torch.from_numpy(words).to(self._ctl.device)
+
+    def select(self, b):
+        self._ctl.copy_(self._plan[b], non_blocking=True)
+
+    def _starts_ptr(self):
+        return E.ptr(self._ctl)
+
+    def _ctl_ptr(self):
+        import ctypes
+        return ctypes.c_void_p(self._ctl.data_ptr() + 4 * 3 * self.max_batch)
+
+    # ---- kernels -----------------------------------------------------------------------------------------------------
+    def gather_current(self, out=None):
+        """crop + normalise the max_batch patches described by the control block -> [P, 1, bz, by, bx]"""
+        bx, by, bz = self.box
+        P = self.max_batch
+        if out is None:
+            out = torch.empty((P, 1, bz, by, bx), dtype=torch.float32, device=self.volume.device)
+        ntype, mean, std, clip, sigma = self._norm
+        E.call('seg3d_patch_gather_normalize', E.ptr(self.volume), self._starts_ptr(), E.ptr(out), E.ptr(self._stat_ws),
+               E.ptr(self._mean_std), self.Z, self.Y, self.X, bx, by, bz, P, ntype, mean, std, clip, sigma, E.stream_ptr())
+        return out
+
+    def scatter_current(self, probs):
+        """accumulate probs [P, C, bz, by, bx] of the control block's valid patches into acc / count"""
+        bx, by, bz = self.box
+        P = self.max_batch
+        if tuple(probs.shape) != (P, self.C, bz, by, bx) or not probs.is_contiguous():
+            raise ValueError('probs must be contiguous [{}, {}, {}, {}, {}], got {}'.format(P, self.C, bz, by, bx,
+                                                                                            tuple(probs.shape)))
+        max_box = min(self.X * self.Y * self.Z, min(self.X, bx * P) * min(self.Y, by * P) * min(self.Z, bz * P))
+        E.call('seg3d_patch_scatter_accumulate', E.ptr(probs), self._starts_ptr(), self._ctl_ptr(), E.ptr(self.acc),
+               E.ptr(self.count), self.Z, self.Y, self.X, bx, by, bz, self.C, max_box, E.stream_ptr())
+
+    # convenience (eager) forms used by tests and the non-graph path
+    def gather(self, idx):
+        self.set_batch(idx)
+        return self.gather_current()[:len(idx)]
+
+    def scatter(self, idx, probs):
+        self.set_batch(idx)
+        P = self.max_batch
+        if probs.shape[0] != P:
+            pad = torch.zeros((P - probs.shape[0],) + tuple(probs.shape[1:]), dtype=probs.dtype, device=probs.device)
+            probs = torch.cat((probs, pad), 0)
+        self.scatter_current(probs.contiguous())
+
+    def finalize(self):
+        """acc *= 1/count (in place) and arg-max -> (probs [C,Z,Y,X], mask int8 [Z,Y,X])"""
+        mask = torch.empty((self.Z, self.Y, self.X), dtype=torch.int8, device=self.volume.device)
+        E.call('seg3d_finalize_argmax', E.ptr(self.acc), E.ptr(self.count), E.ptr(mask), self.C,
+               self.Z * self.Y * self.X, E.stream_ptr())
+        return self.acc, mask
+
+
+def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, batch_size=8, use_graph=True):
+    """run `net` over all patches of a device-resident volume; returns (probs [C,Z,Y,X], mask int8 [Z,Y,X], batcher)"""
+    batcher = SlidingWindowBatcher(volume, starts, box, num_classes, normalizer, max_batch=batch_size)
+    P = batcher.max_batch
+    batches = [list(range(i, min(i + P, len(starts)))) for i in range(0, len(starts), P)]
+    batcher.plan(batches)
+    graph, first = None, 0
+    with torch.no_grad():
+        if use_graph and len(batches) > 2:
+            # warm-up on a side stream (allocator, lazy code-object loading), then capture gather -> net -> scatter
+            # once.  The warm-up batch is accumulated for real: it simply is the first batch of the job.
+            stream = torch.cuda.Stream()
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                batcher.select(0)
+                static_in = batcher.gather_current()
+                batcher.scatter_current(net(static_in).contiguous())
+            torch.cuda.current_stream().wait_stream(stream)
+            first = 1
+            # capture with n_valid = 0 in the control block so the captured launch itself accumulates nothing
+            batcher._ctl.zero_()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                batcher.gather_current(out=static_in)
+                batcher.scatter_current(net(static_in).contiguous())
+        for b in range(first, len(batches)):
+            batcher.select(b)
+            if graph is not None:
+                graph.replay()
+            else:
+                batcher.scatter_current(net(batcher.gather_current()).contiguous())
+        probs, mask = batcher.finalize()
+    return probs, mask, batcher
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reference-shaped API
+# ---------------------------------------------------------------------------------------------------------------------
+class _Model(dict):
+    """attribute dict (the reference uses easydict here, core/seg_infer.py:107)"""
+    __getattr__ = dict.get
+    __setattr__ = dict.__setitem__
+
+
+def load_single_model(model_folder, gpu_id=0):
+    """load one model folder `<folder>/checkpoints/chk_<latest>/params.pth` (reference: seg_infer.py:99-164).
+    gpu_id must be >= 0: this engine has no CPU path (the reference's gpu_id = -1 branch is served by stock torch)."""
+    assert os.path.isdir(model_folder), 'Model folder does not exist: {}'.format(model_folder)
+    if gpu_id is None or int(gpu_id) < 0:
+        raise E.Seg3dEngineError('segmentation3d HIP engine needs gpu_id >= 0 (no CPU inference path)')
+    device = torch.device('cuda:{}'.format(int(gpu_id)))
+    chk_dir = get_checkpoint_folder(os.path.join(model_folder, 'checkpoints'), -1)
+    state = torch.load(os.path.join(chk_dir, 'params.pth'), map_location='cpu', weights_only=True)
+    net_module = importlib.import_module('segmentation3d.network.' + state['net'])
+    net = net_module.SegmentationNet(state['in_channels'], state['out_channels'])
+    net.load_state_dict(strip_module_prefix(state['state_dict']))
+    net.eval()
+    net = net.to(device)
+    model = _Model()
+    model.net = net
+    model.device = device
+    model.spacing, model.max_stride, model.interpolation = state['spacing'], state['max_stride'], state['interpolation']
+    model.in_channels, model.out_channels = state['in_channels'], state['out_channels']
+    model.crop_normalizers = [normalizer_from_dict(d) for d in state['crop_normalizers']]
+    model.crop_normalizer_dicts = list(state['crop_normalizers'])
+    return model
+
+
+def load_models(model_folder, gpu_id=0):
+    """load `infer_config.py` plus the coarse / fine models it names (reference: seg_infer.py:167-205)"""
+    from segmentation3d.utils.file_io import load_config
+    assert os.path.isdir(model_folder), 'Model folder does not exist: {}'.format(model_folder)
+    infer_cfg = load_config(os.path.join(model_folder, 'infer_config.py'))
+    models = _Model()
+    models.infer_cfg = infer_cfg
+    scale = infer_cfg.general.single_scale
+    if scale not in ('coarse', 'fine', 'DISABLE'):
+        raise ValueError('Unsupported single scale type!')
+    models.coarse_model = models.fine_model = None
+    if scale in ('coarse', 'DISABLE'):
+        models.coarse_model = load_single_model(os.path.join(model_folder, infer_cfg.coarse.model_name), gpu_id)
+    if scale in ('fine', 'DISABLE'):
+        models.fine_model = load_single_model(os.path.join(model_folder, infer_cfg.fine.model_name), gpu_id)
+    return models
+
+
+def segmentation_voi(model, iso_image, start_voxel, end_voxel, use_gpu=True):
+    """segment one volume of interest (reference: seg_infer.py:208-246); returns the list of per-class Image3d maps.
+    Kept for API parity; whole volumes should go through segmentation_volume, which batches patches on the device."""
+    vol = torch.from_numpy(np.ascontiguousarray(iso_image.array, dtype=np.float32)).to(model['device'])
+    box = [int(end_voxel[d] - start_voxel[d]) for d in range(3)]
+    norm = model['crop_normalizer_dicts'][0] if model['crop_normalizer_dicts'] else None
+    probs, _, _ = sliding_window_inference(model['net'], vol, [list(start_voxel)], box, model['out_channels'], norm,
+                                           batch_size=1, use_graph=False)
+    z0, y0, x0 = start_voxel[2], start_voxel[1], start_voxel[0]
+    maps = []
+    for c in range(model['out_channels']):
+        roi = probs[c, z0:z0 + box[2], y0:y0 + box[1], x0:x0 + box[0]].cpu().numpy()
+        maps.append(Image3d(roi, iso_image.GetSpacing(), iso_image.GetOrigin(), iso_image.GetDirection()))
+    return maps
+
+
+def segmentation_volume(model, cfg, image, bbox_start_voxel, bbox_end_voxel, use_gpu=True, batch_size=8):
+    """segment a whole volume (reference: seg_infer.py:249-350).
+
+    Scope of this round: the image must already be at the model's spacing (the reference's ITK resampling to the
+    model spacing and back, image_tools.py:329-377, is the next row of the scope table).  The size is padded with
+    zeros up to a multiple of max_stride exactly as `resample_spacing` does for an image at the target spacing.
+    Returns (mean_probs: list of Image3d, mask: Image3d int8).
+    """
+    assert isinstance(image, Image3d)
+    spacing = [float(s) for s in model['spacing']]
+    if any(abs(a - b) > 1e-4 * max(a, b) for a, b in zip(image.GetSpacing(), spacing)):
+        raise NotImplementedError('image spacing {} differs from the model spacing {}: on-device resampling is not '
+                                  'built yet (SURVEY.md section 8f row f1)'.format(image.GetSpacing(), spacing))
+    ms = int(model['max_stride'])
+    X, Y, Z = image.GetSize()
+    Xp, Yp, Zp = [(v + ms - 1) // ms * ms for v in (X, Y, Z)]
+    dev = model['device']
+    vol = torch.zeros((Zp, Yp, Xp), dtype=torch.float32, device=dev)
+    vol[:Z, :Y, :X] = torch.from_numpy(np.ascontiguousarray(image.array, dtype=np.float32)).to(dev)
+    if cfg.partition_type == 'DISABLE':
+        starts, box = [[0, 0, 0]], (Xp, Yp, Zp)
+    elif cfg.partition_type == 'SIZE':
+        if bbox_start_voxel is not None and bbox_end_voxel is not None:
+            s0 = [max(0, int(v)) for v in bbox_start_voxel]
+            e0 = [min(int(v), lim) for v, lim in zip(bbox_end_voxel, (Xp, Yp, Zp))]
+        else:
+            s0, e0 = [0, 0, 0], [Xp, Yp, Zp]
+        starts, ends = image_partition_by_fixed_size(((Xp, Yp, Zp), spacing), s0, e0, list(cfg.partition_size),
+                                                     list(cfg.partition_stride), ms)
+        box = tuple(ends[0][d] - starts[0][d] for d in range(3))
+    else:
+        raise ValueError('Unsupported partition type!')
+    norm = model['crop_normalizer_dicts'][0] if model['crop_normalizer_dicts'] else None
+    probs, mask, _ = sliding_window_inference(model['net'], vol, starts, box, model['out_channels'], norm,
+                                              batch_size=min(batch_size, max(1, len(starts))))
+    probs = probs[:, :Z, :Y, :X]
+    mask = mask[:Z, :Y, :X]
+    frame = (image.GetSpacing(), image.GetOrigin(), image.GetDirection())
+    mean_probs = [Image3d(probs[c].cpu().numpy(), *frame) for c in range(model['out_channels'])]
+    return mean_probs, Image3d(mask.cpu().numpy(), *frame)
+
+
+def segmentation(input_path, model_folder, output_folder, seg_name, gpu_id, return_mask, save_mask, save_image,
+                 save_prob):
+    """volumetric image segmentation engine for MetaImage files (reference: seg_infer.py:353-493).
+    Single-scale configurations ('coarse' or 'fine'); the coarse->fine cascade needs the bounding-box / connected
+    component post-processing that is scoped as next."""
+    from segmentation3d.utils.mha_io import read_mha, write_mha
+    begin = time.time()
+    models = load_models(model_folder, gpu_id)
+    load_model_time = time.time() - begin
+    if os.path.isfile(input_path) and input_path.endswith('.txt'):
+        with open(input_path) as f:
+            paths = [ln.strip() for ln in f.readlines()[1:] if ln.strip()]
+    elif os.path.isfile(input_path) and (input_path.endswith('.mha') or input_path.endswith('.mhd')):
+        paths = [input_path]
+    else:
+        raise ValueError('Unsupported input path.')
+    scale = models['infer_cfg'].general.single_scale
+    if scale == 'DISABLE':
+        raise NotImplementedError('coarse-to-fine cascade is not built yet; set general.single_scale to coarse or fine')
+    model = models['coarse_model'] if scale == 'coarse' else models['fine_model']
+    cfg = models['infer_cfg'].coarse if scale == 'coarse' else models['infer_cfg'].fine
+    masks, total = [], 0.0
+    for i, path in enumerate(paths):
+        print('{}: {}'.format(i, path))
+        image = read_mha(path)
+        begin = time.time()
+        mean_probs, mask = segmentation_volume(model, cfg, image, None, None, True)
+        torch.cuda.synchronize()
+        total += time.time() - begin
+        if return_mask:
+            masks.append(mask)
+        case = os.path.basename(path).split('.')[0]
+        if save_mask or save_image or save_prob:
+            os.makedirs(os.path.join(output_folder, case), exist_ok=True)
+        if save_mask:
+            write_mha(mask, os.path.join(output_folder, case, seg_name))
+        if save_image:
+            write_mha(image, os.path.join(output_folder, case, 'org.mha'))
+        if save_prob:
+            for c, p in enumerate(mean_probs):
+                write_mha(p, os.path.join(output_folder, case, 'mean_prob_{}.mha'.format(c)))
+        print('load model time: {:.2f}, average inference time: {:.2f}'.format(load_model_time, total / (i + 1)))
+    return masks

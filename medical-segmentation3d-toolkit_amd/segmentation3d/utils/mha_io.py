@@ -1,0 +1,65 @@
+"""Minimal MetaImage (.mha / .mhd) reader and writer -- enough to run `seg_infer` on synthetic volumes without
+SimpleITK (the reference reads/writes through `sitk.ReadImage` / `sitk.WriteImage`, core/seg_infer.py:414,467).
+Uncompressed, little-endian, 3-D, scalar element types only."""
+import os
+
+import numpy as np
+
+from segmentation3d.utils.image3d import Image3d
+
+_MET = {'MET_FLOAT': np.float32, 'MET_DOUBLE': np.float64, 'MET_SHORT': np.int16, 'MET_USHORT': np.uint16,
+        'MET_CHAR': np.int8, 'MET_UCHAR': np.uint8, 'MET_INT': np.int32, 'MET_UINT': np.uint32}
+_MET_INV = {np.dtype(v).name: k for k, v in _MET.items()}
+
+
+def read_mha(path, dtype=np.float32):
+    with open(path, 'rb') as f:
+        header = {}
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError('{}: ElementDataFile not found in header'.format(path))
+            key, _, value = line.decode('ascii', 'replace').partition('=')
+            key, value = key.strip(), value.strip()
+            header[key] = value
+            if key == 'ElementDataFile':
+                break
+        if header.get('CompressedData', 'False').lower() == 'true':
+            raise NotImplementedError('compressed MetaImage files are not supported')
+        if int(header.get('NDims', 3)) != 3:
+            raise ValueError('only 3-D images are supported')
+        size = [int(v) for v in header['DimSize'].split()]
+        et = _MET[header['ElementType']]
+        count = size[0] * size[1] * size[2]
+        if header['ElementDataFile'] == 'LOCAL':
+            data = np.frombuffer(f.read(count * np.dtype(et).itemsize), dtype=et)
+        else:
+            raw = os.path.join(os.path.dirname(path), header['ElementDataFile'])
+            data = np.fromfile(raw, dtype=et, count=count)
+    if header.get('BinaryDataByteOrderMSB', 'False').lower() == 'true':
+        data = data.byteswap()
+    array = data.reshape(size[2], size[1], size[0])
+    if dtype is not None:
+        array = array.astype(dtype)
+    spacing = [float(v) for v in header.get('ElementSpacing', '1 1 1').split()]
+    origin = [float(v) for v in header.get('Offset', header.get('Position', '0 0 0')).split()]
+    direction = [float(v) for v in header.get('TransformMatrix', '1 0 0 0 1 0 0 0 1').split()]
+    return Image3d(array, spacing, origin, direction)
+
+
+def write_mha(image, path):
+    array = np.ascontiguousarray(image.array)
+    name = array.dtype.name
+    if name not in _MET_INV:
+        raise ValueError('unsupported dtype {}'.format(name))
+    x, y, z = image.GetSize()
+    lines = ['ObjectType = Image', 'NDims = 3', 'BinaryData = True', 'BinaryDataByteOrderMSB = False',
+             'CompressedData = False',
+             'TransformMatrix = ' + ' '.join(repr(float(v)) for v in image.GetDirection()),
+             'Offset = ' + ' '.join(repr(float(v)) for v in image.GetOrigin()),
+             'CenterOfRotation = 0 0 0', 'AnatomicalOrientation = RAI',
+             'ElementSpacing = ' + ' '.join(repr(float(v)) for v in image.GetSpacing()),
+             'DimSize = {} {} {}'.format(x, y, z), 'ElementType = ' + _MET_INV[name], 'ElementDataFile = LOCAL']
+    with open(path, 'wb') as f:
+        f.write(('\n'.join(lines) + '\n').encode('ascii'))
+        f.write(array.tobytes())

@@ -1,0 +1,308 @@
+"""GPU parity tests of the individual HIP operators against stock torch CPU ops (the operators the reference composes)
+and the oracle's loss closed forms.  Every call goes through the C ABI of libseg3d_hip.so.
+Tolerances: fp32 kernels, 1e-4 absolute on O(1) values (north_star), relative 1e-3..1e-4 on gradients."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import report, max_err, rel_err
+from oracle import detgen, torch_ref, numpy_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(seed, name, shape, std=1.0):
+    return torch.from_numpy(detgen.normal(seed, name, shape, std=std))
+
+
+CONV_K3_CASES = [
+    # N, Cin, Cout, D, H, W
+    (2, 8, 32, 8, 8, 16),
+    (1, 32, 32, 16, 16, 16),
+    (1, 16, 16, 6, 10, 12),
+    (1, 64, 96, 4, 6, 6),
+    (1, 12, 20, 5, 7, 9),
+    (2, 256, 64, 2, 2, 2),
+    (2, 1, 16, 8, 8, 8),
+    (1, 32, 2, 8, 8, 8),
+    (1, 3, 5, 6, 6, 6),
+    (1, 128, 128, 3, 5, 6),
+]
+
+
+@pytest.mark.parametrize('force_direct', [False, True])
+@pytest.mark.parametrize('case', CONV_K3_CASES)
+def test_conv3d_k3_fwd_bwd(hip_device, case, force_direct):
+    from segmentation3d import _ops
+    N, Cin, Cout, D, H, W = case
+    if force_direct and Cin * Cout > 64 * 96:
+        pytest.skip('direct fallback not exercised on the largest shapes')
+    name = 'conv_k3_{}_{}'.format('direct' if force_direct else 'auto', '_'.join(map(str, case)))
+    x = _t(1, name + 'x', (N, Cin, D, H, W)).requires_grad_(True)
+    w = _t(2, name + 'w', (Cout, Cin, 3, 3, 3), std=(2.0 / (Cin * 27)) ** 0.5).requires_grad_(True)
+    b = _t(3, name + 'b', (Cout,), std=0.1).requires_grad_(True)
+    g = _t(4, name + 'g', (N, Cout, D, H, W))
+    ref = F.conv3d(x, w, b, padding=1)
+    rdx, rdw, rdb = torch.autograd.grad(ref, (x, w, b), g)
+    xd, wd, bd = (t.detach().to(hip_device).requires_grad_(True) for t in (x, w, b))
+    _ops.FORCE_DIRECT = force_direct
+    try:
+        out = _ops.conv(xd, wd, bd, 'k3')
+        dx, dw, db = torch.autograd.grad(out, (xd, wd, bd), g.to(hip_device))
+    finally:
+        _ops.FORCE_DIRECT = False
+    torch.cuda.synchronize()
+    e = dict(out=max_err(out, ref), dx=rel_err(dx, rdx), dw=rel_err(dw, rdw), db=rel_err(db, rdb))
+    report(name, **e)
+    assert e['out'] < 1e-4 and e['dx'] < 1e-4 and e['dw'] < 2e-4 and e['db'] < 1e-4, e
+
+
+def test_conv3d_k3_mfma_stats_partials(hip_device):
+    """the conv epilogue's per-workgroup (sum, sumsq) equal the statistics of its own output"""
+    from segmentation3d import _ops
+    N, Cin, Cout, D, H, W = 2, 16, 48, 6, 10, 20
+    x = _t(5, 'stx', (N, Cin, D, H, W)).to(hip_device)
+    w = _t(6, 'stw', (Cout, Cin, 3, 3, 3), std=0.1).to(hip_device)
+    b = _t(7, 'stb', (Cout,), std=0.5).to(hip_device)
+    y, part = _ops.conv_forward(_ops.to_ndhwc(x), w, b, 'k3', want_stats=True)
+    assert part is not None
+    s = part.double().sum(1).cpu()
+    yy = y.double().reshape(N, -1).cpu()
+    assert rel_err(s[:, 0], yy.sum(1)) < 1e-5 and rel_err(s[:, 1], (yy * yy).sum(1)) < 1e-5
+
+
+@pytest.mark.parametrize('kind,cin,cout,dims', [
+    ('k2s2', 16, 32, (2, 8, 8, 8)), ('k2s2', 1, 16, (1, 4, 6, 8)), ('k2s2', 128, 256, (1, 2, 4, 4)),
+    ('convT', 64, 16, (1, 4, 4, 6)), ('convT', 256, 128, (2, 2, 2, 2)), ('convT', 3, 5, (1, 3, 3, 3)),
+    ('k1', 2, 2, (2, 8, 8, 8)), ('k1', 5, 5, (1, 4, 4, 4)), ('k1', 16, 8, (1, 4, 4, 4)),
+])
+def test_strided_convs_fwd_bwd(hip_device, kind, cin, cout, dims):
+    from segmentation3d import _ops
+    N, D, H, W = dims
+    name = 'conv_{}_{}_{}_{}'.format(kind, cin, cout, '_'.join(map(str, dims)))
+    x = _t(11, name + 'x', (N, cin, D, H, W)).requires_grad_(True)
+    if kind == 'convT':
+        w = _t(12, name + 'w', (cin, cout, 2, 2, 2), std=(1.0 / cin) ** 0.5).requires_grad_(True)
+        ref_fn = lambda a, ww, bb: F.conv_transpose3d(a, ww, bb, stride=2)
+    elif kind == 'k2s2':
+        w = _t(12, name + 'w', (cout, cin, 2, 2, 2), std=(1.0 / (8 * cin)) ** 0.5).requires_grad_(True)
+        ref_fn = lambda a, ww, bb: F.conv3d(a, ww, bb, stride=2)
+    else:
+        w = _t(12, name + 'w', (cout, cin, 1, 1, 1), std=(1.0 / cin) ** 0.5).requires_grad_(True)
+        ref_fn = lambda a, ww, bb: F.conv3d(a, ww, bb)
+    b = _t(13, name + 'b', (cout,), std=0.1).requires_grad_(True)
+    ref = ref_fn(x, w, b)
+    g = _t(14, name + 'g', tuple(ref.shape))
+    rdx, rdw, rdb = torch.autograd.grad(ref, (x, w, b), g)
+    xd, wd, bd = (t.detach().to(hip_device).requires_grad_(True) for t in (x, w, b))
+    out = _ops.conv(xd, wd, bd, kind)
+    dx, dw, db = torch.autograd.grad(out, (xd, wd, bd), g.to(hip_device))
+    e = dict(out=max_err(out, ref), dx=rel_err(dx, rdx), dw=rel_err(dw, rdw), db=rel_err(db, rdb))
+    report(name, **e)
+    assert e['out'] < 1e-4 and e['dx'] < 1e-4 and e['dw'] < 2e-4 and e['db'] < 1e-4, e
+
+
+@pytest.mark.parametrize('C,dims,relu,with_res', [
+    (16, (2, 8, 8, 8), True, False), (32, (1, 6, 10, 12), True, True), (256, (2, 2, 3, 3), False, True),
+    (2, (2, 8, 8, 8), True, False), (5, (1, 4, 6, 8), False, False), (64, (1, 20, 20, 24), True, False),
+    (128, (1, 4, 4, 4), False, False),
+])
+def test_fused_conv_gn_act(hip_device, C, dims, relu, with_res):
+    """conv(k1, identity-free) + GroupNorm(1, C) [+res] [+ReLU] forward/backward against F.group_norm autograd"""
+    from segmentation3d import _ops
+    N, D, H, W = dims
+    name = 'gn_{}_{}_{}_{}'.format(C, '_'.join(map(str, dims)), int(relu), int(with_res))
+    x = _t(21, name + 'x', (N, C, D, H, W), std=2.0)
+    x = (x + 0.7).requires_grad_(True)
+    gamma = _t(22, name + 'ga', (C,), std=0.3).add(1.0).requires_grad_(True)
+    beta = _t(23, name + 'be', (C,), std=0.3).requires_grad_(True)
+    res = _t(24, name + 're', (N, C, D, H, W)).requires_grad_(True) if with_res else None
+    ref = F.group_norm(x, 1, gamma, beta, 1e-5)
+    if with_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    g = _t(25, name + 'g', tuple(ref.shape))
+    ins = (x, gamma, beta) + ((res,) if with_res else ())
+    rgr = torch.autograd.grad(ref, ins, g)
+    xd, gd, bd = (t.detach().to(hip_device).requires_grad_(True) for t in (x, gamma, beta))
+    rd = res.detach().to(hip_device).requires_grad_(True) if with_res else None
+
+    # GroupNorm on its own
+    if not with_res:
+        out = _ops.group_norm(xd, gd, bd, relu=relu)
+        gr = torch.autograd.grad(out, (xd, gd, bd), g.to(hip_device))
+        e = dict(out=max_err(out, ref), dx=rel_err(gr[0], rgr[0]), dgamma=rel_err(gr[1], rgr[1]), dbeta=rel_err(gr[2], rgr[2]))
+        report(name + '_gn_only', **e)
+        assert e['out'] < 1e-4 and e['dx'] < 2e-4 and e['dgamma'] < 2e-4 and e['dbeta'] < 2e-4, e
+
+    # fused unit with an identity 1x1x1 conv in front: exercises stats, apply, residual, and dbias through GN backward
+    w = torch.eye(C).reshape(C, C, 1, 1, 1).contiguous().to(hip_device).requires_grad_(True)
+    cb = torch.zeros(C, device=hip_device, requires_grad=True)
+    out = _ops.conv_gn_act(xd, w, cb, gd, bd, residual=rd, kind='k1', relu=relu)
+    outs = torch.autograd.grad(out, (xd, gd, bd, cb) + ((rd,) if with_res else ()), g.to(hip_device))
+    e = dict(out=max_err(out, ref), dx=rel_err(outs[0], rgr[0]), dgamma=rel_err(outs[1], rgr[1]),
+             dbeta=rel_err(outs[2], rgr[2]))
+    # dbias of the conv feeding a GroupNorm: sum over voxels of dL/dy
+    xr = x.detach().clone().requires_grad_(True)
+    bz = torch.zeros(C, requires_grad=True)
+    r2 = F.group_norm(xr + bz.view(1, C, 1, 1, 1), 1, gamma.detach(), beta.detach(), 1e-5)
+    if with_res:
+        r2 = r2 + res.detach()
+    if relu:
+        r2 = F.relu(r2)
+    (rdb,) = torch.autograd.grad(r2, (bz,), g)
+    e['dbias_abs'] = max_err(outs[3], rdb)
+    if with_res:
+        e['dres'] = rel_err(outs[4], rgr[3])
+    report(name + '_fused', **e)
+    assert e['out'] < 1e-4 and e['dx'] < 2e-4 and e['dgamma'] < 2e-4 and e['dbeta'] < 2e-4, e
+    assert e['dbias_abs'] < 1e-3 + 2e-4 * float(rdb.abs().max()), e
+    if with_res:
+        assert e['dres'] < 1e-5, e
+
+
+@pytest.mark.parametrize('C', [2, 5, 16])
+def test_softmax_and_cat(hip_device, C):
+    from segmentation3d import _ops
+    x = _t(31, 'smx{}'.format(C), (2, C, 4, 6, 8), std=2.0).requires_grad_(True)
+    g = _t(32, 'smg{}'.format(C), (2, C, 4, 6, 8))
+    ref = F.softmax(x, dim=1)
+    (rdx,) = torch.autograd.grad(ref, (x,), g)
+    xd = x.detach().to(hip_device).requires_grad_(True)
+    out = _ops.softmax_channels(xd)
+    assert out.is_contiguous()
+    (dx,) = torch.autograd.grad(out, (xd,), g.to(hip_device))
+    e = dict(out=max_err(out, ref), dx=rel_err(dx, rdx))
+    report('softmax_{}'.format(C), **e)
+    assert e['out'] < 1e-6 and e['dx'] < 1e-5
+    a = _t(33, 'cata', (2, C, 4, 4, 4)).to(hip_device).requires_grad_(True)
+    b = _t(34, 'catb', (2, 3 * C, 4, 4, 4)).to(hip_device).requires_grad_(True)
+    out = _ops.cat_channels(a, b)
+    assert torch.equal(out.cpu(), torch.cat((a.detach().cpu(), b.detach().cpu()), 1))
+    gg = _t(35, 'catg', tuple(out.shape)).to(hip_device)
+    da, db = torch.autograd.grad(out, (a, b), gg)
+    assert torch.equal(da.cpu(), gg[:, :C].cpu()) and torch.equal(db.cpu(), gg[:, C:].cpu())
+
+
+def test_layout_roundtrip(hip_device):
+    from segmentation3d import _ops
+    x = _t(36, 'lay', (2, 5, 3, 4, 6)).to(hip_device)
+    n = _ops.to_ndhwc(x)
+    assert torch.equal(n.cpu(), x.cpu().permute(0, 2, 3, 4, 1).contiguous())
+    back = _ops.to_ncdhw_contiguous(n)
+    assert torch.equal(back.cpu(), x.cpu())
+
+
+@pytest.mark.parametrize('C,shape', [(2, (2, 2, 16, 16, 20)), (5, (1, 5, 8, 12, 12)), (3, (3, 3, 4, 4, 4))])
+def test_losses_against_oracle(hip_device, C, shape):
+    from segmentation3d.loss.multi_dice_loss import MultiDiceLoss
+    from segmentation3d.loss.focal_loss import FocalLoss
+    logits = _t(41, 'll{}'.format(C), shape, std=2.0)
+    probs = F.softmax(logits, dim=1)
+    target = torch.from_numpy(detgen.labels(42, 'lt{}'.format(C), (shape[0], 1) + shape[2:], C))
+    w = [1.0 + 0.5 * i for i in range(C)]
+    p = probs.clone().requires_grad_(True)
+    ref = torch_ref.multi_dice_loss(p, target, w)
+    ref.backward()
+    pd = probs.to(hip_device).requires_grad_(True)
+    out = MultiDiceLoss(w, C, use_gpu=True)(pd, target.to(hip_device))
+    out.backward()
+    e = dict(loss=abs(float(out) - float(ref)), grad=rel_err(pd.grad, p.grad))
+    report('dice_{}'.format(C), **e)
+    assert e['loss'] < 1e-5 and e['grad'] < 1e-4, e
+    for gamma, alpha, avg in ((2, None, True), (0, None, True), (1.5, w, True), (2, None, False)):
+        p = probs.clone().requires_grad_(True)
+        ref = torch_ref.focal_loss(p, target, C, alpha, gamma, avg)
+        ref.backward()
+        pd = probs.to(hip_device).requires_grad_(True)
+        out = FocalLoss(C, alpha=alpha, gamma=gamma, size_average=avg, use_gpu=True)(pd, target.to(hip_device))
+        out.backward()
+        e = dict(loss=abs(float(out) - float(ref)) / max(1.0, abs(float(ref))), grad=rel_err(pd.grad, p.grad))
+        report('focal_{}_{}_{}'.format(C, gamma, int(avg)), **e)
+        assert e['loss'] < 1e-5 and e['grad'] < 1e-4, e
+    # 2-D [sample, class] form (focal_loss.py:32)
+    p2 = probs.movedim(1, -1).reshape(-1, C).contiguous()
+    ref = torch_ref.focal_loss(p2, target.reshape(-1), C, None, 2)
+    out = FocalLoss(C, use_gpu=True)(p2.to(hip_device), target.reshape(-1).to(hip_device))
+    assert abs(float(out) - float(ref)) < 1e-5
+
+
+def test_losses_golden_ties(hip_device):
+    """threshold / tie cases pinned by the reference itself (tests/golden/loss_ties2, loss_allbg4)"""
+    from conftest import golden_npz
+    from segmentation3d.loss.multi_dice_loss import MultiDiceLoss
+    from segmentation3d.loss.focal_loss import FocalLoss
+    for name in ('ties2', 'allbg4', 'rand2', 'rand5'):
+        gold = golden_npz('loss_' + name)
+        C = gold['probs'].shape[1]
+        t = torch.from_numpy(gold['target']).to(hip_device)
+        for wname, w in (('uniform', [1.0] * C), ('ramp', [1.0 + i for i in range(C)])):
+            p = torch.from_numpy(gold['probs']).to(hip_device).requires_grad_(True)
+            loss = MultiDiceLoss(w, C, use_gpu=True)(p, t)
+            loss.backward()
+            assert abs(float(loss) - float(gold['dice_' + wname])) < 1e-6, (name, wname)
+            assert max_err(p.grad, gold['dice_{}_grad'.format(wname)]) < 1e-6 * max(1.0, float(np.abs(gold['dice_{}_grad'.format(wname)]).max()) * 1e2)
+        for gname, gamma, alpha in (('g2', 2, None), ('g0', 0, None), ('g1p5_alpha', 1.5, [1.0 + i for i in range(C)])):
+            p = torch.from_numpy(gold['probs']).to(hip_device).requires_grad_(True)
+            loss = FocalLoss(C, alpha=alpha, gamma=gamma, use_gpu=True)(p, t)
+            loss.backward()
+            assert abs(float(loss) - float(gold['focal_' + gname])) < 1e-6, (name, gname)
+            assert rel_err(p.grad, gold['focal_{}_grad'.format(gname)]) < 1e-5
+
+
+def test_fused_adam_matches_torch_adam(hip_device):
+    from segmentation3d.optim.fused_adam import FusedAdam
+    shapes = [(16, 1, 3, 3, 3), (16,), (33,), (5, 7), (1,)]
+    ps_ref = [_t(51, 'ap{}'.format(i), s).requires_grad_(True) for i, s in enumerate(shapes)]
+    ps_dev = [torch.nn.Parameter(p.detach().clone().to(hip_device)) for p in ps_ref]
+    ref = torch.optim.Adam(ps_ref, lr=1e-3, betas=(0.9, 0.999))
+    opt = FusedAdam(ps_dev, lr=1e-3, betas=(0.9, 0.999))
+    for step in range(5):
+        ref.zero_grad()
+        opt.zero_grad()
+        for i, (a, b) in enumerate(zip(ps_ref, ps_dev)):
+            g = _t(52 + step, 'ag{}'.format(i), shapes[i])
+            a.grad = g.clone()
+            b.grad.copy_(g.to(hip_device))
+        ref.step()
+        opt.step()
+    err = max(max_err(b, a) for a, b in zip(ps_ref, ps_dev))
+    report('fused_adam', err=err)
+    assert err < 1e-6
+    sd = opt.state_dict()
+    assert sorted(sd['state'][0].keys()) == ['exp_avg', 'exp_avg_sq', 'step']
+    assert max_err(sd['state'][0]['exp_avg'], ref.state_dict()['state'][0]['exp_avg']) < 1e-6
+
+
+def test_patch_batcher_against_numpy_oracle(hip_device):
+    from segmentation3d.core.seg_infer import SlidingWindowBatcher
+    rng = np.random.RandomState(0)
+    Z, Y, X = 48, 64, 80
+    vol = (rng.randn(Z, Y, X) * 300 - 200).astype(np.float32)
+    starts, ends = numpy_ref.partition_by_fixed_size((X, Y, Z), (1.0, 1.0, 1.0), [0, 0, 0], [X, Y, Z], (32, 32, 32),
+                                                     (24, 24, 16), 16)
+    C = 3
+    for normalizer in ({'type': 1, 'clip_sigma': 2.5}, {'type': 0, 'mean': -150.0, 'stddev': 280.0, 'clip': True}, None):
+        batcher = SlidingWindowBatcher(torch.from_numpy(vol).to(hip_device), starts, (32, 32, 32), C, normalizer)
+        acc = np.zeros((C, Z, Y, X), np.float32)
+        cnt = np.zeros((Z, Y, X), np.float32)
+        P = 5
+        for i in range(0, len(starts), P):
+            idx = list(range(i, min(i + P, len(starts))))
+            batch = batcher.gather(idx)
+            for j, k in enumerate(idx):
+                s, e = starts[k], ends[k]
+                roi = numpy_ref.apply_normalizer(vol[s[2]:e[2], s[1]:e[1], s[0]:e[0]].copy(), normalizer)
+                assert max_err(batch[j, 0], roi) < 2e-5, normalizer
+            probs = torch.softmax(torch.stack([batch[:, 0] * (c + 1) for c in range(C)], 1), 1).contiguous()
+            batcher.scatter(idx, probs)
+            pc = probs.cpu().numpy()
+            for j, k in enumerate(idx):
+                numpy_ref.accumulate_patch(acc, cnt, starts[k], ends[k], pc[j])
+        probs_d, mask_d = batcher.finalize()
+        rp, rm = numpy_ref.finalize(acc, cnt)
+        assert np.array_equal(batcher.count.cpu().numpy(), cnt)
+        assert max_err(probs_d, rp) == 0.0          # same summation order as the sequential reference loop
+        assert np.array_equal(mask_d.cpu().numpy(), rm)

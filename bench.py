@@ -1,0 +1,266 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native segmentation engine.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Metric (BASELINE.json): patches/sec of a 96^3, 1-modality V-Net fp32 TRAIN STEP (forward + Dice loss + backward + Adam),
+batch 4 per GPU, weak scaling over the GPUs of one node; plus the whole-volume sliding-window inference seconds
+(512x512x400, 96^3 patches, stride 48, hipGraph-replayed batches) reported in the `infer` object at N = 1.
+A "step" = one optimisation step on one synthetic batch that is already resident in HBM.
+
+The JSON line also carries
+  roofline     : the dominant kernel (fp32 MFMA 3x3x3 convolution, forward + data-gradient launches), measured live with
+                 events on the launch stream: algorithmic FLOPs of its launches / their summed duration vs 157.3 TFLOP/s
+  cpu_baseline : the oracle (stock torch CPU ops, op-for-op the reference's path) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(REPO, 'medical-segmentation3d-toolkit_amd'), REPO):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=4, help='patches per GPU per step')
+    ap.add_argument('--patch', type=int, default=96)
+    ap.add_argument('--net', default='vnet')
+    ap.add_argument('--in-channels', type=int, default=1)
+    ap.add_argument('--classes', type=int, default=2)
+    ap.add_argument('--loss', default='Dice', choices=['Dice', 'Focal'])
+    ap.add_argument('--no-infer', action='store_true', help='skip the whole-volume inference measurement')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--infer-volume', default='512,512,400', help='X,Y,Z of the synthetic inference volume')
+    ap.add_argument('--infer-batch', type=int, default=8)
+    ap.add_argument('--kernel-report', default='', help='write the per-shape kernel timing table to this json file')
+    return ap.parse_args()
+
+
+def synthetic_batch(batch, cin, ncls, patch, device, seed):
+    """N(0,1) clipped to +-3 (post-AdaptiveNormalizer distribution) and blobby labels, generated on the device"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.randn((batch, cin, patch, patch, patch), generator=g, device=device).clamp_(-3, 3)
+    coarse = torch.rand((batch, 1, patch // 8, patch // 8, patch // 8), generator=g, device=device)
+    lab = torch.nn.functional.interpolate(coarse, scale_factor=8, mode='nearest')
+    t = torch.floor(lab * ncls).clamp_(0, ncls - 1)
+    return x.contiguous(), t.contiguous()
+
+
+class KernelTimer(object):
+    """brackets every launch of the MFMA 3x3x3 convolution entry point with events on torch's current stream (the
+    stream the C ABI launches on) and books its algorithmic FLOPs"""
+
+    def __init__(self):
+        from segmentation3d import _engine
+        self.E = _engine
+        self.records = []
+        self._orig = None
+
+    def __enter__(self):
+        E = self.E
+        self._orig = E.call
+        timer = self
+
+        def call(name, *args):
+            if name != 'seg3d_conv3d_k3_mfma_fwd':
+                return timer._orig(name, *args)
+            N, D, H, W, Cin, Cout = args[5:11]
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = timer._orig(name, *args)
+            b.record()
+            ma = E.query('seg3d_conv3d_k3_mfma_variant', N, D, H, W, Cout)
+            timer.records.append(((N, D, H, W, Cin, Cout, ma), a, b))
+            return rc
+        E.call = call
+        return self
+
+    def __exit__(self, *exc):
+        self.E.call = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        table = {}
+        for key, a, b in self.records:
+            N, D, H, W, Cin, Cout, ma = key
+            ms = a.elapsed_time(b)
+            flops = 2.0 * N * D * H * W * 27 * Cin * Cout
+            e = table.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+            e['launches'] += 1
+            e['ms'] += ms
+            e['flops'] += flops
+        return table
+
+
+def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):
+    """oracle train step (stock torch CPU ops + torch.optim.Adam), B = 1, on this host: ~10-30 s of CPU work"""
+    from oracle import torch_ref
+    from segmentation3d.network import vnet, vbnet
+    plugin = {'vnet': vnet, 'vbnet': vbnet}[net_name]
+    torch.manual_seed(0)
+    net = plugin.SegmentationNet(cin, ncls)
+    plugin.parameters_kaiming_init(net)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-4, betas=(0.9, 0.999))
+    x, t = synthetic_batch(1, cin, ncls, patch, torch.device('cpu'), 123)
+    kw = {'weights': [1.0 / ncls] * ncls} if loss_name == 'Dice' else {'class_num': ncls, 'alpha': None, 'gamma': 2}
+    times = []
+    for i in range(4):
+        t0 = time.time()
+        torch_ref.train_step(sd, opt, x, t, net_name, loss_name, kw)
+        times.append(time.time() - t0)
+    steady = times[1:]
+    return {'value': round(1.0 / (sum(steady) / len(steady)), 4), 'unit': 'patches/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': '{} timed train steps (fwd+{}+bwd+Adam) of {}({},{}) on one {}^3 patch, batch 1, after 1 warm-up; '
+                      'oracle/torch_ref.py = the stock torch CPU ops the reference composes'.format(
+                          len(steady), loss_name, net_name, cin, ncls, patch)}
+
+
+def time_inference(net, volume_xyz, patch, stride, ncls, batch, device):
+    from segmentation3d.core.seg_infer import sliding_window_inference
+    from segmentation3d.utils.image_tools import image_partition_by_fixed_size
+    X, Y, Z = volume_xyz
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    host = torch.randn((Z, Y, X), generator=torch.Generator().manual_seed(7))
+    starts, ends = image_partition_by_fixed_size(((X, Y, Z), (1.0, 1.0, 1.0)), [0, 0, 0], [X, Y, Z], [patch] * 3,
+                                                 [stride] * 3, 16)
+    net.eval()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    vol = host.to(device)
+    torch.cuda.synchronize()
+    t_h2d = time.time() - t0
+    t0 = time.time()
+    probs, mask, _ = sliding_window_inference(net, vol, starts, (patch,) * 3, ncls, {'type': 1, 'clip_sigma': 3},
+                                              batch_size=batch, use_graph=True)
+    torch.cuda.synchronize()
+    t_dev = time.time() - t0
+    t0 = time.time()
+    mask_host = mask.cpu()
+    t_d2h = time.time() - t0
+    return {'workload': 'sliding-window inference, {}x{}x{} volume, {}^3 patches stride {}, {} patches, batch {} per '
+                        'hipGraph replay, 1 forward/patch'.format(X, Y, Z, patch, stride, len(starts), batch),
+            'seconds': round(t_dev, 4), 'h2d_seconds': round(t_h2d, 4), 'd2h_mask_seconds': round(t_d2h, 4),
+            'patches_per_s': round(len(starts) / t_dev, 2), 'mask_nonzero': int((mask_host != 0).sum())}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device (the engine has no CPU path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+    if args.gpus != world and rank == 0:
+        sys.stderr.write('note: --gpus {} but WORLD_SIZE {}\n'.format(args.gpus, world))
+
+    from segmentation3d.core.seg_train import TrainStep
+    weights = [1.0 / args.classes] * args.classes
+    step = TrainStep(args.net, args.in_channels, args.classes, args.loss, weights if args.loss == 'Dice' else None,
+                     device=device, seed=0)
+    x, t = synthetic_batch(args.batch, args.in_channels, args.classes, args.patch, device, 1000 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step(x, t)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(x, t)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.batch * args.steps / elapsed
+
+    roofline, kernels = None, None
+    if not args.no_roofline and rank == 0:
+        with KernelTimer() as kt:
+            for _ in range(2):
+                step(x, t)
+        table = kt.summary()
+        by_variant = {}
+        for key, e in table.items():
+            v = by_variant.setdefault(key[6], {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+            for k in v:
+                v[k] += e[k]
+        dom = max(by_variant, key=lambda m: by_variant[m]['ms'])
+        d = by_variant[dom]
+        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        roofline = {'kernel': 'conv3d_k3_mfma_kernel<{}>'.format(dom), 'bound': 'mfma', 'achieved': round(achieved, 2),
+                    'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    'traffic': None, 'launches_per_step': d['launches'] // 2,
+                    'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                    'gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
+                    'share_of_step_ms': round(d['ms'] / 2, 3)}
+        kernels = [{'N_D_H_W_Cin_Cout_variant': list(k), 'launches_per_step': e['launches'] // 2,
+                    'avg_ms': round(e['ms'] / e['launches'], 4),
+                    'tflops': round(e['flops'] / (e['ms'] * 1e-3) / 1e12, 2)} for k, e in sorted(table.items())]
+        if args.kernel_report:
+            os.makedirs(os.path.dirname(os.path.abspath(args.kernel_report)), exist_ok=True)
+            with open(args.kernel_report, 'w') as f:
+                json.dump({'mfma_conv_launches': kernels, 'ms_per_step': ms_per_step}, f, indent=1)
+
+    infer = None
+    if not args.no_infer and world == 1:
+        vx = tuple(int(v) for v in args.infer_volume.split(','))
+        infer = time_inference(step.net, vx, args.patch, args.patch // 2, args.classes, args.infer_batch, device)
+
+    cpu_baseline = None
+    if not args.no_cpu_baseline and world == 1 and rank == 0:
+        cpu_baseline = time_cpu_baseline(args.net, args.in_channels, args.classes, args.patch, args.loss)
+
+    if rank == 0:
+        out = {
+            'metric': 'patches/sec (96^3, 1-mod V-Net) train-step', 'value': round(value, 3), 'unit': 'patches/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '{}({},{}) train step (fwd + {} loss + bwd + fused Adam), {} patches of {}^3 per GPU, '
+                                   'fp32, random-init weights'.format(args.net, args.in_channels, args.classes, args.loss,
+                                                                      args.batch, args.patch),
+                       'global_batch': world * args.batch, 'patch': args.patch,
+                       'parallelism': 'dp{} (bucketed RCCL all-reduce overlapped with backward)'.format(world) if world > 1 else 'single GPU'},
+            'final_loss': round(final_loss, 6),
+            'roofline': roofline, 'cpu_baseline': cpu_baseline, 'infer': infer,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -240,6 +240,13 @@ extern "C" long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W
   return (long long)seg3d_cdiv(D, t.tz) * seg3d_cdiv(H, t.ty) * seg3d_cdiv(W, t.tx) * cob;
 }
 
+// which template instantiation (accumulators per wave, 1..4) a given problem runs: lets profilers attribute time
+extern "C" int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cout) {
+  Seg3dTile t = seg3d_pick_tile(N, D, H, W, (Cout + 31) / 32);
+  const int subs = (t.tz * t.ty * t.tx + 31) / 32;
+  return (subs + 3) / 4;
+}
+
 template <int MA>
 static int launch_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
                       int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s) {

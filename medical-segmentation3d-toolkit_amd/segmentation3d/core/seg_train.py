@@ -1,0 +1,122 @@
+"""Training engine -- MI355X-native replacement of the hot loop of the reference's core/seg_train.py:110-127
+(zero_grad -> net(crops) -> loss(outputs, masks) -> backward -> Adam step) and of its `nn.DataParallel` wrap (:76-78).
+
+`TrainStep` is the unit both `train()` and bench.py drive: one process per GPU, the network's 3-D conv / GroupNorm /
+loss / Adam arithmetic in HIP kernels, gradients exchanged with a bucketed RCCL all-reduce overlapped with backward
+(core/ddp.py) when torch.distributed is initialised.
+"""
+import importlib
+import os
+import shutil
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from segmentation3d.core.ddp import GradientReducer
+from segmentation3d.loss.cross_entropy_loss import CrossEntropyLoss
+from segmentation3d.loss.focal_loss import FocalLoss
+from segmentation3d.loss.multi_dice_loss import MultiDiceLoss
+from segmentation3d.optim.fused_adam import FusedAdam
+
+
+def build_loss(name, num_classes, obj_weight=None, focal_gamma=2, use_gpu=True):
+    """loss selection of core/seg_train.py:91-102"""
+    if name == 'Focal':
+        return FocalLoss(class_num=num_classes, alpha=obj_weight, gamma=focal_gamma, use_gpu=use_gpu)
+    if name == 'Dice':
+        weights = obj_weight if obj_weight is not None else [1.0 / num_classes] * num_classes
+        return MultiDiceLoss(weights=weights, num_class=num_classes, use_gpu=use_gpu)
+    if name == 'CE':
+        return CrossEntropyLoss()
+    raise ValueError('Unknown loss function')
+
+
+class TrainStep(object):
+    """network + loss + FusedAdam (+ gradient reducer when distributed) on one device"""
+
+    def __init__(self, net_name, in_channels, num_classes, loss_name='Dice', obj_weight=None, focal_gamma=2, lr=1e-4,
+                 betas=(0.9, 0.999), device=None, seed=0, distributed=None, num_buckets=4):
+        self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        net_module = importlib.import_module('segmentation3d.network.' + net_name)      # core/seg_train.py:72
+        torch.manual_seed(seed)
+        self.net = net_module.SegmentationNet(in_channels, num_classes)
+        self.max_stride = self.net.max_stride()
+        net_module.parameters_kaiming_init(self.net)                                    # core/seg_train.py:75
+        self.net = self.net.to(self.device)
+        self.opt = FusedAdam(self.net.parameters(), lr=lr, betas=betas)                 # core/seg_train.py:83
+        self.loss_func = build_loss(loss_name, num_classes, obj_weight, focal_gamma, use_gpu=True)
+        if distributed is None:
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.reducer = None
+        if distributed:
+            self.reducer = GradientReducer(self.opt.flat_grads(), self.opt.flat_layout(), num_buckets=num_buckets)
+            self.reducer.broadcast_parameters([f['params'] for f in self.opt._flat if f is not None], src=0)
+            self.opt.grad_scale = 1.0 / self.reducer.world_size
+
+    def __call__(self, crops, masks):
+        """one optimisation step; returns the (device) loss tensor of this rank's batch"""
+        self.opt.zero_grad()
+        if self.reducer is not None:
+            self.reducer.begin_step()
+        outputs = self.net(crops)
+        loss = self.loss_func(outputs, masks)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish_step()
+        self.opt.step()
+        return loss
+
+
+def train(train_config_file, data_iter_factory=None):
+    """training engine with the reference's config schema (config/train_config.py) and checkpoint layout.
+
+    The reference's `SegmentationDataset` (SimpleITK resampling crops, dataloader/dataset.py) is outside this round's
+    scope; pass `data_iter_factory(cfg) -> iterator of (crops, masks)` device or host float tensors.  Everything
+    else -- model folder, config copies, seeding, loss selection, logging format, checkpoint cadence -- follows
+    core/seg_train.py:22-152.
+    """
+    from segmentation3d.utils.file_io import load_config, setup_logger
+    from segmentation3d.utils.model_io import load_checkpoint, save_checkpoint
+    assert os.path.isfile(train_config_file), 'Config not found: {}'.format(train_config_file)
+    cfg = load_config(train_config_file)
+    model_folder = os.path.join(cfg.general.save_dir, cfg.general.model_scale)
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    if rank == 0:
+        if os.path.isdir(model_folder) and cfg.general.resume_epoch < 0:
+            shutil.rmtree(model_folder)
+        os.makedirs(model_folder, exist_ok=True)
+        shutil.copy(train_config_file, os.path.join(model_folder, 'train_config.py'))
+        infer_cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'config', 'infer_config.py')
+        if os.path.isfile(infer_cfg):
+            shutil.copy(infer_cfg, os.path.join(cfg.general.save_dir, 'infer_config.py'))
+    logger = setup_logger(os.path.join(model_folder, 'train_log.txt'), 'seg3d') if rank == 0 else None
+    np.random.seed(cfg.general.seed)
+    if cfg.general.num_gpus <= 0:
+        raise RuntimeError('segmentation3d HIP engine needs general.num_gpus > 0 (no CPU training path)')
+    num_modality = int(getattr(cfg.dataset, 'num_modality', 1))
+    step = TrainStep(cfg.net.name, num_modality, cfg.dataset.num_classes, cfg.loss.name, cfg.loss.obj_weight,
+                     cfg.loss.focal_gamma, cfg.train.lr, tuple(cfg.train.betas), seed=cfg.general.seed)
+    assert np.all(np.array(cfg.dataset.crop_size) % step.max_stride == 0), 'crop size not divisible by max stride'
+    last_save_epoch, batch_idx = 0, 0
+    if cfg.general.resume_epoch >= 0:
+        last_save_epoch, batch_idx = load_checkpoint(cfg.general.resume_epoch, step.net, step.opt, model_folder)
+    if data_iter_factory is None:
+        raise NotImplementedError('the SimpleITK crop dataset is not part of this round; pass data_iter_factory')
+    num_samples = int(getattr(cfg.dataset, 'num_samples', cfg.train.batchsize))
+    for crops, masks in data_iter_factory(cfg):
+        begin_t = time.time()
+        crops, masks = crops.to(step.device, non_blocking=True), masks.to(step.device, non_blocking=True)
+        loss = step(crops, masks)
+        epoch_idx = batch_idx * cfg.train.batchsize // num_samples
+        batch_idx += 1
+        value = loss.item()
+        sample_duration = (time.time() - begin_t) / cfg.train.batchsize
+        if logger is not None:
+            logger.info('epoch: {}, batch: {}, train_loss: {:.4f}, time: {:.4f} s/vol'.format(epoch_idx, batch_idx, value,
+                                                                                             sample_duration))
+        if rank == 0 and epoch_idx != 0 and epoch_idx % cfg.train.save_epochs == 0 and last_save_epoch != epoch_idx:
+            save_checkpoint(step.net, step.opt, epoch_idx, batch_idx, cfg, step.max_stride, num_modality)
+            last_save_epoch = epoch_idx
+    return step

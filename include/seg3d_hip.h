@@ -72,6 +72,18 @@ long long seg3d_conv3d_k3_mfma_wgrad_workspace_floats(int N, int D, int H, int W
 int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H, int W,
                                int Cin, int Cout, void* stream);
 
+/* fp32 MFMA path for the stride-2 2x2x2 layers (Cin % 4 == 0): gather = Conv3d k2s2 forward / ConvTranspose3d dgrad,
+ * scatter = ConvTranspose3d k2s2 forward / Conv3d k2s2 dgrad, pair-reduce = weight gradient of both */
+long long seg3d_conv3d_k2s2_mfma_stats_count(int Do, int Ho, int Wo, int Cout);
+int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp_mfma, const float* bias, float* y, float* stats_partial,
+                               int N, int Do, int Ho, int Wo, int Cin, int Cout, void* stream);
+long long seg3d_convT3d_k2s2_mfma_stats_count(int Di, int Hi, int Wi, int Cout);
+int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp_mfma, const float* bias, float* y, float* stats_partial,
+                                int N, int Di, int Hi, int Wi, int Cin, int Cout, void* stream);
+long long seg3d_k2_mfma_wgrad_workspace_floats(int N, int Dq, int Hq, int Wq, int CA, int CB);
+int seg3d_k2_mfma_wgrad(const float* P, const float* Q, float* dw, float* workspace, int N, int Dq, int Hq, int Wq, int CA,
+                        int CB, long long sa, long long sb, void* stream);
+
 /* ---- GroupNorm(1, C) [+ ReLU] [+ residual]  (network/module/conv_gn_relu3.py:11,14; residual_block3.py:24,46) ------ */
 long long seg3d_gn_stats_count(long long M);
 int seg3d_gn_stats_partial(const float* y, float* part, int N, long long M, void* stream);

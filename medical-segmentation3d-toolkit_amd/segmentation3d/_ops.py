@@ -101,6 +101,39 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats):
     return y, None
 
 
+def _k2_gather(xn, w, bias, y, A, B, sa, sb, want_stats):
+    """y[v][b] = bias[b] + sum_{t,a} x[2v + t][a] W(a,b,t) on the matrix cores; y preallocated [N,Do,Ho,Wo,B]"""
+    N, Do, Ho, Wo, _ = y.shape
+    wp = _pack_mfma(w, A, B, 8, sa, sb)
+    stats = None
+    if want_stats:
+        stats = _empty((N, E.query('seg3d_conv3d_k2s2_mfma_stats_count', Do, Ho, Wo, B), 2), xn)
+    E.call('seg3d_conv3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho, Wo, A, B,
+           E.stream_ptr())
+    return y, stats
+
+
+def _k2_scatter(xn, w, bias, y, A, B, sa, sb, want_stats):
+    """y[2i + t][b] = bias[b] + sum_a x[i][a] W(a,b,t) on the matrix cores; y preallocated [N,2D,2H,2W,B]"""
+    N, D, H, W_, _ = xn.shape
+    wp = _pack_mfma(w, A, B, 8, sa, sb)
+    stats = None
+    if want_stats:
+        stats = _empty((N, E.query('seg3d_convT3d_k2s2_mfma_stats_count', D, H, W_, B), 2), xn)
+    E.call('seg3d_convT3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
+           E.stream_ptr())
+    return y, stats
+
+
+def _k2_wgrad(P, Q, CA, CB, out_shape, sa, sb):
+    """dW(t,a,b) = sum_v P[2v + t][a] Q[v][b] on the matrix cores, written to dw[a*sa + b*sb + t]"""
+    N, Dq, Hq, Wq, _ = Q.shape
+    ws = _empty((E.query('seg3d_k2_mfma_wgrad_workspace_floats', N, Dq, Hq, Wq, CA, CB),), P)
+    dw = _empty(out_shape, P)
+    E.call('seg3d_k2_mfma_wgrad', E.ptr(P), E.ptr(Q), E.ptr(dw), E.ptr(ws), N, Dq, Hq, Wq, CA, CB, sa, sb, E.stream_ptr())
+    return dw
+
+
 def conv_forward(xn, w, bias, kind, want_stats=False):
     """xn: [N,D,H,W,Cin] contiguous; w in the reference layout; returns (y NDHWC, stats_partial or None)"""
     ks, stride, T, transposed = _KINDS[kind]
@@ -114,8 +147,10 @@ def conv_forward(xn, w, bias, kind, want_stats=False):
         _check_w(w, (Cout, Cin, 2, 2, 2), kind)
         if D % 2 or H % 2 or W_ % 2:
             raise ValueError('Conv3d k2 s2 needs even spatial dims, got {}'.format((D, H, W_)))
-        wp = _pack_tapmajor(w, Cin, Cout, 8, 8, Cin * 8)
         y = _empty((N, D // 2, H // 2, W_ // 2, Cout), xn)
+        if _use_mfma(Cin, Cout):
+            return _k2_gather(xn, w, bias, y, Cin, Cout, 8, Cin * 8, want_stats)
+        wp = _pack_tapmajor(w, Cin, Cout, 8, 8, Cin * 8)
         E.call('seg3d_conv3d_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout, 2, 2,
                E.stream_ptr())
         return y, None
@@ -130,8 +165,10 @@ def conv_forward(xn, w, bias, kind, want_stats=False):
     if kind == 'convT':
         Cout = w.shape[1]
         _check_w(w, (Cin, Cout, 2, 2, 2), kind)
-        wp = _pack_tapmajor(w, Cin, Cout, 8, Cout * 8, 8)
         y = _empty((N, 2 * D, 2 * H, 2 * W_, Cout), xn)
+        if _use_mfma(Cin, Cout):
+            return _k2_scatter(xn, w, bias, y, Cin, Cout, Cout * 8, 8, want_stats)
+        wp = _pack_tapmajor(w, Cin, Cout, 8, Cout * 8, 8)
         E.call('seg3d_convT3d_k2s2_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout,
                E.stream_ptr())
         return y, None
@@ -156,8 +193,10 @@ def conv_dgrad(dyn, w, kind):
     if kind == 'k2s2':
         Cout, Cin = w.shape[0], w.shape[1]
         # dx[2v + t][ci] = sum_co dy[v][co] w[co][ci][t]  == transposed conv of dy
-        wp = _pack_tapmajor(w, Cout, Cin, 8, Cin * 8, 8)
         dx = _empty((N, 2 * D, 2 * H, 2 * W_, Cin), dyn)
+        if _use_mfma(Cout, Cin):
+            return _k2_scatter(dyn, w, None, dx, Cout, Cin, Cin * 8, 8, False)[0]
+        wp = _pack_tapmajor(w, Cout, Cin, 8, Cin * 8, 8)
         E.call('seg3d_convT3d_k2s2_fwd_direct', E.ptr(dyn), E.ptr(wp), None, E.ptr(dx), N, D, H, W_, Cout, Cin,
                E.stream_ptr())
         return dx
@@ -171,8 +210,10 @@ def conv_dgrad(dyn, w, kind):
     if kind == 'convT':
         Cin, Cout = w.shape[0], w.shape[1]
         # dx[i][ci] = sum_{t,co} dy[2i + t][co] w[ci][co][t]  == k2 s2 conv of dy
-        wp = _pack_tapmajor(w, Cout, Cin, 8, 8, Cout * 8)
         dx = _empty((N, D // 2, H // 2, W_ // 2, Cin), dyn)
+        if _use_mfma(Cout, Cin):
+            return _k2_gather(dyn, w, None, dx, Cout, Cin, 8, Cout * 8, False)[0]
+        wp = _pack_tapmajor(w, Cout, Cin, 8, 8, Cout * 8)
         E.call('seg3d_conv3d_fwd_direct', E.ptr(dyn), E.ptr(wp), None, E.ptr(dx), N, D, H, W_, Cout, Cin, 2, 2,
                E.stream_ptr())
         return dx
@@ -207,6 +248,8 @@ def conv_wgrad(xn, dyn, w_shape, kind):
         return _wgrad_direct(xn, dyn, Cin, Cout, 3, 1, 27, w_shape, 27, Cin * 27)
     if kind == 'k2s2':
         Cout, Cin = w_shape[0], w_shape[1]
+        if _use_mfma(Cin, Cout) and Cout % 4 == 0:
+            return _k2_wgrad(xn, dyn, Cin, Cout, w_shape, 8, Cin * 8)
         return _wgrad_direct(xn, dyn, Cin, Cout, 2, 2, 8, w_shape, 8, Cin * 8)
     if kind == 'k1':
         Cout, Cin = w_shape[0], w_shape[1]
@@ -214,6 +257,8 @@ def conv_wgrad(xn, dyn, w_shape, kind):
     if kind == 'convT':
         Cin, Cout = w_shape[0], w_shape[1]
         # dW(t, a=co, b=ci) = sum_i dy[2i + t][co] x[i][ci]  -> w[ci][co][t]
+        if _use_mfma(Cin, Cout) and Cout % 4 == 0:
+            return _k2_wgrad(dyn, xn, Cout, Cin, w_shape, 8, Cout * 8)
         return _wgrad_direct(dyn, xn, Cout, Cin, 2, 2, 8, w_shape, 8, Cout * 8)
     raise ValueError('unknown conv kind {}'.format(kind))
 

@@ -72,15 +72,20 @@ def test_conv3d_k3_mfma_stats_partials(hip_device):
     assert rel_err(s[:, 0], yy.sum(1)) < 1e-5 and rel_err(s[:, 1], (yy * yy).sum(1)) < 1e-5
 
 
+@pytest.mark.parametrize('force_direct', [False, True])
 @pytest.mark.parametrize('kind,cin,cout,dims', [
     ('k2s2', 16, 32, (2, 8, 8, 8)), ('k2s2', 1, 16, (1, 4, 6, 8)), ('k2s2', 128, 256, (1, 2, 4, 4)),
+    ('k2s2', 32, 64, (1, 6, 10, 12)), ('k2s2', 12, 20, (2, 2, 6, 14)),
     ('convT', 64, 16, (1, 4, 4, 6)), ('convT', 256, 128, (2, 2, 2, 2)), ('convT', 3, 5, (1, 3, 3, 3)),
+    ('convT', 128, 32, (1, 3, 5, 7)), ('convT', 16, 24, (2, 5, 4, 9)),
     ('k1', 2, 2, (2, 8, 8, 8)), ('k1', 5, 5, (1, 4, 4, 4)), ('k1', 16, 8, (1, 4, 4, 4)),
 ])
-def test_strided_convs_fwd_bwd(hip_device, kind, cin, cout, dims):
+def test_strided_convs_fwd_bwd(hip_device, kind, cin, cout, dims, force_direct):
     from segmentation3d import _ops
     N, D, H, W = dims
-    name = 'conv_{}_{}_{}_{}'.format(kind, cin, cout, '_'.join(map(str, dims)))
+    if force_direct and (kind == 'k1' or cin < 8):
+        pytest.skip('already the direct path')
+    name = 'conv_{}_{}_{}_{}_{}'.format(kind, 'direct' if force_direct else 'auto', cin, cout, '_'.join(map(str, dims)))
     x = _t(11, name + 'x', (N, cin, D, H, W)).requires_grad_(True)
     if kind == 'convT':
         w = _t(12, name + 'w', (cin, cout, 2, 2, 2), std=(1.0 / cin) ** 0.5).requires_grad_(True)
@@ -96,11 +101,23 @@ def test_strided_convs_fwd_bwd(hip_device, kind, cin, cout, dims):
     g = _t(14, name + 'g', tuple(ref.shape))
     rdx, rdw, rdb = torch.autograd.grad(ref, (x, w, b), g)
     xd, wd, bd = (t.detach().to(hip_device).requires_grad_(True) for t in (x, w, b))
-    out = _ops.conv(xd, wd, bd, kind)
-    dx, dw, db = torch.autograd.grad(out, (xd, wd, bd), g.to(hip_device))
+    _ops.FORCE_DIRECT = force_direct
+    try:
+        out = _ops.conv(xd, wd, bd, kind)
+        dx, dw, db = torch.autograd.grad(out, (xd, wd, bd), g.to(hip_device))
+        # the fused unit also consumes the conv-epilogue GroupNorm statistics of the strided kernels
+        yn, part = _ops.conv_forward(_ops.to_ndhwc(xd.detach()), wd.detach(), bd.detach(), kind, want_stats=True)
+    finally:
+        _ops.FORCE_DIRECT = False
     e = dict(out=max_err(out, ref), dx=rel_err(dx, rdx), dw=rel_err(dw, rdw), db=rel_err(db, rdb))
+    if part is not None:
+        s = part.double().sum(1).cpu()
+        yy = ref.detach().double().reshape(N, -1)
+        e['stat_sum'] = float(((s[:, 0] - yy.sum(1)).abs() / (yy.abs().sum(1) + 1e-30)).max())
+        e['stat_sq'] = rel_err(s[:, 1], (yy * yy).sum(1))
     report(name, **e)
     assert e['out'] < 1e-4 and e['dx'] < 1e-4 and e['dw'] < 2e-4 and e['db'] < 1e-4, e
+    assert e.get('stat_sum', 0.0) < 1e-5 and e.get('stat_sq', 0.0) < 1e-5, e
 
 
 @pytest.mark.parametrize('C,dims,relu,with_res', [

@@ -84,6 +84,22 @@ long long seg3d_k2_mfma_wgrad_workspace_floats(int N, int Dq, int Hq, int Wq, in
 int seg3d_k2_mfma_wgrad(const float* P, const float* Q, float* dw, float* workspace, int N, int Dq, int Hq, int Wq, int CA,
                         int CB, long long sa, long long sb, void* stream);
 
+/* thin 3x3x3 layers at full resolution (stem Cin <= 8 -> 16, head 32 -> num_classes <= 8): HBM-bound special cases
+ * of Conv3d k3 p1 (vnet_inblock.py:9, vnet_outblock.py:13) and of their autograd adjoints */
+long long seg3d_packed_thin_in_floats(int CT, int B);
+int seg3d_pack_weights_thin_in(const float* w, float* wp, int CT, int B, long long sa, long long sb, int flip, void* stream);
+long long seg3d_conv3d_k3_thin_stats_count(int D, int H, int W, int Cout_blocks);
+int seg3d_conv3d_k3_thin_in_fwd(const float* x, const float* wp_thin, const float* bias, float* y, float* stats_partial,
+                                int N, int D, int H, int W, int CT, int Cout, void* stream);
+int seg3d_pack_weights_thin_out(const float* w, float* wq, int A, int B, int CO, long long sa, long long sb, int flip,
+                                void* stream);
+long long seg3d_conv3d_k3_thin_out_stats_count(int D, int H, int W);
+int seg3d_conv3d_k3_thin_out_fwd(const float* x, const float* wq, const float* bias, float* y, float* stats_partial, int N,
+                                 int D, int H, int W, int Cin, int Cout, int CO, void* stream);
+long long seg3d_k3_thin_wgrad_workspace_floats(int N, int D, int H, int W, int CT, int CF);
+int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* dw, float* workspace, int N, int D, int H, int W, int CT,
+                        int CF, long long s_ct, long long s_cf, int flip, void* stream);
+
 /* ---- GroupNorm(1, C) [+ ReLU] [+ residual]  (network/module/conv_gn_relu3.py:11,14; residual_block3.py:24,46) ------ */
 long long seg3d_gn_stats_count(long long M);
 int seg3d_gn_stats_partial(const float* y, float* part, int N, long long M, void* stream);

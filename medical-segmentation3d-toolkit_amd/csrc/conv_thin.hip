@@ -1,0 +1,563 @@
+// conv_thin.hip -- the two "thin" 3x3x3 layers at full resolution, which are HBM-bound, not FLOP-bound
+// (stem AI 12.7 FLOP/B, head AI 25 FLOP/B):
+//   stem  InputBlock.conv   Conv3d(in_channels 1..4 -> 16, k3 p1)      network/module/vnet_inblock.py:9
+//   head  OutputBlock.conv1 Conv3d(32 -> num_classes, k3 p1)           network/module/vnet_outblock.py:13
+// One side of each has only a handful of channels, so the generic implicit GEMM of conv_mfma.hip would waste
+// 8-16x of its MFMA rows/columns.  Three kernels cover forward, data-gradient and weight-gradient of both:
+//
+//   thin-in  (conv3d_k3_thin_in_kernel, MFMA):   y[v][b] = bias[b] + sum_{t, a < CT} x[v + t][a] W(a, b, t)
+//       K = 27*CT <= 216 is folded into ONE GEMM K dimension: lane l supplies A[voxel][k] = x[v + off(t_k)][a_k] with a
+//       per-lane LDS offset, the weights for all K live in registers (<= 108 VGPRs).  = stem forward, head dgrad.
+//   thin-out (conv3d_k3_thin_out_kernel, VALU):  y[v][b < CO] = bias[b] + sum_{t, a} x[v + t][a] W(a, b, t)
+//       LDS-tiled direct form, 2 voxels x CO outputs per thread, weights broadcast from LDS.  = head forward
+//       (and stem dgrad).  12 GFLOP over 453 MB: the VALU keeps up with HBM here.
+//   thin wgrad (k3_thin_wgrad_kernel, MFMA):     G[t][ct][cf] = sum_u fat[u][cf] * thin[u + off(t)][ct]
+//       rows = (tap, thin channel) gathered per lane, columns = fat channels, K = voxels split over the 4 waves.
+//       = stem wgrad (thin = x, fat = dy) and head wgrad (thin = dy, fat = x, taps reversed).
+// All three emit / consume NDHWC fp32 and, where they produce a conv output, the GroupNorm partial statistics.
+#include "seg3d_common.h"
+#include "seg3d_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int thin_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// fixed output tile of the thin kernels: 4 x 8 x 8 = 256 voxels (2 MFMA row blocks per wave), halo tile 6 x 10 x 10
+#define TH_TZ 4
+#define TH_TY 8
+#define TH_TX 8
+#define TH_MT (TH_TZ * TH_TY * TH_TX)
+#define TH_HY (TH_TY + 2)
+#define TH_HX (TH_TX + 2)
+#define TH_NV ((TH_TZ + 2) * TH_HY * TH_HX)  // 600
+
+// ---- weight packer for the thin-in kernel: wp[bb][p][h][j] = W(a = k % CT, b = bb*32 + j, t = k / CT), k = 2p + h ----
+__global__ __launch_bounds__(256) void pack_thin_in_kernel(const float* __restrict__ w, float* __restrict__ wp, int CT,
+                                                             int B, int BB, int KP, i64 sa, i64 sb, int flip) {
+  const i64 total = (i64)BB * KP * 64;
+  for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+    const int j = (int)(idx & 31);
+    const int h = (int)((idx >> 5) & 1);
+    const i64 r = idx >> 6;
+    const int p = (int)(r % KP);
+    const int bb = (int)(r / KP);
+    const int k = 2 * p + h;
+    const int t = k / CT, a = k % CT;
+    const int b = bb * 32 + j;
+    float v = 0.f;
+    if (t < 27 && b < B) v = w[a * sa + b * sb + (flip ? 26 - t : t)];
+    wp[idx] = v;
+  }
+}
+
+extern "C" long long seg3d_packed_thin_in_floats(int CT, int B) {
+  return (long long)((B + 31) / 32) * ((27 * CT + 1) / 2) * 64;
+}
+
+extern "C" int seg3d_pack_weights_thin_in(const float* w, float* wp, int CT, int B, long long sa, long long sb, int flip,
+                                          void* stream) {
+  SEG3D_REQUIRE(w && wp && CT >= 1 && CT <= 8 && B > 0, "seg3d_pack_weights_thin_in: bad arguments (1 <= CT <= 8)");
+  const int KP = (27 * CT + 1) / 2, BB = (B + 31) / 32;
+  const i64 total = (i64)BB * KP * 64;
+  hipLaunchKernelGGL(pack_thin_in_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, CT, B,
+                     BB, KP, (i64)sa, (i64)sb, flip);
+  SEG3D_LAUNCH_CHECK("seg3d_pack_weights_thin_in");
+  return SEG3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// thin-in forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int CT>
+__device__ __forceinline__ int thin_koff(int k) {  // LDS float offset of GEMM-k inside the halo tile
+  const int t = k / CT, a = k % CT;
+  const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+  return t < 27 ? ((kz * TH_HY + ky) * TH_HX + kx) * CT + a : 0;
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ wp,
+                                                                     const float* __restrict__ bias,
+                                                                     float* __restrict__ y, float* __restrict__ stats,
+                                                                     int N, int D, int H, int W, int Cout, int ntz,
+                                                                     int nty, int ntx) {
+  constexpr int KP = (27 * CT + 1) / 2;
+  __shared__ __attribute__((aligned(16))) float xs[TH_NV * CT + 4];
+  __shared__ int voff[TH_MT];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cob = blockIdx.y;
+  int b = blockIdx.x;
+  const int tix = b % ntx; b /= ntx;
+  const int tiy = b % nty; b /= nty;
+  const int tiz = b % ntz;
+  const int n = b / ntz;
+  const int z0 = tiz * TH_TZ, y0 = tiy * TH_TY, x0 = tix * TH_TX;
+
+  // weights of this lane's column for every k-pair, kept in registers
+  float bw[KP];
+  {
+    const float* wsrc = wp + ((i64)cob * KP * 2 + lh) * 32 + li;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) bw[p] = wsrc[p * 64];
+  }
+  for (int e = tid; e < TH_NV * CT; e += 256) {
+    const int v = e / CT, a = e % CT;
+    const int hx = v % TH_HX;
+    const int t = v / TH_HX;
+    const int hy = t % TH_HY;
+    const int hz = t / TH_HY;
+    const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+    float val = 0.f;
+    if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+      val = x[((((i64)n * D + gz) * H + gy) * W + gx) * CT + a];
+    xs[e] = val;
+  }
+  {
+    const int tx = tid % TH_TX;
+    const int t = tid / TH_TX;
+    const int ty = t % TH_TY;
+    const int tz = t / TH_TY;
+    const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
+    voff[tid] = (gz < D && gy < H && gx < W) ? ((n * D + gz) * H + gy) * W + gx : -1;
+  }
+  int abase[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int idx = (wave + 4 * m) * 32 + li;
+    const int tx = idx % TH_TX;
+    const int t = idx / TH_TX;
+    const int ty = t % TH_TY;
+    const int tz = t / TH_TY;
+    abase[m] = ((tz * TH_HY + ty) * TH_HX + tx) * CT;
+  }
+  __syncthreads();
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+  for (int p = 0; p < KP; ++p) {
+    const int koff = lh ? thin_koff<CT>(2 * p + 1) : thin_koff<CT>(2 * p);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[abase[m] + koff], bw[p], acc[m], 0, 0, 0);
+  }
+
+  const int co = cob * 32 + li;
+  const bool co_ok = co < Cout;
+  const float bv = (bias && co_ok) ? bias[co] : 0.f;
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int vo = voff[(wave + 4 * m) * 32 + thin_row(r, lh)];
+      if (vo >= 0 && co_ok) {
+        const float val = acc[m][r] + bv;
+        y[(i64)vo * Cout + co] = val;
+        s[0] += val;
+        s[1] += val * val;
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    block_sum_256<2>(s, xs);
+    if (tid == 0) {
+      const int tiles_per_sample = ntz * nty * ntx;
+      const int tile = (tiz * nty + tiy) * ntx + tix;
+      float* dst = stats + (((i64)n * tiles_per_sample + tile) * gridDim.y + cob) * 2;
+      dst[0] = s[0];
+      dst[1] = s[1];
+    }
+  }
+}
+
+extern "C" long long seg3d_conv3d_k3_thin_stats_count(int D, int H, int W, int Cout_blocks) {
+  return (long long)seg3d_cdiv(D, TH_TZ) * seg3d_cdiv(H, TH_TY) * seg3d_cdiv(W, TH_TX) * Cout_blocks;
+}
+
+template <int CT>
+static void launch_thin_in(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
+                           int W, int Cout, hipStream_t s) {
+  const int ntz = seg3d_cdiv(D, TH_TZ), nty = seg3d_cdiv(H, TH_TY), ntx = seg3d_cdiv(W, TH_TX);
+  dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
+  hipLaunchKernelGGL((conv3d_k3_thin_in_kernel<CT>), grid, dim3(256), 0, s, x, wp, bias, y, stats, N, D, H, W, Cout, ntz, nty,
+                     ntx);
+}
+
+// x [N][D][H][W][CT] (CT <= 8), wp = seg3d_pack_weights_thin_in, y [N][D][H][W][Cout];
+// stats (optional): [N][seg3d_conv3d_k3_thin_stats_count(D,H,W,ceil(Cout/32))][2]
+extern "C" int seg3d_conv3d_k3_thin_in_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N,
+                                           int D, int H, int W, int CT, int Cout, void* stream) {
+  SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_thin_in_fwd: null pointer");
+  SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "seg3d_conv3d_k3_thin_in_fwd: bad dims");
+  SEG3D_REQUIRE(CT >= 1 && CT <= 8, "seg3d_conv3d_k3_thin_in_fwd: thin channel count %d not in [1, 8]", CT);
+  SEG3D_REQUIRE((i64)N * D * H * W * Cout < (1ll << 31), "seg3d_conv3d_k3_thin_in_fwd: tensor exceeds 2^31 elements");
+  hipStream_t s = (hipStream_t)stream;
+  switch (CT) {
+    case 1: launch_thin_in<1>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
+    case 2: launch_thin_in<2>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
+    case 3: launch_thin_in<3>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
+    case 4: launch_thin_in<4>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
+    case 5: launch_thin_in<5>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
+    case 6: launch_thin_in<6>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
+    case 7: launch_thin_in<7>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
+    default: launch_thin_in<8>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
+  }
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_thin_in_fwd");
+  return SEG3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// thin-out forward (VALU): tile 4 x 8 x 16 = 512 voxels, 2 voxels per thread, 8 input channels per LDS chunk
+// ---------------------------------------------------------------------------------------------------------------
+#define TO_TZ 4
+#define TO_TY 8
+#define TO_TX 16
+#define TO_HY (TO_TY + 2)
+#define TO_HX (TO_TX + 2)
+#define TO_NV ((TO_TZ + 2) * TO_HY * TO_HX)  // 1080
+#define TO_E ((2 * TO_NV + 255) / 256)       // 9 float4 per thread per chunk
+
+// weights: wq[cib][tap][8][CO] (tap-major inside an 8-channel chunk), zero padded
+__global__ __launch_bounds__(256) void pack_thin_out_kernel(const float* __restrict__ w, float* __restrict__ wq, int A, int B,
+                                                              int CO, int AB, i64 sa, i64 sb, int flip) {
+  const i64 total = (i64)AB * 27 * 8 * CO;
+  for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+    const int b = (int)(idx % CO);
+    i64 r = idx / CO;
+    const int a8 = (int)(r % 8);
+    r /= 8;
+    const int t = (int)(r % 27);
+    const int ab = (int)(r / 27);
+    const int a = ab * 8 + a8;
+    float v = 0.f;
+    if (a < A && b < B) v = w[a * sa + b * sb + (flip ? 26 - t : t)];
+    wq[idx] = v;
+  }
+}
+
+extern "C" int seg3d_pack_weights_thin_out(const float* w, float* wq, int A, int B, int CO, long long sa, long long sb,
+                                           int flip, void* stream) {
+  SEG3D_REQUIRE(w && wq && A > 0 && B > 0 && B <= CO && (CO == 2 || CO == 4 || CO == 8),
+                "seg3d_pack_weights_thin_out: bad arguments (CO in {2,4,8}, B <= CO)");
+  const int AB = (A + 7) / 8;
+  const i64 total = (i64)AB * 27 * 8 * CO;
+  hipLaunchKernelGGL(pack_thin_out_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wq, A, B,
+                     CO, AB, (i64)sa, (i64)sb, flip);
+  SEG3D_LAUNCH_CHECK("seg3d_pack_weights_thin_out");
+  return SEG3D_OK;
+}
+
+template <int CO>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float* __restrict__ x,
+                                                                      const float* __restrict__ wq,
+                                                                      const float* __restrict__ bias,
+                                                                      float* __restrict__ y, float* __restrict__ stats,
+                                                                      int N, int D, int H, int W, int Cin, int Cout,
+                                                                      int ntz, int nty, int ntx) {
+  __shared__ __attribute__((aligned(16))) float xs[8 * TO_NV];      // [2][NV][4]
+  __shared__ __attribute__((aligned(16))) float ws[27 * 8 * CO];    // [tap][8][CO]
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tix = b % ntx; b /= ntx;
+  const int tiy = b % nty; b /= nty;
+  const int tiz = b % ntz;
+  const int n = b / ntz;
+  const int z0 = tiz * TO_TZ, y0 = tiy * TO_TY, x0 = tix * TO_TX;
+  const int CIB = (Cin + 7) >> 3;
+  const int hh = tid & 1;
+  int goff[TO_E];
+#pragma unroll
+  for (int e = 0; e < TO_E; ++e) {
+    const int eidx = tid + e * 256;
+    goff[e] = -1;
+    if (eidx < 2 * TO_NV) {
+      const int v = eidx >> 1;
+      const int hx = v % TO_HX;
+      const int t = v / TO_HX;
+      const int hy = t % TO_HY;
+      const int hz = t / TO_HY;
+      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+      if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        goff[e] = (((n * D + gz) * H + gy) * W + gx) * Cin + hh * 4;
+    }
+  }
+  // this thread's two output voxels: (tz, ty, tx) and (tz + 2, ty, tx)
+  const int tx = tid & 15, ty = (tid >> 4) & 7, tz = tid >> 7;
+  const int vb0 = ((tz * TO_HY + ty) * TO_HX + tx) * 4;
+  const int vb1 = (((tz + 2) * TO_HY + ty) * TO_HX + tx) * 4;
+  float acc0[CO], acc1[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
+
+  for (int cib = 0; cib < CIB; ++cib) {
+    __syncthreads();
+    const bool half_ok = cib * 8 + hh * 4 < Cin;
+#pragma unroll
+    for (int e = 0; e < TO_E; ++e) {
+      const int eidx = tid + e * 256;
+      if (eidx < 2 * TO_NV) {
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (goff[e] >= 0 && half_ok) val = *reinterpret_cast<const f32x4*>(x + (i64)goff[e] + cib * 8);
+        *reinterpret_cast<f32x4*>(xs + (hh * TO_NV + (eidx >> 1)) * 4) = val;
+      }
+    }
+    for (int k = tid; k < 27 * 8 * CO; k += 256) ws[k] = wq[(i64)cib * 27 * 8 * CO + k];
+    __syncthreads();
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tap = (kz * 3 + ky) * 3 + kx;
+          const int tapoff = ((kz * TO_HY + ky) * TO_HX + kx) * 4;
+          const f32x4 a00 = *reinterpret_cast<const f32x4*>(xs + vb0 + tapoff);
+          const f32x4 a01 = *reinterpret_cast<const f32x4*>(xs + TO_NV * 4 + vb0 + tapoff);
+          const f32x4 a10 = *reinterpret_cast<const f32x4*>(xs + vb1 + tapoff);
+          const f32x4 a11 = *reinterpret_cast<const f32x4*>(xs + TO_NV * 4 + vb1 + tapoff);
+          const float* wt = ws + tap * 8 * CO;
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+              acc0[c] = fmaf(a00[a], wt[a * CO + c], acc0[c]);
+              acc1[c] = fmaf(a10[a], wt[a * CO + c], acc1[c]);
+            }
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+              acc0[c] = fmaf(a01[a], wt[(4 + a) * CO + c], acc0[c]);
+              acc1[c] = fmaf(a11[a], wt[(4 + a) * CO + c], acc1[c]);
+            }
+        }
+  }
+  float s[2] = {0.f, 0.f};
+  const int gy = y0 + ty, gx = x0 + tx;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int gz = z0 + tz + 2 * m;
+    if (gz < D && gy < H && gx < W) {
+      float* yp = y + ((((i64)n * D + gz) * H + gy) * W + gx) * Cout;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        if (c < Cout) {
+          const float val = (m ? acc1[c] : acc0[c]) + (bias ? bias[c] : 0.f);
+          yp[c] = val;
+          s[0] += val;
+          s[1] += val * val;
+        }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    block_sum_256<2>(s, xs);
+    if (tid == 0) {
+      const int tiles_per_sample = ntz * nty * ntx;
+      const int tile = (tiz * nty + tiy) * ntx + tix;
+      float* dst = stats + ((i64)n * tiles_per_sample + tile) * 2;
+      dst[0] = s[0];
+      dst[1] = s[1];
+    }
+  }
+}
+
+extern "C" long long seg3d_conv3d_k3_thin_out_stats_count(int D, int H, int W) {
+  return (long long)seg3d_cdiv(D, TO_TZ) * seg3d_cdiv(H, TO_TY) * seg3d_cdiv(W, TO_TX);
+}
+
+// x [N][D][H][W][Cin] (Cin % 4 == 0), wq = seg3d_pack_weights_thin_out(CO), y [N][D][H][W][Cout], Cout <= CO <= 8
+extern "C" int seg3d_conv3d_k3_thin_out_fwd(const float* x, const float* wq, const float* bias, float* y, float* stats,
+                                            int N, int D, int H, int W, int Cin, int Cout, int CO, void* stream) {
+  SEG3D_REQUIRE(x && wq && y, "seg3d_conv3d_k3_thin_out_fwd: null pointer");
+  SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k3_thin_out_fwd: bad dims");
+  SEG3D_REQUIRE((Cin % 4) == 0 && Cout <= CO, "seg3d_conv3d_k3_thin_out_fwd: need Cin %% 4 == 0 and Cout <= CO");
+  SEG3D_REQUIRE((i64)N * D * H * W * Cin < (1ll << 31), "seg3d_conv3d_k3_thin_out_fwd: tensor exceeds 2^31 elements");
+  const int ntz = seg3d_cdiv(D, TO_TZ), nty = seg3d_cdiv(H, TO_TY), ntx = seg3d_cdiv(W, TO_TX);
+  dim3 grid((unsigned)(N * ntz * nty * ntx));
+  hipStream_t s = (hipStream_t)stream;
+  if (CO == 2) {
+    hipLaunchKernelGGL((conv3d_k3_thin_out_kernel<2>), grid, dim3(256), 0, s, x, wq, bias, y, stats, N, D, H, W, Cin, Cout, ntz,
+                       nty, ntx);
+  } else if (CO == 4) {
+    hipLaunchKernelGGL((conv3d_k3_thin_out_kernel<4>), grid, dim3(256), 0, s, x, wq, bias, y, stats, N, D, H, W, Cin, Cout, ntz,
+                       nty, ntx);
+  } else if (CO == 8) {
+    hipLaunchKernelGGL((conv3d_k3_thin_out_kernel<8>), grid, dim3(256), 0, s, x, wq, bias, y, stats, N, D, H, W, Cin, Cout, ntz,
+                       nty, ntx);
+  } else {
+    SEG3D_UNSUPPORTED("seg3d_conv3d_k3_thin_out_fwd: CO must be 2, 4 or 8 (got %d)", CO);
+  }
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_thin_out_fwd");
+  return SEG3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// thin weight gradient: G[t][ct][cf] = sum_u fat[u][cf] * thin[u + off(t)][ct]
+// ---------------------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __restrict__ thin, const float* __restrict__ fat,
+                                                                 float* __restrict__ part, int N, int D, int H, int W,
+                                                                 int CF, int ntz, int nty, int ntx, int ntiles) {
+  constexpr int ROWS = 27 * CT;
+  constexpr int RB = (ROWS + 31) / 32;
+  __shared__ __attribute__((aligned(16))) float fs[TH_MT * 32];         // fat tile [256][32]; reused for the wave reduce
+  __shared__ __attribute__((aligned(16))) float ts[TH_NV * CT + 4];     // thin halo tile [600][CT]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int cf0 = blockIdx.y * 32;
+  // per-lane row descriptors
+  int roff[RB];
+  float rmask[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int i = rb * 32 + li;
+    const int t = i / CT, a = i % CT;
+    const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+    roff[rb] = i < ROWS ? ((kz * TH_HY + ky) * TH_HX + kx) * CT + a : 0;
+    rmask[rb] = i < ROWS ? 1.f : 0.f;
+  }
+  f32x16 acc[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+  const int q = tid & 7;
+  const bool fq_ok = cf0 + 4 * q < CF;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tix = b % ntx; b /= ntx;
+    const int tiy = b % nty; b /= nty;
+    const int tiz = b % ntz;
+    const int n = b / ntz;
+    const int z0 = tiz * TH_TZ, y0 = tiy * TH_TY, x0 = tix * TH_TX;
+    __syncthreads();
+    for (int e = tid; e < TH_NV * CT; e += 256) {
+      const int v = e / CT, a = e % CT;
+      const int hx = v % TH_HX;
+      const int t = v / TH_HX;
+      const int hy = t % TH_HY;
+      const int hz = t / TH_HY;
+      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+      float val = 0.f;
+      if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        val = thin[((((i64)n * D + gz) * H + gy) * W + gx) * CT + a];
+      ts[e] = val;
+    }
+#pragma unroll
+    for (int e = 0; e < (TH_MT * 8) / 256; ++e) {
+      const int eidx = tid + e * 256;
+      const int v = eidx >> 3;
+      const int tx = v % TH_TX;
+      const int t = v / TH_TX;
+      const int ty = t % TH_TY;
+      const int tz = t / TH_TY;
+      const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (fq_ok && gz < D && gy < H && gx < W)
+        val = *reinterpret_cast<const f32x4*>(fat + ((((i64)n * D + gz) * H + gy) * W + gx) * CF + cf0 + 4 * q);
+      *reinterpret_cast<f32x4*>(fs + v * 32 + 4 * q) = val;
+    }
+    __syncthreads();
+    // K (voxels) is split over the waves: wave w takes voxels [64w, 64w + 64)
+#pragma unroll 4
+    for (int kp = 0; kp < 32; ++kp) {
+      const int v = wave * 64 + 2 * kp + lh;
+      const int tx = v % TH_TX;
+      const int t = v / TH_TX;
+      const int ty = t % TH_TY;
+      const int tz = t / TH_TY;
+      const int ub = ((tz * TH_HY + ty) * TH_HX + tx) * CT;
+      const float bvv = fs[v * 32 + li];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const float a = ts[ub + roff[rb]] * rmask[rb];
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[rb], 0, 0, 0);
+      }
+    }
+  }
+  // reduce the 4 waves' accumulators through LDS (fixed order) and write this workgroup's slab [RB*32][32]
+  float* dst = part + ((i64)blockIdx.x * gridDim.y + blockIdx.y) * RB * 1024;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fs[wave * 1024 + thin_row(r, lh) * 32 + li] = acc[rb][r];
+    __syncthreads();
+    for (int k = tid; k < 1024; k += 256) dst[rb * 1024 + k] = (fs[k] + fs[1024 + k]) + (fs[2048 + k] + fs[3072 + k]);
+  }
+}
+
+// dw[ct*s_ct + cf*s_cf + (flip ? 26 - t : t)] = sum_slab part[slab][cfb][row = t*CT + ct][cf % 32]
+__global__ __launch_bounds__(256) void k3_thin_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                     int slabs, int CT, int CF, int CFB, int RB, i64 s_ct,
+                                                                     i64 s_cf, int flip) {
+  const i64 total = (i64)27 * CT * CF;
+  for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+    const int cf = (int)(idx % CF);
+    const int row = (int)(idx / CF);
+    const int t = row / CT, ct = row % CT;
+    const float* p = part + ((i64)(cf >> 5) * RB * 1024) + (i64)row * 32 + (cf & 31);
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += p[(i64)k * CFB * RB * 1024];
+    dw[ct * s_ct + cf * s_cf + (flip ? 26 - t : t)] = s;
+  }
+}
+
+static int thin_wgrad_slabs(int N, int D, int H, int W) {
+  const int ntiles = N * seg3d_cdiv(D, TH_TZ) * seg3d_cdiv(H, TH_TY) * seg3d_cdiv(W, TH_TX);
+  return ntiles < 1024 ? ntiles : 1024;
+}
+
+extern "C" long long seg3d_k3_thin_wgrad_workspace_floats(int N, int D, int H, int W, int CT, int CF) {
+  const int RB = (27 * CT + 31) / 32, CFB = (CF + 31) / 32;
+  return (long long)thin_wgrad_slabs(N, D, H, W) * CFB * RB * 1024;
+}
+
+template <int CT>
+static void launch_thin_wgrad(const float* thin, const float* fat, float* part, int N, int D, int H, int W, int CF, int slabs,
+                              hipStream_t s) {
+  const int ntz = seg3d_cdiv(D, TH_TZ), nty = seg3d_cdiv(H, TH_TY), ntx = seg3d_cdiv(W, TH_TX);
+  hipLaunchKernelGGL((k3_thin_wgrad_kernel<CT>), dim3(slabs, (CF + 31) / 32), dim3(256), 0, s, thin, fat, part, N, D, H, W, CF,
+                     ntz, nty, ntx, N * ntz * nty * ntx);
+}
+
+// thin [N][D][H][W][CT] (CT <= 8), fat [N][D][H][W][CF] (CF % 4 == 0); dw[ct*s_ct + cf*s_cf + tap]
+// stem wgrad: thin = x, fat = dy, s_ct = 27, s_cf = Cin*27, flip = 0;  head wgrad: thin = dy, fat = x,
+// s_ct = Cin*27, s_cf = 27, flip = 1.
+extern "C" int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* dw, float* workspace, int N, int D, int H,
+                                   int W, int CT, int CF, long long s_ct, long long s_cf, int flip, void* stream) {
+  SEG3D_REQUIRE(thin && fat && dw && workspace, "seg3d_k3_thin_wgrad: null pointer");
+  SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "seg3d_k3_thin_wgrad: bad dims");
+  SEG3D_REQUIRE(CT >= 1 && CT <= 8 && CF > 0 && (CF % 4) == 0, "seg3d_k3_thin_wgrad: need 1 <= CT <= 8 and CF %% 4 == 0");
+  const int slabs = thin_wgrad_slabs(N, D, H, W);
+  const int RB = (27 * CT + 31) / 32, CFB = (CF + 31) / 32;
+  hipStream_t s = (hipStream_t)stream;
+  switch (CT) {
+    case 1: launch_thin_wgrad<1>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
+    case 2: launch_thin_wgrad<2>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
+    case 3: launch_thin_wgrad<3>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
+    case 4: launch_thin_wgrad<4>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
+    case 5: launch_thin_wgrad<5>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
+    case 6: launch_thin_wgrad<6>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
+    case 7: launch_thin_wgrad<7>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
+    default: launch_thin_wgrad<8>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
+  }
+  SEG3D_LAUNCH_CHECK("seg3d_k3_thin_wgrad");
+  const i64 total = (i64)27 * CT * CF;
+  hipLaunchKernelGGL(k3_thin_wgrad_reduce_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, s, workspace, dw, slabs, CT, CF,
+                     CFB, RB, (i64)s_ct, (i64)s_cf, flip);
+  SEG3D_LAUNCH_CHECK("seg3d_k3_thin_wgrad(reduce)");
+  return SEG3D_OK;
+}

@@ -96,6 +96,27 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats):
         E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
                E.stream_ptr())
         return y, stats
+    if A <= 8 and not FORCE_DIRECT:
+        # thin input (stem forward, head data-gradient): all 27*A taps folded into one MFMA K dimension
+        wp = _empty((E.query('seg3d_packed_thin_in_floats', A, B),), w)
+        E.call('seg3d_pack_weights_thin_in', E.ptr(w), E.ptr(wp), A, B, sa, sb, flip, E.stream_ptr())
+        stats = None
+        if want_stats:
+            stats = _empty((N, E.query('seg3d_conv3d_k3_thin_stats_count', D, H, W_, (B + 31) // 32), 2), xn)
+        E.call('seg3d_conv3d_k3_thin_in_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
+               E.stream_ptr())
+        return y, stats
+    if B <= 8 and A % 4 == 0 and not FORCE_DIRECT:
+        # thin output (head forward): LDS-tiled VALU kernel, CO outputs per voxel
+        CO = 2 if B <= 2 else (4 if B <= 4 else 8)
+        wq = _empty(((A + 7) // 8 * 27 * 8 * CO,), w)
+        E.call('seg3d_pack_weights_thin_out', E.ptr(w), E.ptr(wq), A, B, CO, sa, sb, flip, E.stream_ptr())
+        stats = None
+        if want_stats:
+            stats = _empty((N, E.query('seg3d_conv3d_k3_thin_out_stats_count', D, H, W_), 2), xn)
+        E.call('seg3d_conv3d_k3_thin_out_fwd', E.ptr(xn), E.ptr(wq), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
+               CO, E.stream_ptr())
+        return y, stats
     wp = _pack_tapmajor(w, A, B, 27, sa, sb, flip)
     E.call('seg3d_conv3d_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, A, B, 3, 1, E.stream_ptr())
     return y, None
@@ -131,6 +152,16 @@ def _k2_wgrad(P, Q, CA, CB, out_shape, sa, sb):
     ws = _empty((E.query('seg3d_k2_mfma_wgrad_workspace_floats', N, Dq, Hq, Wq, CA, CB),), P)
     dw = _empty(out_shape, P)
     E.call('seg3d_k2_mfma_wgrad', E.ptr(P), E.ptr(Q), E.ptr(dw), E.ptr(ws), N, Dq, Hq, Wq, CA, CB, sa, sb, E.stream_ptr())
+    return dw
+
+
+def _thin_wgrad(thin, fat, CT, CF, out_shape, s_ct, s_cf, flip):
+    """dw[ct*s_ct + cf*s_cf + tap] = sum_u fat[u][cf] thin[u + off(tap)][ct] (taps reversed when flip) on the matrix cores"""
+    N, D, H, W_, _ = thin.shape
+    ws = _empty((E.query('seg3d_k3_thin_wgrad_workspace_floats', N, D, H, W_, CT, CF),), thin)
+    dw = _empty(out_shape, thin)
+    E.call('seg3d_k3_thin_wgrad', E.ptr(thin), E.ptr(fat), E.ptr(dw), E.ptr(ws), N, D, H, W_, CT, CF, s_ct, s_cf, flip,
+           E.stream_ptr())
     return dw
 
 
@@ -245,6 +276,10 @@ def conv_wgrad(xn, dyn, w_shape, kind):
             E.call('seg3d_conv3d_k3_mfma_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(dw), E.ptr(ws), N, D, H, W_, Cin, Cout,
                    E.stream_ptr())
             return dw
+        if not FORCE_DIRECT and Cin <= 8 and Cout % 4 == 0:      # stem: thin = x, fat = dy
+            return _thin_wgrad(xn, dyn, Cin, Cout, w_shape, 27, Cin * 27, 0)
+        if not FORCE_DIRECT and Cout <= 8 and Cin % 4 == 0:      # head: thin = dy, fat = x, taps reversed
+            return _thin_wgrad(dyn, xn, Cout, Cin, w_shape, Cin * 27, 27, 1)
         return _wgrad_direct(xn, dyn, Cin, Cout, 3, 1, 27, w_shape, 27, Cin * 27)
     if kind == 'k2s2':
         Cout, Cin = w_shape[0], w_shape[1]

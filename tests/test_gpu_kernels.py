@@ -28,6 +28,11 @@ CONV_K3_CASES = [
     (1, 32, 2, 8, 8, 8),
     (1, 3, 5, 6, 6, 6),
     (1, 128, 128, 3, 5, 6),
+    (1, 4, 16, 5, 9, 11),     # thin-in (stem, 4 modalities), masked tiles
+    (2, 32, 5, 6, 10, 18),    # thin-out (head, 5 classes), masked tiles
+    (1, 16, 4, 4, 8, 16),     # thin-out, 4 outputs
+    (1, 8, 16, 4, 8, 8),      # thin-in with 8 channels / generic MFMA boundary
+    (4, 1, 16, 16, 16, 16),
 ]
 
 

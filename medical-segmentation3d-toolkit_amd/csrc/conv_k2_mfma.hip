@@ -156,19 +156,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const float* _
   const bool co_ok = co < Cout;
   const float bv = (bias && co_ok) ? bias[co] : 0.f;
   float s[2] = {0.f, 0.f};
+  // two passes: every store reads its own accumulator register (no shared temporary -> no vmcnt wait per store)
+  int ooff[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int idx = wave * 32 + k2_row(r, lh);
-    if (idx < MT && co_ok) {
-      const int vo = voff[idx];
-      if (vo >= 0) {
-        const float val = acc[r] + bv;
-        y[(i64)vo * Cout + co] = val;
-        s[0] += val;
-        s[1] += val * val;
-      }
-    }
+    const int vo = idx < MT ? voff[idx] : -1;
+    const bool ok = vo >= 0 && co_ok;
+    ooff[r] = ok ? vo * Cout + co : -1;
+    acc[r] += bv;
+    const float val = ok ? acc[r] : 0.f;
+    s[0] += val;
+    s[1] += val * val;
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (ooff[r] >= 0) y[(i64)ooff[r]] = acc[r];
   if (stats) {
     __syncthreads();
     block_sum_256<2>(s, xs);
@@ -284,20 +287,28 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const float* 
   const bool co_ok = co < Cout;
   const float bv = (bias && co_ok) ? bias[co] : 0.f;
   float s[2] = {0.f, 0.f};
+  int ob[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int idx = wave * 32 + k2_row(r, lh);
-    if (idx < MT && co_ok) {
-      const int ob = obase[idx];
-      if (ob >= 0) {
+    const int o = idx < MT ? obase[idx] : -1;
+    const bool ok = o >= 0 && co_ok;
+    ob[r] = ok ? o : -1;
 #pragma unroll
-        for (int tap = 0; tap < 8; ++tap) {
-          const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
-          const float val = acc[tap][r] + bv;
-          y[((i64)ob + (kz * Ho + ky) * Wo + kx) * Cout + co] = val;
-          s[0] += val;
-          s[1] += val * val;
-        }
+    for (int tap = 0; tap < 8; ++tap) {
+      acc[tap][r] += bv;
+      const float val = ok ? acc[tap][r] : 0.f;
+      s[0] += val;
+      s[1] += val * val;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (ob[r] >= 0) {
+#pragma unroll
+      for (int tap = 0; tap < 8; ++tap) {
+        const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
+        y[((i64)ob[r] + (kz * Ho + ky) * Wo + kx) * Cout + co] = acc[tap][r];
       }
     }
   }
@@ -458,9 +469,9 @@ __global__ __launch_bounds__(256) void k2_wgrad_reduce_kernel(const float* __res
 
 static int k2_wgrad_slabs(int N, int Dq, int Hq, int Wq, int npairs) {
   const int ntiles = N * seg3d_cdiv(Dq, K2W_TZ) * seg3d_cdiv(Hq, K2W_TY) * seg3d_cdiv(Wq, K2W_TX);
-  int slabs = 1024 / npairs;
+  int slabs = 512 / npairs;
+  if (slabs > (ntiles + 3) / 4) slabs = (ntiles + 3) / 4;
   if (slabs < 1) slabs = 1;
-  if (slabs > ntiles) slabs = ntiles;
   return slabs;
 }
 

@@ -109,73 +109,97 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-  for (int cib = 0; cib < CIB; ++cib) {
-    __syncthreads();  // previous chunk fully consumed
+  // Software pipeline (register prefetch, one LDS buffer): the global loads of chunk c+1 (input tile + weights) are
+  // issued BEFORE the MFMA block of chunk c and stay in flight behind it (nothing in the block waits on vmcnt: both
+  // operands come from LDS); after the block a barrier retires the LDS reads, the parked registers are written to
+  // LDS, and a second barrier publishes them.  Global latency is hidden inside the workgroup instead of relying on
+  // the co-resident workgroup being out of phase.
+  f32x4 xstage[SEG3D_MAXE];
+  f32x4 wstage[7];
+  auto load_chunk = [&](int cib) {
+    // branch-free: out-of-range lanes read a valid dummy address and are zeroed by a select, so the compiler keeps
+    // all loads in flight instead of waiting inside exec-masked branches
     const bool half_ok = cib * 8 + hh * 4 < Cin;
 #pragma unroll
     for (int e = 0; e < SEG3D_MAXE; ++e) {
+      const bool ok = goff[e] >= 0 && half_ok;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(x + (ok ? (i64)goff[e] + cib * 8 : (i64)0));
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      xstage[e] = ok ? val : zero;
+    }
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * SEG3D_W_CHUNK);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int idx = tid + k * 256;
+      wstage[k] = wsrc[idx < SEG3D_W_CHUNK / 4 ? idx : 0];
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int e = 0; e < SEG3D_MAXE; ++e) {
       const int eidx = tid + e * 256;
-      if (eidx < 2 * NV) {
-        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (goff[e] >= 0 && half_ok) val = *reinterpret_cast<const f32x4*>(x + (i64)goff[e] + cib * 8);
-        *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) = val;
-      }
+      if (eidx < 2 * NV) *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) = xstage[e];
     }
-    {
-      const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * SEG3D_W_CHUNK);
-      f32x4* wdst = reinterpret_cast<f32x4*>(ws);
 #pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const int idx = tid + k * 256;
-        if (idx < SEG3D_W_CHUNK / 4) wdst[idx] = wsrc[idx];
-      }
+    for (int k = 0; k < 7; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < SEG3D_W_CHUNK / 4) reinterpret_cast<f32x4*>(ws)[idx] = wstage[k];
     }
-    __syncthreads();
-
+  };
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+  for (int cib = 0; cib < CIB; ++cib) {
+    if (cib + 1 < CIB) load_chunk(cib + 1);
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+      const int tapoff = ((kz * HY + ky) * HX + kx) * 4;
+      const f32x4 bw = *reinterpret_cast<const f32x4*>(ws + tap * 256 + bbase);
+      f32x4 av[MA];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
+      for (int m = 0; m < MA; ++m) av[m] = *reinterpret_cast<const f32x4*>(xs + abase[m] + tapoff);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int tap = (kz * 3 + ky) * 3 + kx;
-          const int tapoff = ((kz * HY + ky) * HX + kx) * 4;
-          const f32x4 bw = *reinterpret_cast<const f32x4*>(ws + tap * 256 + bbase);
-          f32x4 av[MA];
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int m = 0; m < MA; ++m) av[m] = *reinterpret_cast<const f32x4*>(xs + abase[m] + tapoff);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int m = 0; m < MA; ++m)
-              acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][r], bw[r], acc[m], 0, 0, 0);
-        }
-      }
+        for (int m = 0; m < MA; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][r], bw[r], acc[m], 0, 0, 0);
+    }
+    if (cib + 1 < CIB) {
+      __syncthreads();  // every wave is done reading chunk c
+      store_chunk();
+      __syncthreads();  // chunk c+1 visible
     }
   }
 
   // ---- epilogue: bias, store, GroupNorm partial statistics ----
+  // Two passes so that every store reads its own accumulator register: a shared temporary would force the compiler
+  // to wait (vmcnt) for the previous store before reusing it, serialising 16*MA stores per lane.
   const int co = cob * 32 + li;
   const bool co_ok = co < Cout;
   const float bv = (bias && co_ok) ? bias[co] : 0.f;
   float s[2] = {0.f, 0.f};
+  int ooff[MA][16];
 #pragma unroll
   for (int m = 0; m < MA; ++m) {
     const int sub = wave + 4 * m;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int idx = sub * 32 + mfma_row(r, lh);
-      if (idx < MT && co_ok) {
-        const int vo = voff[idx];
-        if (vo >= 0) {
-          const float val = acc[m][r] + bv;
-          y[(i64)vo * Cout + co] = val;
-          s[0] += val;
-          s[1] += val * val;
-        }
-      }
+      const int vo = idx < MT ? voff[idx] : -1;
+      const bool ok = vo >= 0 && co_ok;
+      ooff[m][r] = ok ? vo * Cout + co : -1;
+      acc[m][r] += bv;
+      const float val = ok ? acc[m][r] : 0.f;
+      s[0] += val;
+      s[1] += val * val;
     }
   }
+#pragma unroll
+  for (int m = 0; m < MA; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ooff[m][r] >= 0) y[(i64)ooff[m][r]] = acc[m][r];
   if (stats) {
     __syncthreads();
     block_sum_256<2>(s, xs);
@@ -430,9 +454,9 @@ __global__ __launch_bounds__(256) void conv3d_k3_wgrad_reduce_kernel(const float
 
 static int seg3d_wgrad_slabs(int N, int D, int H, int W, int npairs) {
   const int ntiles = N * seg3d_cdiv(D, SEG3D_WG_TZ) * seg3d_cdiv(H, SEG3D_WG_TY) * seg3d_cdiv(W, SEG3D_WG_TX);
-  int slabs = 1024 / npairs;
+  int slabs = 1024 / npairs;                   // ~4 workgroups per CU over the whole grid
+  if (slabs > (ntiles + 3) / 4) slabs = (ntiles + 3) / 4;  // small levels: >= 4 tiles per workgroup, fewer partial slabs
   if (slabs < 1) slabs = 1;
-  if (slabs > ntiles) slabs = ntiles;
   return slabs;
 }
 

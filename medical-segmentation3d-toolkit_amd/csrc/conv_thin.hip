@@ -151,19 +151,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_kernel(const float* 
   const bool co_ok = co < Cout;
   const float bv = (bias && co_ok) ? bias[co] : 0.f;
   float s[2] = {0.f, 0.f};
+  int ooff[2][16];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int vo = voff[(wave + 4 * m) * 32 + thin_row(r, lh)];
-      if (vo >= 0 && co_ok) {
-        const float val = acc[m][r] + bv;
-        y[(i64)vo * Cout + co] = val;
-        s[0] += val;
-        s[1] += val * val;
-      }
+      const bool ok = vo >= 0 && co_ok;
+      ooff[m][r] = ok ? vo * Cout + co : -1;
+      acc[m][r] += bv;
+      const float val = ok ? acc[m][r] : 0.f;
+      s[0] += val;
+      s[1] += val * val;
     }
   }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ooff[m][r] >= 0) y[(i64)ooff[m][r]] = acc[m][r];
   if (stats) {
     __syncthreads();
     block_sum_256<2>(s, xs);
@@ -517,7 +523,8 @@ __global__ __launch_bounds__(256) void k3_thin_wgrad_reduce_kernel(const float* 
 
 static int thin_wgrad_slabs(int N, int D, int H, int W) {
   const int ntiles = N * seg3d_cdiv(D, TH_TZ) * seg3d_cdiv(H, TH_TY) * seg3d_cdiv(W, TH_TX);
-  return ntiles < 1024 ? ntiles : 1024;
+  const int want = (ntiles + 7) / 8;  // >= 8 tiles per workgroup keeps the slab count (and the serial reduce) small
+  return want < 512 ? (want < 1 ? 1 : want) : 512;
 }
 
 extern "C" long long seg3d_k3_thin_wgrad_workspace_floats(int N, int D, int H, int W, int CT, int CF) {

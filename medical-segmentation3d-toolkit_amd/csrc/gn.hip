@@ -173,18 +173,33 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __r
   i64 s1 = s0 + GN_BWD_VPB;
   if (s1 > S) s1 = S;
   float a[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0}, xx[4] = {0, 0, 0, 0};
-  for (i64 sv = s0 + vl; sv < s1; sv += VL) {
-    const i64 off = ((i64)n * S + sv) * C + 4 * q;
-    float4 g = *reinterpret_cast<const float4*>(dout + off);
-    const float4 yv = *reinterpret_cast<const float4*>(y + off);
-    if (relu) {
-      const float4 o = *reinterpret_cast<const float4*>(out + off);
-      g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+  // 4 voxels per trip: 12 independent 16-byte loads in flight per thread (the kernel is pure streaming)
+  for (i64 sv = s0 + vl; sv < s1; sv += 4 * VL) {
+    float4 g[4], yv[4], o[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const i64 svu = sv + u * VL;
+      ok[u] = svu < s1;
+      const i64 off = ((i64)n * S + (ok[u] ? svu : s0)) * C + 4 * q;
+      g[u] = *reinterpret_cast<const float4*>(dout + off);
+      yv[u] = *reinterpret_cast<const float4*>(y + off);
+      if (relu) o[u] = *reinterpret_cast<const float4*>(out + off);
     }
-    const float x0 = (yv.x - mean) * rstd, x1 = (yv.y - mean) * rstd, x2 = (yv.z - mean) * rstd, x3 = (yv.w - mean) * rstd;
-    a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
-    bb[0] += g.x * x0; bb[1] += g.y * x1; bb[2] += g.z * x2; bb[3] += g.w * x3;
-    xx[0] += x0; xx[1] += x1; xx[2] += x2; xx[3] += x3;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      float4 gg = g[u];
+      if (relu) {
+        gg.x = o[u].x > 0.f ? gg.x : 0.f; gg.y = o[u].y > 0.f ? gg.y : 0.f;
+        gg.z = o[u].z > 0.f ? gg.z : 0.f; gg.w = o[u].w > 0.f ? gg.w : 0.f;
+      }
+      const float x0 = (yv[u].x - mean) * rstd, x1 = (yv[u].y - mean) * rstd, x2 = (yv[u].z - mean) * rstd,
+                  x3 = (yv[u].w - mean) * rstd;
+      a[0] += gg.x; a[1] += gg.y; a[2] += gg.z; a[3] += gg.w;
+      bb[0] += gg.x * x0; bb[1] += gg.y * x1; bb[2] += gg.z * x2; bb[3] += gg.w * x3;
+      xx[0] += x0; xx[1] += x1; xx[2] += x2; xx[3] += x3;
+    }
   }
   float* r = red + threadIdx.x * 12;
 #pragma unroll

@@ -1,0 +1,49 @@
+"""micro-benchmark of single conv launches (events on the launch stream); used for kernel A/B work and PMC runs.
+usage: python tools/bench_conv.py [fwd|wgrad|all] [N D H W Cin Cout] [--iters K]"""
+import os, sys, time
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'medical-segmentation3d-toolkit_amd')); sys.path.insert(0, REPO)
+from segmentation3d import _ops, _engine as E
+
+def run(kind, N, D, H, W, Cin, Cout, iters=10):
+    dev = torch.device('cuda:0')
+    x = torch.randn(N, D, H, W, Cin, device=dev)
+    dy = torch.randn(N, D, H, W, Cout, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, 3, device=dev) * 0.05
+    b = torch.zeros(Cout, device=dev)
+    if kind == 'fwd':
+        wp = _ops._pack_mfma(w, Cin, Cout, 27, 27, Cin * 27)
+        y = torch.empty(N, D, H, W, Cout, device=dev)
+        cnt = E.query('seg3d_conv3d_k3_mfma_stats_count', N, D, H, W, Cout)
+        st = torch.empty(N, cnt, 2, device=dev)
+        fn = lambda: E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(x), E.ptr(wp), E.ptr(b), E.ptr(y), E.ptr(st), N, D, H, W, Cin, Cout, E.stream_ptr())
+    else:
+        ws = torch.empty(E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W, Cin, Cout), device=dev)
+        dw = torch.empty(Cout, Cin, 3, 3, 3, device=dev)
+        fn = lambda: E.call('seg3d_conv3d_k3_mfma_wgrad', E.ptr(x), E.ptr(dy), E.ptr(dw), E.ptr(ws), N, D, H, W, Cin, Cout, E.stream_ptr())
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    c.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(c) / iters
+    fl = 2.0 * N * D * H * W * 27 * Cin * Cout
+    print('{:5s} N={} {}x{}x{} {}->{}  {:8.3f} ms  {:7.2f} TFLOP/s'.format(kind, N, D, H, W, Cin, Cout, ms, fl / ms / 1e9), flush=True)
+
+if __name__ == '__main__':
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    iters = 10
+    if '--iters' in sys.argv:
+        iters = int(sys.argv[sys.argv.index('--iters') + 1]); args = [a for a in args if a != str(iters)]
+    kind = args[0] if args else 'all'
+    shapes = [tuple(int(v) for v in args[1:7])] if len(args) >= 7 else [
+        (4, 96, 96, 96, 32, 32), (4, 48, 48, 48, 64, 64), (4, 48, 48, 48, 32, 32), (4, 24, 24, 24, 128, 128),
+        (4, 24, 24, 24, 64, 64), (4, 12, 12, 12, 256, 256), (4, 12, 12, 12, 128, 128), (4, 6, 6, 6, 256, 256)]
+    for s in shapes:
+        for k in (['fwd', 'wgrad'] if kind == 'all' else [kind]):
+            run(k, *s, iters=iters)

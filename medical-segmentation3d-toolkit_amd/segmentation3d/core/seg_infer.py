@@ -151,12 +151,28 @@ class SlidingWindowBatcher(object):
         return self.acc, mask
 
 
-def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, batch_size=8, use_graph=True):
-    """run `net` over all patches of a device-resident volume; returns (probs [C,Z,Y,X], mask int8 [Z,Y,X], batcher)"""
+def shard_batches(batches, rank, world_size):
+    """patch batches of this rank: patches are independent, so the ordered batch list is dealt round-robin over the
+    ranks; each rank accumulates into its own acc / count and ONE sum all-reduce merges them (no other exchange)"""
+    return [b for i, b in enumerate(batches) if i % world_size == rank]
+
+
+def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, batch_size=8, use_graph=True,
+                             process_group=None, shard=False):
+    """run `net` over all patches of a device-resident volume; returns (probs [C,Z,Y,X], mask int8 [Z,Y,X], batcher).
+    With shard=True under an initialised torch.distributed group every rank processes its share of the batches and
+    the accumulators are summed with one all-reduce before the final divide + arg-max (float summation order then
+    differs from the sequential reference loop by rounding only)."""
     batcher = SlidingWindowBatcher(volume, starts, box, num_classes, normalizer, max_batch=batch_size)
     P = batcher.max_batch
     batches = [list(range(i, min(i + P, len(starts)))) for i in range(0, len(starts), P)]
-    batcher.plan(batches)
+    sharded = shard and torch.distributed.is_available() and torch.distributed.is_initialized() and \
+        torch.distributed.get_world_size(process_group) > 1
+    if sharded:
+        batches = shard_batches(batches, torch.distributed.get_rank(process_group),
+                                torch.distributed.get_world_size(process_group))
+    if batches:
+        batcher.plan(batches)
     graph, first = None, 0
     with torch.no_grad():
         if use_graph and len(batches) > 2:
@@ -183,6 +199,9 @@ def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, 
                 graph.replay()
             else:
                 batcher.scatter_current(net(batcher.gather_current()).contiguous())
+        if sharded:
+            torch.distributed.all_reduce(batcher.acc, group=process_group)
+            torch.distributed.all_reduce(batcher.count, group=process_group)
         probs, mask = batcher.finalize()
     return probs, mask, batcher
 

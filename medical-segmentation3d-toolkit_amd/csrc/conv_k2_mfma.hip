@@ -449,21 +449,30 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
   }
 }
 
-// dw[a*sa + b*sb + t] = sum_slab part[slab][a/32][b/32][t][a%32][b%32]
-__global__ __launch_bounds__(256) void k2_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                int slabs, int A, int B, int BB32, int npairs, i64 sa,
-                                                                i64 sb) {
-  const i64 total = (i64)8 * A * B;
-  for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
-    const int b = (int)(idx % B);
-    i64 r = idx / B;
-    const int a = (int)(r % A);
-    const int t = (int)(r / A);
-    const int pair = (a >> 5) * BB32 + (b >> 5);
-    const float* p = part + ((i64)pair * 8 + t) * 1024 + (a & 31) * 32 + (b & 31);
-    float s = 0.f;
-    for (int k = 0; k < slabs; ++k) s += p[(i64)k * npairs * 8 * 1024];
-    dw[a * sa + b * sb + t] = s;
+// dw[a*sa + b*sb + t] = sum_slab part[slab][a/32][b/32][t][a%32][b%32]   (a = reduction-side channel, b = output channel)
+// 64 outputs per workgroup, 4 slab groups per output (coalesced reads of every slab), combined in a fixed order.
+__global__ __launch_bounds__(256) void k2_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int slabs, int A,
+             int B, int BB32, int npairs, i64 sa, i64 sb) {
+  constexpr int T = 8;
+  __shared__ float red[256];
+  const i64 total = (i64)npairs * T * 1024;
+  const i64 pidx = (i64)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (pidx < total) {
+    const float* p = part + pidx;
+    for (int k = g; k < slabs; k += 4) s += p[(i64)k * total];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && pidx < total) {
+    const float v = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+    const int b32 = (int)(pidx & 31), a32 = (int)((pidx >> 5) & 31);
+    const i64 r = pidx >> 10;
+    const int t = (int)(r % T);
+    const int pair = (int)(r / T);
+    const int a = (pair / BB32) * 32 + a32, b = (pair % BB32) * 32 + b32;
+    if (a < A && b < B) dw[a * sa + b * sb + t] = v;
   }
 }
 
@@ -496,8 +505,8 @@ extern "C" int seg3d_k2_mfma_wgrad(const float* P, const float* Q, float* dw, fl
   hipLaunchKernelGGL(k2_wgrad_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s, P, Q, workspace, N, Dq, Hq, Wq, CA, CB, ntz,
                      nty, ntx, ntiles, BB32);
   SEG3D_LAUNCH_CHECK("seg3d_k2_mfma_wgrad");
-  const i64 total = (i64)8 * CA * CB;
-  hipLaunchKernelGGL(k2_wgrad_reduce_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, s, workspace, dw, slabs, CA, CB,
+  const i64 total = (i64)npairs * 8 * 1024;
+  hipLaunchKernelGGL(k2_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dw, slabs, CA, CB,
                      BB32, npairs, (i64)sa, (i64)sb);
   SEG3D_LAUNCH_CHECK("seg3d_k2_mfma_wgrad(reduce)");
   return SEG3D_OK;

@@ -323,14 +323,14 @@ extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const f
 // ================================================================================================================
 // weight gradient
 // ================================================================================================================
-#define SEG3D_WG_TZ 2
+#define SEG3D_WG_TZ 4
 #define SEG3D_WG_TY 4
-#define SEG3D_WG_TX 16
+#define SEG3D_WG_TX 8
 #define SEG3D_WG_MT (SEG3D_WG_TZ * SEG3D_WG_TY * SEG3D_WG_TX)                           // 128 voxels
 #define SEG3D_WG_HY (SEG3D_WG_TY + 2)
 #define SEG3D_WG_HX (SEG3D_WG_TX + 2)
-#define SEG3D_WG_NV ((SEG3D_WG_TZ + 2) * SEG3D_WG_HY * SEG3D_WG_HX)                     // 432 halo voxels
-#define SEG3D_WG_XE ((SEG3D_WG_NV * 8 + 255) / 256)                                     // float4 per thread: 14
+#define SEG3D_WG_NV ((SEG3D_WG_TZ + 2) * SEG3D_WG_HY * SEG3D_WG_HX)                     // 360 halo voxels
+#define SEG3D_WG_XE ((SEG3D_WG_NV * 8 + 255) / 256)                                     // float4 per thread: 12
 #define SEG3D_WG_YE ((SEG3D_WG_MT * 8) / 256)                                           // 4
 
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const float* __restrict__ x,
@@ -434,27 +434,36 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
   }
 }
 
-// dw[a*sa + b*sb + t] = sum_slab part[slab][a/32][b/32][t][a%32][b%32]   (a = ci, b = co)
-__global__ __launch_bounds__(256) void conv3d_k3_wgrad_reduce_kernel(const float* __restrict__ part,
-                                                                       float* __restrict__ dw, int slabs, int A, int B,
-                                                                       int COB32, int npairs, i64 sa, i64 sb) {
-  const i64 total = (i64)27 * A * B;
-  for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
-    const int b = (int)(idx % B);
-    i64 r = idx / B;
-    const int a = (int)(r % A);
-    const int t = (int)(r / A);
-    const int pair = (a >> 5) * COB32 + (b >> 5);
-    const float* p = part + ((i64)pair * 27 + t) * 1024 + (a & 31) * 32 + (b & 31);
-    float s = 0.f;
-    for (int k = 0; k < slabs; ++k) s += p[(i64)k * npairs * 27 * 1024];
-    dw[a * sa + b * sb + t] = s;
+// dw[a*sa + b*sb + t] = sum_slab part[slab][a/32][b/32][t][a%32][b%32]   (a = reduction-side channel, b = output channel)
+// 64 outputs per workgroup, 4 slab groups per output (coalesced reads of every slab), combined in a fixed order.
+__global__ __launch_bounds__(256) void conv3d_k3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int slabs, int A,
+                    int B, int BB32, int npairs, i64 sa, i64 sb) {
+  constexpr int T = 27;
+  __shared__ float red[256];
+  const i64 total = (i64)npairs * T * 1024;
+  const i64 pidx = (i64)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (pidx < total) {
+    const float* p = part + pidx;
+    for (int k = g; k < slabs; k += 4) s += p[(i64)k * total];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && pidx < total) {
+    const float v = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+    const int b32 = (int)(pidx & 31), a32 = (int)((pidx >> 5) & 31);
+    const i64 r = pidx >> 10;
+    const int t = (int)(r % T);
+    const int pair = (int)(r / T);
+    const int a = (pair / BB32) * 32 + a32, b = (pair % BB32) * 32 + b32;
+    if (a < A && b < B) dw[a * sa + b * sb + t] = v;
   }
 }
 
 static int seg3d_wgrad_slabs(int N, int D, int H, int W, int npairs) {
   const int ntiles = N * seg3d_cdiv(D, SEG3D_WG_TZ) * seg3d_cdiv(H, SEG3D_WG_TY) * seg3d_cdiv(W, SEG3D_WG_TX);
-  int slabs = 1024 / npairs;                   // ~4 workgroups per CU over the whole grid
+  int slabs = 512 / npairs;                    // 2 resident workgroups per CU over the whole grid
   if (slabs > (ntiles + 3) / 4) slabs = (ntiles + 3) / 4;  // small levels: >= 4 tiles per workgroup, fewer partial slabs
   if (slabs < 1) slabs = 1;
   return slabs;
@@ -481,8 +490,8 @@ extern "C" int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float
   hipLaunchKernelGGL(conv3d_k3_wgrad_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s, x, dy, workspace, N, D, H, W, Cin,
                      Cout, ntz, nty, ntx, ntiles, COB32);
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_wgrad");
-  const i64 total = (i64)27 * Cin * Cout;
-  hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, s, workspace, dw, slabs,
+  const i64 total = (i64)npairs * 27 * 1024;  // padded (32 x 32 per pair) partial elements, 64 per workgroup
+  hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dw, slabs,
                      Cin, Cout, COB32, npairs, (i64)27, (i64)Cin * 27);
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_wgrad(reduce)");
   return SEG3D_OK;

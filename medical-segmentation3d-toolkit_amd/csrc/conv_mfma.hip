@@ -151,19 +151,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
   __syncthreads();
   for (int cib = 0; cib < CIB; ++cib) {
     if (cib + 1 < CIB) load_chunk(cib + 1);
-#pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-      const int tapoff = ((kz * HY + ky) * HX + kx) * 4;
-      const f32x4 bw = *reinterpret_cast<const f32x4*>(ws + tap * 256 + bbase);
+    {
+      // LDS operands are double-buffered in registers: tap t+1 is read before the 4*MA MFMAs of tap t are issued
+      f32x4 bw = *reinterpret_cast<const f32x4*>(ws + bbase);
       f32x4 av[MA];
 #pragma unroll
-      for (int m = 0; m < MA; ++m) av[m] = *reinterpret_cast<const f32x4*>(xs + abase[m] + tapoff);
+      for (int m = 0; m < MA; ++m) av[m] = *reinterpret_cast<const f32x4*>(xs + abase[m]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int tap = 0; tap < 27; ++tap) {
+        f32x4 bwn = bw;
+        f32x4 avn[MA];
 #pragma unroll
-        for (int m = 0; m < MA; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][r], bw[r], acc[m], 0, 0, 0);
+        for (int m = 0; m < MA; ++m) avn[m] = av[m];
+        if (tap + 1 < 27) {
+          const int t1 = tap + 1;
+          const int kz = t1 / 9, ky = (t1 / 3) % 3, kx = t1 % 3;
+          const int tapoff = ((kz * HY + ky) * HX + kx) * 4;
+          bwn = *reinterpret_cast<const f32x4*>(ws + t1 * 256 + bbase);
+#pragma unroll
+          for (int m = 0; m < MA; ++m) avn[m] = *reinterpret_cast<const f32x4*>(xs + abase[m] + tapoff);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int m = 0; m < MA; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][r], bw[r], acc[m], 0, 0, 0);
+        bw = bwn;
+#pragma unroll
+        for (int m = 0; m < MA; ++m) av[m] = avn[m];
+      }
     }
     if (cib + 1 < CIB) {
       __syncthreads();  // every wave is done reading chunk c

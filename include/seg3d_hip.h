@@ -64,10 +64,12 @@ int seg3d_wgrad_reduce(const float* part, float* dw, int chunks, int T, int A, i
                        void* stream);
 
 /* fp32 MFMA implicit-GEMM path for k3 s1 p1 with Cin % 4 == 0 (the FLOP-dominant C->C layers) */
-long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W, int Cout);
+long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W, int Cin, int Cout);
+long long seg3d_conv3d_k3_mfma_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cout);
 int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp_mfma, const float* bias, float* y, float* stats_partial,
-                             int N, int D, int H, int W, int Cin, int Cout, void* stream);
+                             float* workspace /* split-K partials, may be NULL when the query returns 0 */, int N, int D,
+                             int H, int W, int Cin, int Cout, void* stream);
 long long seg3d_conv3d_k3_mfma_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H, int W,
                                int Cin, int Cout, void* stream);

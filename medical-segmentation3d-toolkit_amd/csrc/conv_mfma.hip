@@ -38,7 +38,7 @@ template <int MA>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ stats, int N, int D, int H, int W, int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
-    int ntx) {
+    int ntx, float* __restrict__ kpart, int cpk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int HY = TY + 2, HX = TX + 2;
   const int NV = (TZ + 2) * HY * HX;
@@ -146,11 +146,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
       if (idx < SEG3D_W_CHUNK / 4) reinterpret_cast<f32x4*>(ws)[idx] = wstage[k];
     }
   };
-  load_chunk(0);
+  // split-K (deep, spatially tiny levels): blockIdx.z owns the K-chunks [cib0, cib1) and writes a raw partial slab
+  const int cib0 = kpart ? blockIdx.z * cpk : 0;
+  const int cib1 = kpart ? (cib0 + cpk < CIB ? cib0 + cpk : CIB) : CIB;
+  load_chunk(cib0);
   store_chunk();
   __syncthreads();
-  for (int cib = 0; cib < CIB; ++cib) {
-    if (cib + 1 < CIB) load_chunk(cib + 1);
+  for (int cib = cib0; cib < cib1; ++cib) {
+    if (cib + 1 < cib1) load_chunk(cib + 1);
     {
       // LDS operands are double-buffered in registers: tap t+1 is read before the 4*MA MFMAs of tap t are issued
       f32x4 bw = *reinterpret_cast<const f32x4*>(ws + bbase);
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
         for (int m = 0; m < MA; ++m) av[m] = avn[m];
       }
     }
-    if (cib + 1 < CIB) {
+    if (cib + 1 < cib1) {
       __syncthreads();  // every wave is done reading chunk c
       store_chunk();
       __syncthreads();  // chunk c+1 visible
@@ -193,6 +196,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
   // to wait (vmcnt) for the previous store before reusing it, serialising 16*MA stores per lane.
   const int co = cob * 32 + li;
   const bool co_ok = co < Cout;
+  if (kpart) {  // raw partial sums; bias, store and statistics happen in conv3d_splitk_finish_kernel
+    float* dstp = kpart + (i64)blockIdx.z * N * D * H * W * Cout;
+#pragma unroll
+    for (int m = 0; m < MA; ++m) {
+      const int sub = wave + 4 * m;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int idx = sub * 32 + mfma_row(r, lh);
+        const int vo = idx < MT ? voff[idx] : -1;
+        if (vo >= 0 && co_ok) dstp[(i64)vo * Cout + co] = acc[m][r];
+      }
+    }
+    return;
+  }
   const float bv = (bias && co_ok) ? bias[co] : 0.f;
   float s[2] = {0.f, 0.f};
   int ooff[MA][16];
@@ -232,6 +249,41 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
 struct Seg3dTile {
   int tz, ty, tx;
 };
+
+#define SPLITK_CHUNK 4096  // elements per workgroup of the finish pass
+
+// y[e] = bias[c] + sum_ks part[ks][e]; emits GroupNorm (sum, sumsq) partials per workgroup.  HBM-bound, float4.
+__global__ __launch_bounds__(256) void conv3d_splitk_finish_kernel(const float* __restrict__ part,
+                                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                                     float* __restrict__ stats, int KS, i64 M, i64 total,
+                                                                     int Cout, int nblk) {
+  __shared__ float red[8];
+  const int n = blockIdx.y;
+  const i64 e0 = (i64)blockIdx.x * SPLITK_CHUNK;
+  i64 e1 = e0 + SPLITK_CHUNK;
+  if (e1 > M) e1 = M;
+  float s[2] = {0.f, 0.f};
+  for (i64 e = e0 + 4 * threadIdx.x; e < e1; e += 1024) {
+    const i64 g = (i64)n * M + e;
+    float4 acc = *reinterpret_cast<const float4*>(part + g);
+    for (int k = 1; k < KS; ++k) {
+      const float4 p = *reinterpret_cast<const float4*>(part + (i64)k * total + g);
+      acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    if (bias) {
+      const int c = (int)(e % Cout);
+      acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3];
+    }
+    *reinterpret_cast<float4*>(y + g) = acc;
+    s[0] += (acc.x + acc.y) + (acc.z + acc.w);
+    s[1] += (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w);
+  }
+  block_sum_256<2>(s, red);
+  if (stats && threadIdx.x == 0) {
+    stats[((i64)n * nblk + blockIdx.x) * 2 + 0] = s[0];
+    stats[((i64)n * nblk + blockIdx.x) * 2 + 1] = s[1];
+  }
+}
 
 // Pick the output tile for one level: at most 512 voxels (4 waves x 4 accumulators), halo tile <= 1280 voxels,
 // as few wasted (masked) voxels and as little halo as possible, and enough workgroups to fill 256 CUs.
@@ -274,7 +326,26 @@ static size_t seg3d_fwd_lds_bytes(const Seg3dTile& t) {
   return (size_t)(8 * nv + SEG3D_W_CHUNK + ((mt + 3) & ~3)) * 4;
 }
 
-extern "C" long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W, int Cout) {
+// number of K splits: only when the (tile, cout-block) grid cannot fill the chip and K is long enough to cut
+static int seg3d_fwd_ksplit(int N, int D, int H, int W, int Cin, int Cout) {
+  const int cob = (Cout + 31) / 32, cib = (Cin + 7) / 8;
+  Seg3dTile t = seg3d_pick_tile(N, D, H, W, cob);
+  const i64 wgs = (i64)N * seg3d_cdiv(D, t.tz) * seg3d_cdiv(H, t.ty) * seg3d_cdiv(W, t.tx) * cob;
+  if (wgs >= 192 || cib < 4 || (Cout & 3)) return 1;
+  int ks = (int)((512 + wgs - 1) / wgs);
+  if (ks > cib / 2) ks = cib / 2;
+  if (ks > 16) ks = 16;
+  return ks < 2 ? 1 : ks;
+}
+
+extern "C" long long seg3d_conv3d_k3_mfma_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
+  const int ks = seg3d_fwd_ksplit(N, D, H, W, Cin, Cout);
+  return ks > 1 ? (long long)ks * N * D * H * W * Cout : 0;
+}
+
+// GroupNorm partial (sum, sumsq) slots per sample that seg3d_conv3d_k3_mfma_fwd writes for this problem
+extern "C" long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W, int Cin, int Cout) {
+  if (seg3d_fwd_ksplit(N, D, H, W, Cin, Cout) > 1) return ((long long)D * H * W * Cout + SPLITK_CHUNK - 1) / SPLITK_CHUNK;
   const int cob = (Cout + 31) / 32;
   Seg3dTile t = seg3d_pick_tile(N, D, H, W, cob);
   return (long long)seg3d_cdiv(D, t.tz) * seg3d_cdiv(H, t.ty) * seg3d_cdiv(W, t.tx) * cob;
@@ -289,7 +360,7 @@ extern "C" int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cout
 
 template <int MA>
 static int launch_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
-                      int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s) {
+                      int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, float* kpart, int ks) {
   const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
   const size_t lds = seg3d_fwd_lds_bytes(t);
   static size_t configured = 0;
@@ -302,16 +373,18 @@ static int launch_fwd(const float* x, const float* wp, const float* bias, float*
     }
     configured = 160 * 1024;
   }
-  dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
+  const int cib = (Cin + 7) / 8;
+  const int cpk = (cib + ks - 1) / ks;
+  dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32), (unsigned)(ks > 1 ? (cib + cpk - 1) / cpk : 1));
   hipLaunchKernelGGL((conv3d_k3_mfma_kernel<MA>), grid, dim3(256), lds, s, x, wp, bias, y, stats, N, D, H, W, Cin, Cout,
-                     t.tz, t.ty, t.tx, ntz, nty, ntx);
+                     t.tz, t.ty, t.tx, ntz, nty, ntx, ks > 1 ? kpart : nullptr, cpk);
   return SEG3D_OK;
 }
 
 // x [N][D][H][W][Cin], wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 27), y [N][D][H][W][Cout];
 // stats (optional): [N][seg3d_conv3d_k3_mfma_stats_count][2] partial (sum, sumsq) of y per sample.
-extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N,
-                                        int D, int H, int W, int Cin, int Cout, void* stream) {
+extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
+                                        float* workspace, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_mfma_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k3_mfma_fwd: bad dims");
   SEG3D_REQUIRE((Cin % 4) == 0, "seg3d_conv3d_k3_mfma_fwd: Cin must be a multiple of 4 (got %d); use the direct kernel", Cin);
@@ -322,17 +395,28 @@ extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const f
   const int subs = (t.tz * t.ty * t.tx + 31) / 32;
   const int ma = (subs + 3) / 4;
   hipStream_t s = (hipStream_t)stream;
+  const int ks = seg3d_fwd_ksplit(N, D, H, W, Cin, Cout);
+  SEG3D_REQUIRE(ks == 1 || workspace, "seg3d_conv3d_k3_mfma_fwd: this shape runs split-K and needs the workspace "
+                "(seg3d_conv3d_k3_mfma_fwd_workspace_floats)");
   int rc;
   switch (ma) {
-    case 1: rc = launch_fwd<1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s); break;
-    case 2: rc = launch_fwd<2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s); break;
-    case 3: rc = launch_fwd<3>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s); break;
-    case 4: rc = launch_fwd<4>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s); break;
+    case 1: rc = launch_fwd<1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks); break;
+    case 2: rc = launch_fwd<2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks); break;
+    case 3: rc = launch_fwd<3>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks); break;
+    case 4: rc = launch_fwd<4>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks); break;
     default:
       SEG3D_UNSUPPORTED("seg3d_conv3d_k3_mfma_fwd: internal tile error (ma=%d)", ma);
   }
   if (rc != SEG3D_OK) return rc;
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_fwd");
+  if (ks > 1) {
+    const i64 M = (i64)D * H * W * Cout;
+    const int nblk = (int)((M + SPLITK_CHUNK - 1) / SPLITK_CHUNK);
+    const int cib = (Cin + 7) / 8, cpk = (cib + ks - 1) / ks;
+    hipLaunchKernelGGL(conv3d_splitk_finish_kernel, dim3(nblk, N), dim3(256), 0, s, workspace, bias, y, stats,
+                       (cib + cpk - 1) / cpk, M, (i64)N * M, Cout, nblk);
+    SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_fwd(split-K finish)");
+  }
   return SEG3D_OK;
 }
 

@@ -32,9 +32,10 @@ _SIGNATURES = {
     'seg3d_wgrad_direct_workspace_floats': (_c_ll, [_c_int] * 7),
     'seg3d_wgrad_direct': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 8 + [ctypes.POINTER(_c_int), _c_p]),
     'seg3d_wgrad_reduce': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p]),
-    'seg3d_conv3d_k3_mfma_stats_count': (_c_ll, [_c_int] * 5),
+    'seg3d_conv3d_k3_mfma_stats_count': (_c_ll, [_c_int] * 6),
+    'seg3d_conv3d_k3_mfma_fwd_workspace_floats': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_variant': (_c_int, [_c_int] * 5),
-    'seg3d_conv3d_k3_mfma_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
+    'seg3d_conv3d_k3_mfma_fwd': (_c_int, [_c_p] * 6 + [_c_int] * 6 + [_c_p]),
     'seg3d_conv3d_k3_mfma_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_p]),
     'seg3d_conv3d_k2s2_mfma_stats_count': (_c_ll, [_c_int] * 4),

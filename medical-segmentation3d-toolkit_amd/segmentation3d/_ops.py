@@ -91,10 +91,12 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats):
         wp = _pack_mfma(w, A, B, 27, sa, sb, flip)
         stats = None
         if want_stats:
-            cnt = E.query('seg3d_conv3d_k3_mfma_stats_count', N, D, H, W_, B)
+            cnt = E.query('seg3d_conv3d_k3_mfma_stats_count', N, D, H, W_, A, B)
             stats = _empty((N, cnt, 2), xn)
-        E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
-               E.stream_ptr())
+        nws = E.query('seg3d_conv3d_k3_mfma_fwd_workspace_floats', N, D, H, W_, A, B)
+        ws = _empty((nws,), xn) if nws else None    # split-K partial slabs for the deep, spatially tiny levels
+        E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), E.ptr(ws), N, D, H,
+               W_, A, B, E.stream_ptr())
         return y, stats
     if A <= 8 and not FORCE_DIRECT:
         # thin input (stem forward, head data-gradient): all 27*A taps folded into one MFMA K dimension

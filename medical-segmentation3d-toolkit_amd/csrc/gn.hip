@@ -162,6 +162,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __r
                                                                   const float* __restrict__ out,
                                                                   const float* __restrict__ y,
                                                                   const float* __restrict__ mean_rstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
                                                                   float* __restrict__ part, i64 S, int C, int nblk,
                                                                   int relu) {
   __shared__ float red[256 * 12];
@@ -184,7 +186,18 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __r
       const i64 off = ((i64)n * S + (ok[u] ? svu : s0)) * C + 4 * q;
       g[u] = *reinterpret_cast<const float4*>(dout + off);
       yv[u] = *reinterpret_cast<const float4*>(y + off);
-      if (relu) o[u] = *reinterpret_cast<const float4*>(out + off);
+      if (relu && out) o[u] = *reinterpret_cast<const float4*>(out + off);
+    }
+    if (relu && !out) {
+      // no residual: the forward output is a pure function of y -> recompute it (same expression as gn_apply_kernel)
+      // instead of reading a third tensor
+      const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * q);
+      const float4 bt = *reinterpret_cast<const float4*>(beta + 4 * q);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        o[u].x = (yv[u].x - mean) * rstd * gm.x + bt.x; o[u].y = (yv[u].y - mean) * rstd * gm.y + bt.y;
+        o[u].z = (yv[u].z - mean) * rstd * gm.z + bt.z; o[u].w = (yv[u].w - mean) * rstd * gm.w + bt.w;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -227,6 +240,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_small_kernel(const float* _
                                                                     const float* __restrict__ out,
                                                                     const float* __restrict__ y,
                                                                     const float* __restrict__ mean_rstd,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta,
                                                                     float* __restrict__ part, i64 S, int C, int nblk,
                                                                     int relu) {
   __shared__ float red[4 * 3];
@@ -244,7 +259,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_small_kernel(const float* _
     for (int c = 0; c < GN_SMALLC; ++c) {
       if (c < C) {
         float g = dout[off + c];
-        if (relu && !(out[off + c] > 0.f)) g = 0.f;
+        const float ov = out ? out[off + c] : (y[off + c] - mean) * rstd * gamma[c] + beta[c];
+        if (relu && !(ov > 0.f)) g = 0.f;
         const float xh = (y[off + c] - mean) * rstd;
         a[c] += g;
         bb[c] += g * xh;
@@ -270,18 +286,21 @@ extern "C" long long seg3d_gn_bwd_blocks(long long S) { return (S + GN_BWD_VPB -
 static bool gn_vec_ok(int C) { return (C & 3) == 0 && (C >> 2) <= 256 && (256 % (C >> 2)) == 0; }
 
 // part: [N][seg3d_gn_bwd_blocks(S)][C][3]
+// `out` = forward output of the unit (needed for the ReLU mask only when a residual was added); with out == NULL the
+// mask is recomputed from y, gamma, beta.
 extern "C" int seg3d_gn_bwd_reduce(const float* dout, const float* out, const float* y, const float* mean_rstd,
-                                   float* part, int N, long long S, int C, int relu, void* stream) {
+                                   const float* gamma, const float* beta, float* part, int N, long long S, int C,
+                                   int relu, void* stream) {
   SEG3D_REQUIRE(dout && y && mean_rstd && part && N > 0 && S > 0 && C > 0, "seg3d_gn_bwd_reduce: bad arguments");
-  SEG3D_REQUIRE(!relu || out, "seg3d_gn_bwd_reduce: relu mask needs the forward output");
+  SEG3D_REQUIRE(!relu || out || (gamma && beta), "seg3d_gn_bwd_reduce: relu mask needs the forward output or gamma/beta");
   const int nblk = (int)seg3d_gn_bwd_blocks(S);
   hipStream_t s = (hipStream_t)stream;
   if (gn_vec_ok(C)) {
-    hipLaunchKernelGGL(gn_bwd_reduce_vec_kernel, dim3(nblk, N), dim3(256), 0, s, dout, out, y, mean_rstd, part, (i64)S, C,
-                       nblk, relu);
+    hipLaunchKernelGGL(gn_bwd_reduce_vec_kernel, dim3(nblk, N), dim3(256), 0, s, dout, out, y, mean_rstd, gamma, beta, part,
+                       (i64)S, C, nblk, relu);
   } else if (C <= GN_SMALLC) {
-    hipLaunchKernelGGL(gn_bwd_reduce_small_kernel, dim3(nblk, N), dim3(256), 0, s, dout, out, y, mean_rstd, part, (i64)S,
-                       C, nblk, relu);
+    hipLaunchKernelGGL(gn_bwd_reduce_small_kernel, dim3(nblk, N), dim3(256), 0, s, dout, out, y, mean_rstd, gamma, beta,
+                       part, (i64)S, C, nblk, relu);
   } else {
     SEG3D_UNSUPPORTED("seg3d_gn_bwd_reduce: unsupported channel count %d (need C<=16 or C%%4==0 with C/4 | 256)", C);
   }
@@ -294,30 +313,46 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_sample_kernel(const float
                                                                        const float* __restrict__ gamma,
                                                                        float* __restrict__ abx, float* __restrict__ s12,
                                                                        int C, int nblk, double M) {
-  __shared__ double red[2 * 4];
+  // thread = (channel c, slab group p): PARTS groups split the nblk partial slabs; combined in fixed order through LDS
+  __shared__ double red[256 * 3];
+  __shared__ double red2[2 * 4];
   const int n = blockIdx.x;
+  const int CW = C < 256 ? C : 256;
+  const int PARTS = 256 / CW;
   double s1 = 0.0, s2 = 0.0;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c0 = 0; c0 < C; c0 += CW) {
+    const int cl = threadIdx.x % CW, pg = threadIdx.x / CW;
+    const int c = c0 + cl;
     double A = 0.0, B = 0.0, X = 0.0;
-    const float* p = part + ((i64)n * nblk * C + c) * 3;
-    for (int k = 0; k < nblk; ++k) {
-      A += (double)p[(i64)k * C * 3 + 0];
-      B += (double)p[(i64)k * C * 3 + 1];
-      X += (double)p[(i64)k * C * 3 + 2];
+    if (pg < PARTS && c < C) {
+      const float* p = part + ((i64)n * nblk * C + c) * 3;
+      for (int k = pg; k < nblk; k += PARTS) {
+        A += (double)p[(i64)k * C * 3 + 0];
+        B += (double)p[(i64)k * C * 3 + 1];
+        X += (double)p[(i64)k * C * 3 + 2];
+      }
     }
-    float* d = abx + ((i64)n * C + c) * 3;
-    d[0] = (float)A; d[1] = (float)B; d[2] = (float)X;
-    s1 += (double)gamma[c] * A;
-    s2 += (double)gamma[c] * B;
+    __syncthreads();
+    red[threadIdx.x * 3 + 0] = A; red[threadIdx.x * 3 + 1] = B; red[threadIdx.x * 3 + 2] = X;
+    __syncthreads();
+    if (pg == 0 && c < C) {
+      for (int k = 1; k < PARTS; ++k) {
+        A += red[(k * CW + cl) * 3 + 0]; B += red[(k * CW + cl) * 3 + 1]; X += red[(k * CW + cl) * 3 + 2];
+      }
+      float* d = abx + ((i64)n * C + c) * 3;
+      d[0] = (float)A; d[1] = (float)B; d[2] = (float)X;
+      s1 += (double)gamma[c] * A;
+      s2 += (double)gamma[c] * B;
+    }
   }
   s1 = wave_sum_d(s1);
   s2 = wave_sum_d(s2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+  if (lane == 0) { red2[wave] = s1; red2[4 + wave] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    s12[2 * n + 0] = (float)((red[0] + red[1] + red[2] + red[3]) / M);
-    s12[2 * n + 1] = (float)((red[4] + red[5] + red[6] + red[7]) / M);
+    s12[2 * n + 0] = (float)((red2[0] + red2[1] + red2[2] + red2[3]) / M);
+    s12[2 * n + 1] = (float)((red2[4] + red2[5] + red2[6] + red2[7]) / M);
   }
 }
 
@@ -365,7 +400,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                              const float* __restrict__ y,
                                                              const float* __restrict__ mean_rstd,
                                                              const float* __restrict__ s12,
-                                                             const float* __restrict__ gamma, float* __restrict__ dy,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ dy,
                                                              float* __restrict__ dres, i64 S, int C, i64 total_vox,
                                                              int relu) {
   if (VEC) {
@@ -381,7 +417,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
       const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * q);
       if (relu) {
-        const float4 o = *reinterpret_cast<const float4*>(out + idx * 4);
+        float4 o;
+        if (out) {
+          o = *reinterpret_cast<const float4*>(out + idx * 4);
+        } else {
+          const float4 bt = *reinterpret_cast<const float4*>(beta + 4 * q);
+          o.x = (yv.x - mean) * rstd * gm.x + bt.x; o.y = (yv.y - mean) * rstd * gm.y + bt.y;
+          o.z = (yv.z - mean) * rstd * gm.z + bt.z; o.w = (yv.w - mean) * rstd * gm.w + bt.w;
+        }
         g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
       }
       float4 d;
@@ -400,7 +443,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       const int n = (int)(v / S);
       const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
       float g = dout[idx];
-      if (relu && !(out[idx] > 0.f)) g = 0.f;
+      const float ov = out ? out[idx] : (y[idx] - mean) * rstd * gamma[c] + beta[c];
+      if (relu && !(ov > 0.f)) g = 0.f;
       dy[idx] = rstd * (gamma[c] * g - s12[2 * n] - (y[idx] - mean) * rstd * s12[2 * n + 1]);
       if (dres) dres[idx] = g;
     }
@@ -408,18 +452,18 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 }
 
 extern "C" int seg3d_gn_bwd_apply(const float* dout, const float* out, const float* y, const float* mean_rstd,
-                                  const float* s12, const float* gamma, float* dy, float* dres, int N, long long S, int C,
-                                  int relu, void* stream) {
+                                  const float* s12, const float* gamma, const float* beta, float* dy, float* dres, int N,
+                                  long long S, int C, int relu, void* stream) {
   SEG3D_REQUIRE(dout && y && mean_rstd && s12 && gamma && dy && N > 0 && S > 0 && C > 0, "seg3d_gn_bwd_apply: bad arguments");
-  SEG3D_REQUIRE(!relu || out, "seg3d_gn_bwd_apply: relu mask needs the forward output");
+  SEG3D_REQUIRE(!relu || out || beta, "seg3d_gn_bwd_apply: relu mask needs the forward output or beta");
   const i64 total_vox = (i64)N * S;
   hipStream_t s = (hipStream_t)stream;
   if ((C & 3) == 0) {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), dim3(seg3d_ew_grid(total_vox * (C / 4), 256)), dim3(256), 0, s, dout, out,
-                       y, mean_rstd, s12, gamma, dy, dres, (i64)S, C, total_vox, relu);
+                       y, mean_rstd, s12, gamma, beta, dy, dres, (i64)S, C, total_vox, relu);
   } else {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<false>), dim3(seg3d_ew_grid(total_vox * C, 256)), dim3(256), 0, s, dout, out, y,
-                       mean_rstd, s12, gamma, dy, dres, (i64)S, C, total_vox, relu);
+                       mean_rstd, s12, gamma, beta, dy, dres, (i64)S, C, total_vox, relu);
   }
   SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_apply");
   return SEG3D_OK;

@@ -325,14 +325,16 @@ def gn_apply(yn, mean_rstd, gamma, beta, resn, relu):
     return out
 
 
-def gn_backward(doutn, outn, yn, mean_rstd, gamma, relu, want_dres, want_dbias=True):
-    """returns (dy, dres or None, dgamma, dbeta, dbias or None)"""
+def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_dbias=True):
+    """returns (dy, dres or None, dgamma, dbeta, dbias or None).  `outn` (the unit's forward output) is only read when
+    it cannot be recomputed from y, i.e. when a residual was added; pass None otherwise."""
     N, D, H, W_, C = yn.shape
     S = D * H * W_
     nblk = E.query('seg3d_gn_bwd_blocks', S)
     part = _empty((N, nblk, C, 3), yn)
-    E.call('seg3d_gn_bwd_reduce', E.ptr(doutn), E.ptr(outn if relu else None), E.ptr(yn), E.ptr(mean_rstd), E.ptr(part), N,
-           S, C, int(relu), E.stream_ptr())
+    mask_src = outn if relu else None
+    E.call('seg3d_gn_bwd_reduce', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta),
+           E.ptr(part), N, S, C, int(relu), E.stream_ptr())
     abx = _empty((N, C, 3), yn)
     s12 = _empty((N, 2), yn)
     dgamma = _empty((C,), yn)
@@ -342,8 +344,8 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, relu, want_dres, want_dbias=T
            E.ptr(dbeta), E.ptr(dbias), N, S, C, E.stream_ptr())
     dy = torch.empty_like(yn)
     dres = torch.empty_like(yn) if want_dres else None
-    E.call('seg3d_gn_bwd_apply', E.ptr(doutn), E.ptr(outn if relu else None), E.ptr(yn), E.ptr(mean_rstd), E.ptr(s12),
-           E.ptr(gamma), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), E.stream_ptr())
+    E.call('seg3d_gn_bwd_apply', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(s12), E.ptr(gamma),
+           E.ptr(beta), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), E.stream_ptr())
     return dy, dres, dgamma, dbeta, dbias
 
 
@@ -370,14 +372,16 @@ class ConvGnActFunction(torch.autograd.Function):
         ctx.kind, ctx.relu = kind, bool(relu)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.w_shape = tuple(weight.shape)
-        ctx.save_for_backward(xn, w, gamma.detach(), yn, outn, mean_rstd)
+        # the forward output is kept for backward only when a residual was added (otherwise the ReLU mask is
+        # recomputed from y, saving one full-tensor read in each of the two GroupNorm backward passes)
+        ctx.save_for_backward(xn, w, gamma.detach(), beta.detach(), yn, outn if residual is not None else None, mean_rstd)
         return from_ndhwc(outn)
 
     @staticmethod
     def backward(ctx, dout):
-        xn, w, gamma, yn, outn, mean_rstd = ctx.saved_tensors
+        xn, w, gamma, beta, yn, outn, mean_rstd = ctx.saved_tensors
         dn = to_ndhwc(dout)
-        dy, dres, dgamma, dbeta, dbias = gn_backward(dn, outn, yn, mean_rstd, gamma, ctx.relu,
+        dy, dres, dgamma, dbeta, dbias = gn_backward(dn, outn, yn, mean_rstd, gamma, beta, ctx.relu,
                                                      want_dres=ctx.has_res and ctx.needs_input_grad[5],
                                                      want_dbias=ctx.has_bias)
         dx = None
@@ -431,14 +435,15 @@ class GroupNormFunction(torch.autograd.Function):
         mean_rstd = gn_stats(yn, None, eps)
         outn = gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), None, relu)
         ctx.relu = bool(relu)
-        ctx.save_for_backward(yn, outn, mean_rstd, gamma.detach())
+        ctx.save_for_backward(yn, mean_rstd, gamma.detach(), beta.detach())
         return from_ndhwc(outn)
 
     @staticmethod
     def backward(ctx, dout):
-        yn, outn, mean_rstd, gamma = ctx.saved_tensors
+        yn, mean_rstd, gamma, beta = ctx.saved_tensors
         dn = to_ndhwc(dout)
-        dy, _, dgamma, dbeta, _ = gn_backward(dn, outn, yn, mean_rstd, gamma, ctx.relu, want_dres=False, want_dbias=False)
+        dy, _, dgamma, dbeta, _ = gn_backward(dn, None, yn, mean_rstd, gamma, beta, ctx.relu, want_dres=False,
+                                              want_dbias=False)
         return from_ndhwc(dy), dgamma, dbeta, None, None
 
 

@@ -387,43 +387,58 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
   const bool pq_ok = a0 + 4 * q < CA;
   const bool qq_ok = b0 + 4 * q < CB;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // register-prefetch pipeline over the tile loop (see conv3d_k3_wgrad_mfma_kernel): this kernel is HBM-bound at the
+  // top level, so keeping the next tile's 18 x 16-byte loads per thread in flight behind the MFMA block is what
+  // keeps the memory system busy
+  constexpr int PE = (K2W_NV * 8) / 256, QE = (K2W_MT * 8) / 256;
+  f32x4 pst[PE], qst[QE];
+  auto load_tile = [&](int tile) {
     int b = tile;
     const int tix = b % ntx; b /= ntx;
     const int tiy = b % nty; b /= nty;
     const int tiz = b % ntz;
     const int n = b / ntz;
     const int z0 = tiz * K2W_TZ, y0 = tiy * K2W_TY, x0 = tix * K2W_TX;
-    __syncthreads();
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < (K2W_NV * 8) / 256; ++e) {
-      const int eidx = tid + e * 256;
-      const int v = eidx >> 3;
+    for (int e = 0; e < PE; ++e) {
+      const int v = (tid + e * 256) >> 3;
       const int hx = v % K2W_HX;
       const int t = v / K2W_HX;
       const int hy = t % K2W_HY;
       const int hz = t / K2W_HY;
       const int gz = 2 * z0 + hz, gy = 2 * y0 + hy, gx = 2 * x0 + hx;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (pq_ok && gz < Dp && gy < Hp && gx < Wp)
-        val = *reinterpret_cast<const f32x4*>(P + ((((i64)n * Dp + gz) * Hp + gy) * Wp + gx) * CA + a0 + 4 * q);
-      *reinterpret_cast<f32x4*>(ps + v * 32 + 4 * q) = val;
+      const bool ok = pq_ok && gz < Dp && gy < Hp && gx < Wp;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(
+          P + (ok ? ((((i64)n * Dp + gz) * Hp + gy) * Wp + gx) * CA + a0 + 4 * q : (i64)0));
+      pst[e] = ok ? val : zero;
     }
 #pragma unroll
-    for (int e = 0; e < (K2W_MT * 8) / 256; ++e) {
-      const int eidx = tid + e * 256;
-      const int v = eidx >> 3;
+    for (int e = 0; e < QE; ++e) {
+      const int v = (tid + e * 256) >> 3;
       const int tx = v % K2W_TX;
       const int t = v / K2W_TX;
       const int ty = t % K2W_TY;
       const int tz = t / K2W_TY;
       const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (qq_ok && gz < Dq && gy < Hq && gx < Wq)
-        val = *reinterpret_cast<const f32x4*>(Q + ((((i64)n * Dq + gz) * Hq + gy) * Wq + gx) * CB + b0 + 4 * q);
-      *reinterpret_cast<f32x4*>(qs + v * 32 + 4 * q) = val;
+      const bool ok = qq_ok && gz < Dq && gy < Hq && gx < Wq;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(
+          Q + (ok ? ((((i64)n * Dq + gz) * Hq + gy) * Wq + gx) * CB + b0 + 4 * q : (i64)0));
+      qst[e] = ok ? val : zero;
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int e = 0; e < PE; ++e) *reinterpret_cast<f32x4*>(ps + ((tid + e * 256) >> 3) * 32 + 4 * q) = pst[e];
+#pragma unroll
+    for (int e = 0; e < QE; ++e) *reinterpret_cast<f32x4*>(qs + ((tid + e * 256) >> 3) * 32 + 4 * q) = qst[e];
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
 #pragma unroll 4
     for (int kp = 0; kp < K2W_MT / 2; ++kp) {
       const int v = 2 * kp + lh;

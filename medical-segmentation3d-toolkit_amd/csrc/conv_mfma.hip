@@ -465,29 +465,30 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
   const bool xq_ok = ci0 + 4 * q < Cin;
   const bool yq_ok = co0 + 4 * q < Cout;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Register-prefetch pipeline over the tile loop: the global loads of tile t+1 are issued before the MFMA block of
+  // tile t (branch-free, clamped addresses) and written to LDS after it, so HBM/L2 latency hides behind the matrix work.
+  f32x4 xst[SEG3D_WG_XE], yst[SEG3D_WG_YE];
+  auto load_tile = [&](int tile) {
     int b = tile;
     const int tix = b % ntx; b /= ntx;
     const int tiy = b % nty; b /= nty;
     const int tiz = b % ntz;
     const int n = b / ntz;
     const int z0 = tiz * SEG3D_WG_TZ, y0 = tiy * SEG3D_WG_TY, x0 = tix * SEG3D_WG_TX;
-    __syncthreads();
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < SEG3D_WG_XE; ++e) {
       const int eidx = tid + e * 256;
-      if (eidx < SEG3D_WG_NV * 8) {
-        const int v = eidx >> 3;
-        const int hx = v % SEG3D_WG_HX;
-        const int t = v / SEG3D_WG_HX;
-        const int hy = t % SEG3D_WG_HY;
-        const int hz = t / SEG3D_WG_HY;
-        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (xq_ok && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-          val = *reinterpret_cast<const f32x4*>(x + ((((i64)n * D + gz) * H + gy) * W + gx) * Cin + ci0 + 4 * q);
-        *reinterpret_cast<f32x4*>(xs + v * 32 + 4 * q) = val;
-      }
+      const int v = eidx >> 3;
+      const int hx = v % SEG3D_WG_HX;
+      const int t = v / SEG3D_WG_HX;
+      const int hy = t % SEG3D_WG_HY;
+      const int hz = t / SEG3D_WG_HY;
+      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const bool ok = eidx < SEG3D_WG_NV * 8 && xq_ok && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(
+          x + (ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * Cin + ci0 + 4 * q : (i64)0));
+      xst[e] = ok ? val : zero;
     }
 #pragma unroll
     for (int e = 0; e < SEG3D_WG_YE; ++e) {
@@ -498,12 +499,30 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
       const int ty = t % SEG3D_WG_TY;
       const int tz = t / SEG3D_WG_TY;
       const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (yq_ok && gz < D && gy < H && gx < W)
-        val = *reinterpret_cast<const f32x4*>(dy + ((((i64)n * D + gz) * H + gy) * W + gx) * Cout + co0 + 4 * q);
-      *reinterpret_cast<f32x4*>(dys + v * 32 + 4 * q) = val;
+      const bool ok = yq_ok && gz < D && gy < H && gx < W;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(
+          dy + (ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * Cout + co0 + 4 * q : (i64)0));
+      yst[e] = ok ? val : zero;
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int e = 0; e < SEG3D_WG_XE; ++e) {
+      const int eidx = tid + e * 256;
+      if (eidx < SEG3D_WG_NV * 8) *reinterpret_cast<f32x4*>(xs + (eidx >> 3) * 32 + 4 * q) = xst[e];
+    }
+#pragma unroll
+    for (int e = 0; e < SEG3D_WG_YE; ++e) {
+      const int eidx = tid + e * 256;
+      *reinterpret_cast<f32x4*>(dys + (eidx >> 3) * 32 + 4 * q) = yst[e];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile fully consumed
+    store_tile();
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
 
 #pragma unroll 4
     for (int kp = 0; kp < SEG3D_WG_MT / 2; ++kp) {

@@ -441,41 +441,61 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
   const int q = tid & 7;
   const bool fq_ok = cf0 + 4 * q < CF;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // register-prefetch pipeline over the tile loop (HBM-bound kernel: the next tile's loads stay in flight behind
+  // the MFMA block of the current one)
+  constexpr int TE = (TH_NV * CT + 255) / 256, FE = (TH_MT * 8) / 256;
+  float tst[TE];
+  f32x4 fst[FE];
+  auto load_tile = [&](int tile) {
     int b = tile;
     const int tix = b % ntx; b /= ntx;
     const int tiy = b % nty; b /= nty;
     const int tiz = b % ntz;
     const int n = b / ntz;
     const int z0 = tiz * TH_TZ, y0 = tiy * TH_TY, x0 = tix * TH_TX;
-    __syncthreads();
-    for (int e = tid; e < TH_NV * CT; e += 256) {
+#pragma unroll
+    for (int k = 0; k < TE; ++k) {
+      const int e = tid + k * 256;
       const int v = e / CT, a = e % CT;
       const int hx = v % TH_HX;
       const int t = v / TH_HX;
       const int hy = t % TH_HY;
       const int hz = t / TH_HY;
       const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-      float val = 0.f;
-      if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-        val = thin[((((i64)n * D + gz) * H + gy) * W + gx) * CT + a];
-      ts[e] = val;
+      const bool ok = e < TH_NV * CT && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float val = thin[ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * CT + a : (i64)0];
+      tst[k] = ok ? val : 0.f;
     }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < (TH_MT * 8) / 256; ++e) {
-      const int eidx = tid + e * 256;
-      const int v = eidx >> 3;
+    for (int k = 0; k < FE; ++k) {
+      const int v = (tid + k * 256) >> 3;
       const int tx = v % TH_TX;
       const int t = v / TH_TX;
       const int ty = t % TH_TY;
       const int tz = t / TH_TY;
       const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (fq_ok && gz < D && gy < H && gx < W)
-        val = *reinterpret_cast<const f32x4*>(fat + ((((i64)n * D + gz) * H + gy) * W + gx) * CF + cf0 + 4 * q);
-      *reinterpret_cast<f32x4*>(fs + v * 32 + 4 * q) = val;
+      const bool ok = fq_ok && gz < D && gy < H && gx < W;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(
+          fat + (ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * CF + cf0 + 4 * q : (i64)0));
+      fst[k] = ok ? val : zero;
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < TE; ++k) {
+      const int e = tid + k * 256;
+      if (e < TH_NV * CT) ts[e] = tst[k];
+    }
+#pragma unroll
+    for (int k = 0; k < FE; ++k) *reinterpret_cast<f32x4*>(fs + ((tid + k * 256) >> 3) * 32 + 4 * q) = fst[k];
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
     // K (voxels) is split over the waves: wave w takes voxels [64w, 64w + 64)
 #pragma unroll 4
     for (int kp = 0; kp < 32; ++kp) {
@@ -506,18 +526,32 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
 }
 
 // dw[ct*s_ct + cf*s_cf + (flip ? 26 - t : t)] = sum_slab part[slab][cfb][row = t*CT + ct][cf % 32]
+// 16 outputs x 16 slab groups per workgroup (the output is tiny: the reduction over <= 512 slabs is the work),
+// combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void k3_thin_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                      int slabs, int CT, int CF, int CFB, int RB, i64 s_ct,
                                                                      i64 s_cf, int flip) {
+  __shared__ float red[256];
   const i64 total = (i64)27 * CT * CF;
-  for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
-    const int cf = (int)(idx % CF);
+  const i64 idx = (i64)blockIdx.x * 16 + (threadIdx.x & 15);
+  const int g = threadIdx.x >> 4;
+  float s = 0.f;
+  int t = 0, ct = 0, cf = 0;
+  if (idx < total) {
+    cf = (int)(idx % CF);
     const int row = (int)(idx / CF);
-    const int t = row / CT, ct = row % CT;
+    t = row / CT;
+    ct = row % CT;
     const float* p = part + ((i64)(cf >> 5) * RB * 1024) + (i64)row * 32 + (cf & 31);
-    float s = 0.f;
-    for (int k = 0; k < slabs; ++k) s += p[(i64)k * CFB * RB * 1024];
-    dw[ct * s_ct + cf * s_cf + (flip ? 26 - t : t)] = s;
+    for (int k = g; k < slabs; k += 16) s += p[(i64)k * CFB * RB * 1024];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && idx < total) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k * 16 + threadIdx.x];
+    dw[ct * s_ct + cf * s_cf + (flip ? 26 - t : t)] = v;
   }
 }
 
@@ -563,7 +597,7 @@ extern "C" int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* d
   }
   SEG3D_LAUNCH_CHECK("seg3d_k3_thin_wgrad");
   const i64 total = (i64)27 * CT * CF;
-  hipLaunchKernelGGL(k3_thin_wgrad_reduce_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, s, workspace, dw, slabs, CT, CF,
+  hipLaunchKernelGGL(k3_thin_wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, workspace, dw, slabs, CT, CF,
                      CFB, RB, (i64)s_ct, (i64)s_cf, flip);
   SEG3D_LAUNCH_CHECK("seg3d_k3_thin_wgrad(reduce)");
   return SEG3D_OK;

@@ -155,7 +155,14 @@ extern "C" int seg3d_gn_apply(const float* y, const float* mean_rstd, const floa
 }
 
 // ---- backward reduce: per (n, c) partial A = sum g, B = sum g*xhat, X = sum xhat ---------------------------------
-#define GN_BWD_VPB 2048  // voxels per workgroup
+// voxels per workgroup of the backward reduce: <= 2048, but small levels are cut finer so that the pass still
+// spreads over >= ~128 workgroups per sample (a 12^3 x 256-channel tensor would otherwise run on 4 workgroups)
+static inline int gn_bwd_vpb(i64 S) {
+  i64 v = (S + 127) / 128;
+  if (v < 32) v = 32;
+  if (v > 2048) v = 2048;
+  return (int)v;
+}
 
 // fast path: C % 4 == 0 and (C/4) divides 256: thread = (channel quad, voxel lane)
 __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __restrict__ dout,
@@ -165,14 +172,14 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __r
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta,
                                                                   float* __restrict__ part, i64 S, int C, int nblk,
-                                                                  int relu) {
+                                                                  int relu, int vpb) {
   __shared__ float red[256 * 12];
   const int n = blockIdx.y;
   const int CQ = C >> 2, VL = 256 / CQ;
   const int q = threadIdx.x % CQ, vl = threadIdx.x / CQ;
   const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
-  const i64 s0 = (i64)blockIdx.x * GN_BWD_VPB;
-  i64 s1 = s0 + GN_BWD_VPB;
+  const i64 s0 = (i64)blockIdx.x * vpb;
+  i64 s1 = s0 + vpb;
   if (s1 > S) s1 = S;
   float a[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0}, xx[4] = {0, 0, 0, 0};
   // 4 voxels per trip: 12 independent 16-byte loads in flight per thread (the kernel is pure streaming)
@@ -243,12 +250,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_small_kernel(const float* _
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta,
                                                                     float* __restrict__ part, i64 S, int C, int nblk,
-                                                                    int relu) {
+                                                                    int relu, int vpb) {
   __shared__ float red[4 * 3];
   const int n = blockIdx.y;
   const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
-  const i64 s0 = (i64)blockIdx.x * GN_BWD_VPB;
-  i64 s1 = s0 + GN_BWD_VPB;
+  const i64 s0 = (i64)blockIdx.x * vpb;
+  i64 s1 = s0 + vpb;
   if (s1 > S) s1 = S;
   float a[GN_SMALLC], bb[GN_SMALLC], xx[GN_SMALLC];
 #pragma unroll
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_small_kernel(const float* _
   }
 }
 
-extern "C" long long seg3d_gn_bwd_blocks(long long S) { return (S + GN_BWD_VPB - 1) / GN_BWD_VPB; }
+extern "C" long long seg3d_gn_bwd_blocks(long long S) { const int v = gn_bwd_vpb(S); return (S + v - 1) / v; }
 
 static bool gn_vec_ok(int C) { return (C & 3) == 0 && (C >> 2) <= 256 && (256 % (C >> 2)) == 0; }
 
@@ -297,10 +304,10 @@ extern "C" int seg3d_gn_bwd_reduce(const float* dout, const float* out, const fl
   hipStream_t s = (hipStream_t)stream;
   if (gn_vec_ok(C)) {
     hipLaunchKernelGGL(gn_bwd_reduce_vec_kernel, dim3(nblk, N), dim3(256), 0, s, dout, out, y, mean_rstd, gamma, beta, part,
-                       (i64)S, C, nblk, relu);
+                       (i64)S, C, nblk, relu, gn_bwd_vpb(S));
   } else if (C <= GN_SMALLC) {
     hipLaunchKernelGGL(gn_bwd_reduce_small_kernel, dim3(nblk, N), dim3(256), 0, s, dout, out, y, mean_rstd, gamma, beta,
-                       part, (i64)S, C, nblk, relu);
+                       part, (i64)S, C, nblk, relu, gn_bwd_vpb(S));
   } else {
     SEG3D_UNSUPPORTED("seg3d_gn_bwd_reduce: unsupported channel count %d (need C<=16 or C%%4==0 with C/4 | 256)", C);
   }

@@ -110,6 +110,22 @@ class KernelTimer(object):
         return table
 
 
+def pmc_traffic_gb(kernel_name):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_fetch_write_per_kernel.json: FETCH_SIZE and WRITE_SIZE in KB, collected in separate --pmc
+    passes).  gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE under-reports wide coalesced reads
+    by 2x, WRITE_SIZE is exact.  Counters cannot be collected from inside bench.py; returns None when absent."""
+    path = os.path.join(REPO, 'profiles', 'r01_pmc_fetch_write_per_kernel.json')
+    if not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    e = table.get(kernel_name)
+    if not e or 'FETCH_SIZE_KB_per_launch' not in e or 'WRITE_SIZE_KB_per_launch' not in e:
+        return None
+    return round((2.0 * e['FETCH_SIZE_KB_per_launch'] + e['WRITE_SIZE_KB_per_launch']) * 1024 / 1e9, 3)
+
+
 def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):
     """oracle train step (stock torch CPU ops + torch.optim.Adam), B = 1, on this host: ~10-30 s of CPU work"""
     from oracle import torch_ref
@@ -171,11 +187,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device (the engine has no CPU path)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # one process per GPU over RCCL ("nccl" on ROCm).  SEG3D_DIST_BACKEND=gloo allows rehearsing the N > 1 code path
+    # with several ranks sharing one GPU (RCCL refuses two ranks on one device); never used for reported numbers.
+    backend = os.environ.get('SEG3D_DIST_BACKEND', 'nccl')
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         sys.stderr.write('note: --gpus {} but WORLD_SIZE {}\n'.format(args.gpus, world))
 
@@ -208,22 +231,27 @@ def main():
     value = world * args.batch * args.steps / elapsed
 
     roofline, kernels = None, None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
+        # two extra, instrumented steps AFTER the timed region; every rank runs them (the gradient all-reduce is a
+        # collective), rank 0 reports
         with KernelTimer() as kt:
             for _ in range(2):
                 step(x, t)
         table = kt.summary()
+    if not args.no_roofline and rank == 0:
         by_variant = {}
         for key, e in table.items():
             v = by_variant.setdefault(key[6], {'launches': 0, 'ms': 0.0, 'flops': 0.0})
             for k in v:
                 v[k] += e[k]
         dom = max(by_variant, key=lambda m: by_variant[m]['ms'])
+        traffic = pmc_traffic_gb('void conv3d_k3_mfma_kernel<{}>'.format(dom))
         d = by_variant[dom]
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
         roofline = {'kernel': 'conv3d_k3_mfma_kernel<{}>'.format(dom), 'bound': 'mfma', 'achieved': round(achieved, 2),
                     'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                    'traffic': None, 'launches_per_step': d['launches'] // 2,
+                    'traffic': traffic, 'traffic_unit': 'GB per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, see profiles/)',
+                    'launches_per_step': d['launches'] // 2,
                     'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                     'gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
                     'share_of_step_ms': round(d['ms'] / 2, 3)}

@@ -25,6 +25,7 @@
 //   Partial slabs are reduced in fixed order by conv3d_k3_wgrad_reduce_kernel (bitwise reproducible).
 #include "seg3d_common.h"
 #include "seg3d_hip.h"
+#include <math.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -285,8 +286,10 @@ __global__ __launch_bounds__(256) void conv3d_splitk_finish_kernel(const float* 
   }
 }
 
-// Pick the output tile for one level: at most 512 voxels (4 waves x 4 accumulators), halo tile <= 1280 voxels,
-// as few wasted (masked) voxels and as little halo as possible, and enough workgroups to fill 256 CUs.
+// Pick the output tile for one level by a small time model: a workgroup's duration is proportional to its MFMA row
+// blocks per wave (MA) plus a mild halo-staging term; 512 workgroups are resident at once (2 per CU), a partial last
+// round runs somewhat faster than a full one (its workgroups have their SIMDs to themselves).  Constraints: tile <= 512
+// voxels (4 waves x 4 accumulators), halo tile <= 1280 voxels (staging registers).
 static Seg3dTile seg3d_pick_tile(int N, int D, int H, int W, int cout_blocks) {
   const int cand_z[] = {1, 2, 3, 4, 6, 8};
   const int cand_y[] = {2, 3, 4, 6, 8, 12, 16};
@@ -302,16 +305,14 @@ static Seg3dTile seg3d_pick_tile(int N, int D, int H, int W, int cout_blocks) {
         const int nv = (tz + 2) * (ty + 2) * (tx + 2);
         if (2 * nv > SEG3D_MAXE * 256) continue;
         const int ntz = seg3d_cdiv(D, tz), nty = seg3d_cdiv(H, ty), ntx = seg3d_cdiv(W, tx);
-        const double tiles = (double)N * ntz * nty * ntx;
+        const double wgs = (double)N * ntz * nty * ntx * cout_blocks;
         const int subs = (mt + 31) / 32;
         const int ma = (subs + 3) / 4;
-        // MFMA slots issued per tile (4 waves x ma) vs useful voxels
-        const double slots = tiles * 4.0 * ma * 32.0;
-        const double useful = (double)N * D * H * W;
-        double cost = slots / useful;                 // >= 1, MFMA waste
-        cost *= 1.0 + 0.08 * ((double)nv / mt - 1.0);  // halo staging overhead (mild)
-        const double wgs = tiles * cout_blocks;
-        if (wgs < 512.0) cost *= 1.0 + 0.5 * (512.0 - wgs) / 512.0;  // under-filled chip
+        const double full = floor(wgs / 512.0);
+        const double rem = wgs - 512.0 * full;
+        const double rounds = full + (rem > 0.0 ? 0.55 + 0.45 * rem / 512.0 : 0.0);
+        const double per_wg = (double)ma * (1.0 + 0.06 * ((double)nv / mt - 1.0)) + 0.35;  // + fixed prologue/epilogue
+        const double cost = rounds * per_wg;
         if (cost < best_cost) {
           best_cost = cost;
           best = {tz, ty, tx};

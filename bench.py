@@ -82,7 +82,7 @@ class KernelTimer(object):
         def call(name, *args):
             if name != 'seg3d_conv3d_k3_mfma_fwd':
                 return timer._orig(name, *args)
-            N, D, H, W, Cin, Cout = args[6:12]
+            N, D, H, W, Cin, Cout = args[7:13]
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             rc = timer._orig(name, *args)

@@ -67,9 +67,10 @@ int seg3d_wgrad_reduce(const float* part, float* dw, int chunks, int T, int A, i
 long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W, int Cin, int Cout);
 long long seg3d_conv3d_k3_mfma_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cout);
-int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp_mfma, const float* bias, float* y, float* stats_partial,
-                             float* workspace /* split-K partials, may be NULL when the query returns 0 */, int N, int D,
-                             int H, int W, int Cin, int Cout, void* stream);
+int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp_mfma, const float* bias,
+                             const float* addend /* optional, shape of y: y = conv + bias + addend */, float* y,
+                             float* stats_partial, float* workspace /* split-K partials; NULL when the query returns 0 */,
+                             int N, int D, int H, int W, int Cin, int Cout, void* stream);
 long long seg3d_conv3d_k3_mfma_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H, int W,
                                int Cin, int Cout, void* stream);

@@ -39,7 +39,7 @@ template <int MA>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ stats, int N, int D, int H, int W, int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
-    int ntx, float* __restrict__ kpart, int cpk) {
+    int ntx, float* __restrict__ kpart, int cpk, const float* __restrict__ addend) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int HY = TY + 2, HX = TX + 2;
   const int NV = (TZ + 2) * HY * HX;
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
       const bool ok = vo >= 0 && co_ok;
       ooff[m][r] = ok ? vo * Cout + co : -1;
       acc[m][r] += bv;
+      if (addend && ok) acc[m][r] += addend[(i64)ooff[m][r]];  // fused "+ residual-path gradient" (dgrad use)
       const float val = ok ? acc[m][r] : 0.f;
       s[0] += val;
       s[1] += val * val;
@@ -255,7 +256,8 @@ struct Seg3dTile {
 
 // y[e] = bias[c] + sum_ks part[ks][e]; emits GroupNorm (sum, sumsq) partials per workgroup.  HBM-bound, float4.
 __global__ __launch_bounds__(256) void conv3d_splitk_finish_kernel(const float* __restrict__ part,
-                                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                                     const float* __restrict__ bias,
+                                                                     const float* __restrict__ addend, float* __restrict__ y,
                                                                      float* __restrict__ stats, int KS, i64 M, i64 total,
                                                                      int Cout, int nblk) {
   __shared__ float red[8];
@@ -274,6 +276,10 @@ __global__ __launch_bounds__(256) void conv3d_splitk_finish_kernel(const float* 
     if (bias) {
       const int c = (int)(e % Cout);
       acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3];
+    }
+    if (addend) {
+      const float4 a = *reinterpret_cast<const float4*>(addend + g);
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
     }
     *reinterpret_cast<float4*>(y + g) = acc;
     s[0] += (acc.x + acc.y) + (acc.z + acc.w);
@@ -361,7 +367,8 @@ extern "C" int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cout
 
 template <int MA>
 static int launch_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
-                      int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, float* kpart, int ks) {
+                      int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, float* kpart, int ks,
+                      const float* addend) {
   const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
   const size_t lds = seg3d_fwd_lds_bytes(t);
   static size_t configured = 0;
@@ -378,14 +385,17 @@ static int launch_fwd(const float* x, const float* wp, const float* bias, float*
   const int cpk = (cib + ks - 1) / ks;
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32), (unsigned)(ks > 1 ? (cib + cpk - 1) / cpk : 1));
   hipLaunchKernelGGL((conv3d_k3_mfma_kernel<MA>), grid, dim3(256), lds, s, x, wp, bias, y, stats, N, D, H, W, Cin, Cout,
-                     t.tz, t.ty, t.tx, ntz, nty, ntx, ks > 1 ? kpart : nullptr, cpk);
+                     t.tz, t.ty, t.tx, ntz, nty, ntx, ks > 1 ? kpart : nullptr, cpk, ks > 1 ? nullptr : addend);
   return SEG3D_OK;
 }
 
 // x [N][D][H][W][Cin], wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 27), y [N][D][H][W][Cout];
 // stats (optional): [N][seg3d_conv3d_k3_mfma_stats_count][2] partial (sum, sumsq) of y per sample.
-extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
-                                        float* workspace, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+// addend (optional, same shape as y): y = conv(x) + bias + addend -- used by the data-gradient of the first conv of a
+// residual block to fold in the gradient that arrives through the identity path.
+extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const float* bias, const float* addend, float* y,
+                                        float* stats, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
+                                        void* stream) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_mfma_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k3_mfma_fwd: bad dims");
   SEG3D_REQUIRE((Cin % 4) == 0, "seg3d_conv3d_k3_mfma_fwd: Cin must be a multiple of 4 (got %d); use the direct kernel", Cin);
@@ -401,10 +411,10 @@ extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const f
                 "(seg3d_conv3d_k3_mfma_fwd_workspace_floats)");
   int rc;
   switch (ma) {
-    case 1: rc = launch_fwd<1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks); break;
-    case 2: rc = launch_fwd<2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks); break;
-    case 3: rc = launch_fwd<3>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks); break;
-    case 4: rc = launch_fwd<4>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks); break;
+    case 1: rc = launch_fwd<1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks, addend); break;
+    case 2: rc = launch_fwd<2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks, addend); break;
+    case 3: rc = launch_fwd<3>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks, addend); break;
+    case 4: rc = launch_fwd<4>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks, addend); break;
     default:
       SEG3D_UNSUPPORTED("seg3d_conv3d_k3_mfma_fwd: internal tile error (ma=%d)", ma);
   }
@@ -414,7 +424,7 @@ extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const f
     const i64 M = (i64)D * H * W * Cout;
     const int nblk = (int)((M + SPLITK_CHUNK - 1) / SPLITK_CHUNK);
     const int cib = (Cin + 7) / 8, cpk = (cib + ks - 1) / ks;
-    hipLaunchKernelGGL(conv3d_splitk_finish_kernel, dim3(nblk, N), dim3(256), 0, s, workspace, bias, y, stats,
+    hipLaunchKernelGGL(conv3d_splitk_finish_kernel, dim3(nblk, N), dim3(256), 0, s, workspace, bias, addend, y, stats,
                        (cib + cpk - 1) / cpk, M, (i64)N * M, Cout, nblk);
     SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_fwd(split-K finish)");
   }

@@ -82,8 +82,8 @@ def _use_mfma(cin, cout):
     return (not FORCE_DIRECT) and cin % 4 == 0 and cin >= 8 and cout >= 8
 
 
-def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats):
-    """y[v][b] = bias[b] + sum_{t,a} x[v + t - 1][a] W(a,b,t);  returns (y, stats_partial or None)"""
+def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None):
+    """y[v][b] = bias[b] + sum_{t,a} x[v + t - 1][a] W(a,b,t) [+ addend];  returns (y, stats_partial or None)"""
     N, D, H, W_, Cin = xn.shape
     assert Cin == A
     y = _empty((N, D, H, W_, B), xn)
@@ -95,9 +95,12 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats):
             stats = _empty((N, cnt, 2), xn)
         nws = E.query('seg3d_conv3d_k3_mfma_fwd_workspace_floats', N, D, H, W_, A, B)
         ws = _empty((nws,), xn) if nws else None    # split-K partial slabs for the deep, spatially tiny levels
-        E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), E.ptr(ws), N, D, H,
-               W_, A, B, E.stream_ptr())
+        E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(addend), E.ptr(y), E.ptr(stats),
+               E.ptr(ws), N, D, H, W_, A, B, E.stream_ptr())
         return y, stats
+    if addend is not None:   # the special-case kernels below have no fused addend: add afterwards (device op)
+        y2, st = _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats)
+        return y2.add_(addend), st
     if A <= 8 and not FORCE_DIRECT:
         # thin input (stem forward, head data-gradient): all 27*A taps folded into one MFMA K dimension
         wp = _empty((E.query('seg3d_packed_thin_in_floats', A, B),), w)
@@ -215,14 +218,17 @@ def _check_w(w, shape, kind):
         raise ValueError('conv weights must be contiguous')
 
 
-def conv_dgrad(dyn, w, kind):
-    """gradient w.r.t. the conv input; dyn: [N,Do,Ho,Wo,Cout] contiguous"""
+def conv_dgrad(dyn, w, kind, addend=None):
+    """gradient w.r.t. the conv input (+ addend, an extra gradient for the same tensor that is folded into the kernel
+    epilogue); dyn: [N,Do,Ho,Wo,Cout] contiguous"""
     N, D, H, W_, _ = dyn.shape
     if kind == 'k3':
         Cout, Cin = w.shape[0], w.shape[1]
         # dx[v][ci] = sum_{t',co} dy[v + t' - 1][co] w[co][ci][26 - t']
-        dx, _ = _conv_k3_generic(dyn, w, None, Cout, Cin, Cin * 27, 27, 1, False)
+        dx, _ = _conv_k3_generic(dyn, w, None, Cout, Cin, Cin * 27, 27, 1, False, addend=addend)
         return dx
+    if addend is not None:
+        return conv_dgrad(dyn, w, kind).add_(addend)
     if kind == 'k2s2':
         Cout, Cin = w.shape[0], w.shape[1]
         # dx[2v + t][ci] = sum_co dy[v][co] w[co][ci][t]  == transposed conv of dy
@@ -352,11 +358,25 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
 # ------------------------------------------------------------------------------------------------------------------
 # autograd functions
 # ------------------------------------------------------------------------------------------------------------------
+class ResidualLink(object):
+    """Side channel between the LAST unit of a residual block (which receives the block input as `residual`) and its
+    FIRST unit (whose conv input is that same tensor).  In backward the last unit runs first and parks the gradient of
+    the identity path here; the first unit's data-gradient kernel adds it in its epilogue, so the block input's
+    gradient is written once instead of being summed by a separate elementwise pass over two full tensors
+    (residual_block3.py:24: act(input + ops(input)))."""
+
+    def __init__(self):
+        self.grad = None
+
+
 class ConvGnActFunction(torch.autograd.Function):
-    """out = act(GroupNorm_1(conv(x) + bias) [+ residual]); conv kind in {'k3','k2s2','k1','convT'}"""
+    """out = act(GroupNorm_1(conv(x) + bias) [+ residual]); conv kind in {'k3','k2s2','k1','convT'}.
+    link_in: ResidualLink whose parked gradient this unit adds to its input gradient (first unit of a block);
+    link_out: ResidualLink where this unit parks the residual gradient instead of returning it (last unit).
+    When x is the residual itself (single-conv block) the two gradients are fused without a link."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, residual, kind, relu, eps):
+    def forward(ctx, x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in=None, link_out=None):
         E.require_device(x, weight, bias, gamma, beta, residual)
         xn = to_ndhwc(x)
         w = weight.detach()
@@ -372,6 +392,8 @@ class ConvGnActFunction(torch.autograd.Function):
         ctx.kind, ctx.relu = kind, bool(relu)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.w_shape = tuple(weight.shape)
+        ctx.res_is_x = residual is not None and residual is x
+        ctx.link_in, ctx.link_out = link_in, (link_out if residual is not None else None)
         # the forward output is kept for backward only when a residual was added (otherwise the ReLU mask is
         # recomputed from y, saving one full-tensor read in each of the two GroupNorm backward passes)
         ctx.save_for_backward(xn, w, gamma.detach(), beta.detach(), yn, outn if residual is not None else None, mean_rstd)
@@ -385,15 +407,25 @@ class ConvGnActFunction(torch.autograd.Function):
                                                      want_dres=ctx.has_res and ctx.needs_input_grad[5],
                                                      want_dbias=ctx.has_bias)
         dx = None
+        addend = None
+        if ctx.res_is_x and dres is not None and ctx.needs_input_grad[0]:
+            addend, dres = dres, None                      # single-conv block: identity-path gradient joins dx here
+        elif ctx.link_out is not None and dres is not None:
+            ctx.link_out.grad, dres = dres, None           # parked for the block's first unit (runs later in backward)
+        if ctx.link_in is not None and ctx.link_in.grad is not None:
+            if addend is not None or not ctx.needs_input_grad[0]:
+                raise RuntimeError('ResidualLink misuse: the linked unit must produce exactly one input gradient')
+            addend, ctx.link_in.grad = ctx.link_in.grad, None
         if ctx.needs_input_grad[0]:
-            dx = from_ndhwc(conv_dgrad(dy, w, ctx.kind))
+            dx = from_ndhwc(conv_dgrad(dy, w, ctx.kind, addend=addend))
         dw = conv_wgrad(xn, dy, ctx.w_shape, ctx.kind) if ctx.needs_input_grad[1] else None
         return (dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta,
-                from_ndhwc(dres) if dres is not None else None, None, None, None)
+                from_ndhwc(dres) if dres is not None else None, None, None, None, None, None)
 
 
-def conv_gn_act(x, weight, bias, gamma, beta, residual=None, kind='k3', relu=True, eps=GN_EPS):
-    return ConvGnActFunction.apply(x, weight, bias, gamma, beta, residual, kind, relu, eps)
+def conv_gn_act(x, weight, bias, gamma, beta, residual=None, kind='k3', relu=True, eps=GN_EPS, link_in=None,
+                link_out=None):
+    return ConvGnActFunction.apply(x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in, link_out)
 
 
 class ConvFunction(torch.autograd.Function):

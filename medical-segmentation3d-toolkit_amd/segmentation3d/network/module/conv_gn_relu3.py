@@ -21,11 +21,13 @@ class ConvGnRelu3(nn.Module):
         if do_act:
             self.act = ReLU(inplace=True)
 
-    def forward(self, input, residual=None, force_act=False):
+    def forward(self, input, residual=None, force_act=False, link_in=None, link_out=None):
         """`residual`/`force_act` let a residual block fuse `ReLU(input + GN(conv(.)))` into this unit
-        (residual_block3.py:24); without them this is exactly the reference forward."""
+        (residual_block3.py:24); `link_in`/`link_out` (see _ops.ResidualLink) let the block's first and last unit fuse
+        the backward sum of the identity-path and conv-path gradients.  Without them this is the reference forward."""
         return _ops.conv_gn_act(input, self.conv.weight, self.conv.bias, self.gn.weight, self.gn.bias,
-                                residual=residual, kind=self.conv.kind, relu=self.do_act or force_act, eps=self.gn.eps)
+                                residual=residual, kind=self.conv.kind, relu=self.do_act or force_act, eps=self.gn.eps,
+                                link_in=link_in, link_out=link_out)
 
 
 class BottConvGnRelu3(nn.Module):
@@ -37,6 +39,6 @@ class BottConvGnRelu3(nn.Module):
         self.conv2 = ConvGnRelu3(in_channels // ratio, in_channels // ratio, ksize, stride, padding, do_act=True, bias=bias)
         self.conv3 = ConvGnRelu3(in_channels // ratio, out_channels, ksize, stride, padding, do_act=do_act, bias=bias)
 
-    def forward(self, input, residual=None, force_act=False):
-        out = self.conv2(self.conv1(input))
-        return self.conv3(out, residual=residual, force_act=force_act)
+    def forward(self, input, residual=None, force_act=False, link_in=None, link_out=None):
+        out = self.conv2(self.conv1(input, link_in=link_in))
+        return self.conv3(out, residual=residual, force_act=force_act, link_out=link_out)

@@ -5,8 +5,23 @@ GroupNorm-apply kernel, so the block costs no extra pass over the tensor.
 """
 import torch.nn as nn
 
+from segmentation3d import _ops
+
 from segmentation3d.network.module.conv_gn_relu3 import ConvGnRelu3, BottConvGnRelu3
 from segmentation3d.network.module.layers import ReLU
+
+
+def _residual_forward(ops, input):
+    """act(input + ops(input)) with the add + ReLU fused into the last unit (residual_block3.py:21-26, 44-46) and, for
+    backward, the identity-path gradient routed from the last unit to the first unit's data-gradient kernel."""
+    n = len(ops)
+    if n == 1:
+        return ops[0](input, residual=input, force_act=True)
+    link = _ops.ResidualLink() if input.requires_grad else None
+    output = ops[0](input, link_in=link)
+    for i in range(1, n - 1):
+        output = ops[i](output)
+    return ops[n - 1](output, residual=input, force_act=True, link_out=link)
 
 
 class ResidualBlock3(nn.Module):
@@ -21,14 +36,7 @@ class ResidualBlock3(nn.Module):
         self.act = ReLU(inplace=True)
 
     def forward(self, input):
-        output = input
-        n = len(self.ops)
-        for i, op in enumerate(self.ops):
-            if i != n - 1:
-                output = op(output)
-            else:
-                output = op(output, residual=input, force_act=True)  # act(input + ops(input))
-        return output
+        return _residual_forward(self.ops, input)
 
 
 class BottResidualBlock3(nn.Module):
@@ -43,11 +51,4 @@ class BottResidualBlock3(nn.Module):
         self.act = ReLU(inplace=True)
 
     def forward(self, input):
-        output = input
-        n = len(self.ops)
-        for i, op in enumerate(self.ops):
-            if i != n - 1:
-                output = op(output)
-            else:
-                output = op(output, residual=input, force_act=True)
-        return output
+        return _residual_forward(self.ops, input)

@@ -61,7 +61,7 @@ long long seg3d_wgrad_direct_workspace_floats(int N, int Dq, int Hq, int Wq, int
 int seg3d_wgrad_direct(const float* P, const float* Q, float* part, int N, int Dp, int Hp, int Wp, int CA, int CB,
                        int ksize, int stride, int* n_chunks_out /* host */, void* stream);
 int seg3d_wgrad_reduce(const float* part, float* dw, int chunks, int T, int A, int B, long long sa, long long sb,
-                       void* stream);
+                       int accumulate /* dw += instead of = */, void* stream);
 
 /* fp32 MFMA implicit-GEMM path for k3 s1 p1 with Cin % 4 == 0 (the FLOP-dominant C->C layers) */
 long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W, int Cin, int Cout);
@@ -73,7 +73,7 @@ int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp_mfma, const float* 
                              int N, int D, int H, int W, int Cin, int Cout, void* stream);
 long long seg3d_conv3d_k3_mfma_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H, int W,
-                               int Cin, int Cout, void* stream);
+                               int Cin, int Cout, int accumulate, void* stream);
 
 /* fp32 MFMA path for the stride-2 2x2x2 layers (Cin % 4 == 0): gather = Conv3d k2s2 forward / ConvTranspose3d dgrad,
  * scatter = ConvTranspose3d k2s2 forward / Conv3d k2s2 dgrad, pair-reduce = weight gradient of both */
@@ -85,7 +85,7 @@ int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp_mfma, const floa
                                 int N, int Di, int Hi, int Wi, int Cin, int Cout, void* stream);
 long long seg3d_k2_mfma_wgrad_workspace_floats(int N, int Dq, int Hq, int Wq, int CA, int CB);
 int seg3d_k2_mfma_wgrad(const float* P, const float* Q, float* dw, float* workspace, int N, int Dq, int Hq, int Wq, int CA,
-                        int CB, long long sa, long long sb, void* stream);
+                        int CB, long long sa, long long sb, int accumulate, void* stream);
 
 /* thin 3x3x3 layers at full resolution (stem Cin <= 8 -> 16, head 32 -> num_classes <= 8): HBM-bound special cases
  * of Conv3d k3 p1 (vnet_inblock.py:9, vnet_outblock.py:13) and of their autograd adjoints */
@@ -101,7 +101,7 @@ int seg3d_conv3d_k3_thin_out_fwd(const float* x, const float* wq, const float* b
                                  int D, int H, int W, int Cin, int Cout, int CO, void* stream);
 long long seg3d_k3_thin_wgrad_workspace_floats(int N, int D, int H, int W, int CT, int CF);
 int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* dw, float* workspace, int N, int D, int H, int W, int CT,
-                        int CF, long long s_ct, long long s_cf, int flip, void* stream);
+                        int CF, long long s_ct, long long s_cf, int flip, int accumulate, void* stream);
 
 /* ---- GroupNorm(1, C) [+ ReLU] [+ residual]  (network/module/conv_gn_relu3.py:11,14; residual_block3.py:24,46) ------ */
 long long seg3d_gn_stats_count(long long M);
@@ -114,7 +114,8 @@ int seg3d_gn_bwd_reduce(const float* dout, const float* out /* NULL: recompute t
                         const float* mean_rstd, const float* gamma, const float* beta, float* part, int N, long long S,
                         int C, int relu, void* stream);
 int seg3d_gn_bwd_finalize(const float* part, const float* gamma, const float* mean_rstd, float* abx, float* s12,
-                          float* dgamma, float* dbeta, float* dbias, int N, long long S, int C, void* stream);
+                          float* dgamma, float* dbeta, float* dbias, int N, long long S, int C,
+                          int acc_mask /* bit 0/1/2: accumulate into dgamma/dbeta/dbias */, void* stream);
 int seg3d_gn_bwd_apply(const float* dout, const float* out /* NULL: recompute */, const float* y, const float* mean_rstd,
                        const float* s12, const float* gamma, const float* beta, float* dy, float* dres, int N, long long S,
                        int C, int relu, void* stream);

@@ -338,7 +338,8 @@ extern "C" int seg3d_wgrad_direct(const float* P, const float* Q, float* part, i
 
 // dw[a*sa + b*sb + t] = sum_chunk part[chunk][t][a][bp]   (fixed chunk order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                             int chunks, int T, int A, int B, int BP, i64 sa, i64 sb) {
+                                                             int chunks, int T, int A, int B, int BP, i64 sa, i64 sb,
+                                                             int accumulate) {
   const i64 total = (i64)T * A * B;
   const i64 slab = (i64)T * A * BP;
   for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
@@ -349,17 +350,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const float* p = part + ((i64)t * A + a) * BP + b;
     float s = 0.f;
     for (int c = 0; c < chunks; ++c) s += p[(i64)c * slab];
-    dw[a * sa + b * sb + t] = s;
+    float* d = dw + a * sa + b * sb + t;
+    *d = accumulate ? *d + s : s;
   }
 }
 
 extern "C" int seg3d_wgrad_reduce(const float* part, float* dw, int chunks, int T, int A, int B, long long sa,
-                                  long long sb, void* stream) {
+                                  long long sb, int accumulate, void* stream) {
   SEG3D_REQUIRE(part && dw && chunks > 0 && T > 0 && A > 0 && B > 0, "seg3d_wgrad_reduce: bad arguments");
   const int BP = seg3d_round_up(B, 4);
   i64 total = (i64)T * A * B;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, part, dw,
-                     chunks, T, A, B, BP, (i64)sa, (i64)sb);
+                     chunks, T, A, B, BP, (i64)sa, (i64)sb, accumulate);
   SEG3D_LAUNCH_CHECK("seg3d_wgrad_reduce");
   return SEG3D_OK;
 }

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
 // dw[a*sa + b*sb + t] = sum_slab part[slab][a/32][b/32][t][a%32][b%32]   (a = reduction-side channel, b = output channel)
 // 64 outputs per workgroup, 4 slab groups per output (coalesced reads of every slab), combined in a fixed order.
 __global__ __launch_bounds__(256) void k2_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int slabs, int A,
-             int B, int BB32, int npairs, i64 sa, i64 sb) {
+             int B, int BB32, int npairs, i64 sa, i64 sb, int accumulate) {
   constexpr int T = 8;
   __shared__ float red[256];
   const i64 total = (i64)npairs * T * 1024;
@@ -487,7 +487,10 @@ __global__ __launch_bounds__(256) void k2_wgrad_reduce_kernel(const float* __res
     const int t = (int)(r % T);
     const int pair = (int)(r / T);
     const int a = (pair / BB32) * 32 + a32, b = (pair % BB32) * 32 + b32;
-    if (a < A && b < B) dw[a * sa + b * sb + t] = v;
+    if (a < A && b < B) {
+      float* d = dw + a * sa + b * sb + t;
+      *d = accumulate ? *d + v : v;
+    }
   }
 }
 
@@ -506,7 +509,7 @@ extern "C" long long seg3d_k2_mfma_wgrad_workspace_floats(int N, int Dq, int Hq,
 
 // P [N][2Dq][2Hq][2Wq][CA], Q [N][Dq][Hq][Wq][CB];  dw[a*sa + b*sb + t] (t < 8) receives the gradient
 extern "C" int seg3d_k2_mfma_wgrad(const float* P, const float* Q, float* dw, float* workspace, int N, int Dq, int Hq,
-                                   int Wq, int CA, int CB, long long sa, long long sb, void* stream) {
+                                   int Wq, int CA, int CB, long long sa, long long sb, int accumulate, void* stream) {
   SEG3D_REQUIRE(P && Q && dw && workspace, "seg3d_k2_mfma_wgrad: null pointer");
   SEG3D_REQUIRE(N > 0 && Dq > 0 && Hq > 0 && Wq > 0 && CA > 0 && CB > 0, "seg3d_k2_mfma_wgrad: bad dims");
   SEG3D_REQUIRE((CA % 4) == 0 && (CB % 4) == 0, "seg3d_k2_mfma_wgrad: channel counts must be multiples of 4 (got %d, %d)",
@@ -522,7 +525,7 @@ extern "C" int seg3d_k2_mfma_wgrad(const float* P, const float* Q, float* dw, fl
   SEG3D_LAUNCH_CHECK("seg3d_k2_mfma_wgrad");
   const i64 total = (i64)npairs * 8 * 1024;
   hipLaunchKernelGGL(k2_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dw, slabs, CA, CB,
-                     BB32, npairs, (i64)sa, (i64)sb);
+                     BB32, npairs, (i64)sa, (i64)sb, accumulate);
   SEG3D_LAUNCH_CHECK("seg3d_k2_mfma_wgrad(reduce)");
   return SEG3D_OK;
 }

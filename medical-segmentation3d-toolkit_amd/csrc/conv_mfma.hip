@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
 // dw[a*sa + b*sb + t] = sum_slab part[slab][a/32][b/32][t][a%32][b%32]   (a = reduction-side channel, b = output channel)
 // 64 outputs per workgroup, 4 slab groups per output (coalesced reads of every slab), combined in a fixed order.
 __global__ __launch_bounds__(256) void conv3d_k3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int slabs, int A,
-                    int B, int BB32, int npairs, i64 sa, i64 sb) {
+                    int B, int BB32, int npairs, i64 sa, i64 sb, int accumulate) {
   constexpr int T = 27;
   __shared__ float red[256];
   const i64 total = (i64)npairs * T * 1024;
@@ -587,7 +587,10 @@ __global__ __launch_bounds__(256) void conv3d_k3_wgrad_reduce_kernel(const float
     const int t = (int)(r % T);
     const int pair = (int)(r / T);
     const int a = (pair / BB32) * 32 + a32, b = (pair % BB32) * 32 + b32;
-    if (a < A && b < B) dw[a * sa + b * sb + t] = v;
+    if (a < A && b < B) {
+      float* d = dw + a * sa + b * sb + t;
+      *d = accumulate ? *d + v : v;
+    }
   }
 }
 
@@ -606,7 +609,7 @@ extern "C" long long seg3d_conv3d_k3_mfma_wgrad_workspace_floats(int N, int D, i
 
 // dw is written in the reference Conv3d layout [Cout][Cin][3][3][3]  (sa = 27 for ci, sb = Cin*27 for co).
 extern "C" int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D,
-                                          int H, int W, int Cin, int Cout, void* stream) {
+                                          int H, int W, int Cin, int Cout, int accumulate, void* stream) {
   SEG3D_REQUIRE(x && dy && dw && workspace, "seg3d_conv3d_k3_mfma_wgrad: null pointer");
   SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k3_mfma_wgrad: bad dims");
   SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
@@ -622,7 +625,7 @@ extern "C" int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_wgrad");
   const i64 total = (i64)npairs * 27 * 1024;  // padded (32 x 32 per pair) partial elements, 64 per workgroup
   hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dw, slabs,
-                     Cin, Cout, COB32, npairs, (i64)27, (i64)Cin * 27);
+                     Cin, Cout, COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_wgrad(reduce)");
   return SEG3D_OK;
 }

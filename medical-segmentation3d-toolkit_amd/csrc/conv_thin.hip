@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
 // combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void k3_thin_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                      int slabs, int CT, int CF, int CFB, int RB, i64 s_ct,
-                                                                     i64 s_cf, int flip) {
+                                                                     i64 s_cf, int flip, int accumulate) {
   __shared__ float red[256];
   const i64 total = (i64)27 * CT * CF;
   const i64 idx = (i64)blockIdx.x * 16 + (threadIdx.x & 15);
@@ -551,7 +551,8 @@ __global__ __launch_bounds__(256) void k3_thin_wgrad_reduce_kernel(const float* 
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) v += red[k * 16 + threadIdx.x];
-    dw[ct * s_ct + cf * s_cf + (flip ? 26 - t : t)] = v;
+    float* d = dw + ct * s_ct + cf * s_cf + (flip ? 26 - t : t);
+    *d = accumulate ? *d + v : v;
   }
 }
 
@@ -578,7 +579,8 @@ static void launch_thin_wgrad(const float* thin, const float* fat, float* part, 
 // stem wgrad: thin = x, fat = dy, s_ct = 27, s_cf = Cin*27, flip = 0;  head wgrad: thin = dy, fat = x,
 // s_ct = Cin*27, s_cf = 27, flip = 1.
 extern "C" int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* dw, float* workspace, int N, int D, int H,
-                                   int W, int CT, int CF, long long s_ct, long long s_cf, int flip, void* stream) {
+                                   int W, int CT, int CF, long long s_ct, long long s_cf, int flip, int accumulate,
+                                   void* stream) {
   SEG3D_REQUIRE(thin && fat && dw && workspace, "seg3d_k3_thin_wgrad: null pointer");
   SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "seg3d_k3_thin_wgrad: bad dims");
   SEG3D_REQUIRE(CT >= 1 && CT <= 8 && CF > 0 && (CF % 4) == 0, "seg3d_k3_thin_wgrad: need 1 <= CT <= 8 and CF %% 4 == 0");
@@ -598,7 +600,7 @@ extern "C" int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* d
   SEG3D_LAUNCH_CHECK("seg3d_k3_thin_wgrad");
   const i64 total = (i64)27 * CT * CF;
   hipLaunchKernelGGL(k3_thin_wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, workspace, dw, slabs, CT, CF,
-                     CFB, RB, (i64)s_ct, (i64)s_cf, flip);
+                     CFB, RB, (i64)s_ct, (i64)s_cf, flip, accumulate);
   SEG3D_LAUNCH_CHECK("seg3d_k3_thin_wgrad(reduce)");
   return SEG3D_OK;
 }

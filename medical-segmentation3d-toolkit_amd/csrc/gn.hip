@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_param_kernel(const float*
                                                                       const float* __restrict__ mean_rstd,
                                                                       const float* __restrict__ gamma,
                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                      float* __restrict__ dbias, int N, int C, double S) {
+                                                                      float* __restrict__ dbias, int N, int C, double S,
+                                                                      int acc_mask) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double dg = 0.0, db = 0.0, dc = 0.0;
@@ -380,14 +381,15 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_param_kernel(const float*
     db += A;
     dc += (double)mean_rstd[2 * n + 1] * ((double)gamma[c] * A - S * (double)s12[2 * n] - (double)s12[2 * n + 1] * X);
   }
-  dgamma[c] = (float)dg;
-  dbeta[c] = (float)db;
-  if (dbias) dbias[c] = (float)dc;
+  dgamma[c] = (acc_mask & 1) ? dgamma[c] + (float)dg : (float)dg;
+  dbeta[c] = (acc_mask & 2) ? dbeta[c] + (float)db : (float)db;
+  if (dbias) dbias[c] = (acc_mask & 4) ? dbias[c] + (float)dc : (float)dc;
 }
 
 // abx: [N][C][3] scratch, s12: [N][2]
 extern "C" int seg3d_gn_bwd_finalize(const float* part, const float* gamma, const float* mean_rstd, float* abx, float* s12,
-                                     float* dgamma, float* dbeta, float* dbias, int N, long long S, int C, void* stream) {
+                                     float* dgamma, float* dbeta, float* dbias, int N, long long S, int C, int acc_mask,
+                                     void* stream) {
   SEG3D_REQUIRE(part && gamma && mean_rstd && abx && s12 && dgamma && dbeta && N > 0 && S > 0 && C > 0,
                 "seg3d_gn_bwd_finalize: bad arguments");
   const int nblk = (int)seg3d_gn_bwd_blocks(S);
@@ -396,7 +398,7 @@ extern "C" int seg3d_gn_bwd_finalize(const float* part, const float* gamma, cons
                      (double)S * (double)C);
   SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_finalize(sample)");
   hipLaunchKernelGGL(gn_bwd_finalize_param_kernel, dim3(seg3d_cdiv(C, 256)), dim3(256), 0, s, abx, s12, mean_rstd, gamma,
-                     dgamma, dbeta, dbias, N, C, (double)S);
+                     dgamma, dbeta, dbias, N, C, (double)S, acc_mask);
   SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_finalize(param)");
   return SEG3D_OK;
 }

@@ -31,19 +31,19 @@ _SIGNATURES = {
     'seg3d_convT3d_k2s2_fwd_direct': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 6 + [_c_p]),
     'seg3d_wgrad_direct_workspace_floats': (_c_ll, [_c_int] * 7),
     'seg3d_wgrad_direct': (_c_int, [_c_p, _c_p, _c_p] + [_c_int] * 8 + [ctypes.POINTER(_c_int), _c_p]),
-    'seg3d_wgrad_reduce': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_p]),
+    'seg3d_wgrad_reduce': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p]),
     'seg3d_conv3d_k3_mfma_stats_count': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_fwd_workspace_floats': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_variant': (_c_int, [_c_int] * 5),
     'seg3d_conv3d_k3_mfma_fwd': (_c_int, [_c_p] * 7 + [_c_int] * 6 + [_c_p]),
     'seg3d_conv3d_k3_mfma_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
-    'seg3d_conv3d_k3_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_p]),
+    'seg3d_conv3d_k3_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 7 + [_c_p]),
     'seg3d_conv3d_k2s2_mfma_stats_count': (_c_ll, [_c_int] * 4),
     'seg3d_conv3d_k2s2_mfma_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
     'seg3d_convT3d_k2s2_mfma_stats_count': (_c_ll, [_c_int] * 4),
     'seg3d_convT3d_k2s2_mfma_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
     'seg3d_k2_mfma_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
-    'seg3d_k2_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_ll, _c_ll, _c_p]),
+    'seg3d_k2_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_ll, _c_ll, _c_int, _c_p]),
     'seg3d_packed_thin_in_floats': (_c_ll, [_c_int, _c_int]),
     'seg3d_pack_weights_thin_in': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p]),
     'seg3d_conv3d_k3_thin_stats_count': (_c_ll, [_c_int] * 4),
@@ -52,14 +52,14 @@ _SIGNATURES = {
     'seg3d_conv3d_k3_thin_out_stats_count': (_c_ll, [_c_int] * 3),
     'seg3d_conv3d_k3_thin_out_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 7 + [_c_p]),
     'seg3d_k3_thin_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
-    'seg3d_k3_thin_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_ll, _c_ll, _c_int, _c_p]),
+    'seg3d_k3_thin_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_ll, _c_ll, _c_int, _c_int, _c_p]),
     'seg3d_gn_stats_count': (_c_ll, [_c_ll]),
     'seg3d_gn_stats_partial': (_c_int, [_c_p, _c_p, _c_int, _c_ll, _c_p]),
     'seg3d_gn_stats_finalize': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
     'seg3d_gn_apply': (_c_int, [_c_p] * 6 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
     'seg3d_gn_bwd_blocks': (_c_ll, [_c_ll]),
     'seg3d_gn_bwd_reduce': (_c_int, [_c_p] * 7 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
-    'seg3d_gn_bwd_finalize': (_c_int, [_c_p] * 8 + [_c_int, _c_ll, _c_int, _c_p]),
+    'seg3d_gn_bwd_finalize': (_c_int, [_c_p] * 8 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
     'seg3d_gn_bwd_apply': (_c_int, [_c_p] * 9 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
     'seg3d_softmax_fwd': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
     'seg3d_softmax_bwd': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),

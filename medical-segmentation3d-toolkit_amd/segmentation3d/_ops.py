@@ -13,6 +13,7 @@ import ctypes
 import torch
 
 from . import _engine as E
+from . import _grad_sink as G
 
 GN_EPS = 1e-5  # nn.GroupNorm default (network/module/conv_gn_relu3.py:11)
 
@@ -151,22 +152,23 @@ def _k2_scatter(xn, w, bias, y, A, B, sa, sb, want_stats):
     return y, stats
 
 
-def _k2_wgrad(P, Q, CA, CB, out_shape, sa, sb):
-    """dW(t,a,b) = sum_v P[2v + t][a] Q[v][b] on the matrix cores, written to dw[a*sa + b*sb + t]"""
+def _k2_wgrad(P, Q, CA, CB, out_shape, sa, sb, out=None):
+    """dW(t,a,b) = sum_v P[2v + t][a] Q[v][b] on the matrix cores, written to dw[a*sa + b*sb + t] (added when `out`)"""
     N, Dq, Hq, Wq, _ = Q.shape
     ws = _empty((E.query('seg3d_k2_mfma_wgrad_workspace_floats', N, Dq, Hq, Wq, CA, CB),), P)
-    dw = _empty(out_shape, P)
-    E.call('seg3d_k2_mfma_wgrad', E.ptr(P), E.ptr(Q), E.ptr(dw), E.ptr(ws), N, Dq, Hq, Wq, CA, CB, sa, sb, E.stream_ptr())
+    dw = _empty(out_shape, P) if out is None else out
+    E.call('seg3d_k2_mfma_wgrad', E.ptr(P), E.ptr(Q), E.ptr(dw), E.ptr(ws), N, Dq, Hq, Wq, CA, CB, sa, sb,
+           int(out is not None), E.stream_ptr())
     return dw
 
 
-def _thin_wgrad(thin, fat, CT, CF, out_shape, s_ct, s_cf, flip):
+def _thin_wgrad(thin, fat, CT, CF, out_shape, s_ct, s_cf, flip, out=None):
     """dw[ct*s_ct + cf*s_cf + tap] = sum_u fat[u][cf] thin[u + off(tap)][ct] (taps reversed when flip) on the matrix cores"""
     N, D, H, W_, _ = thin.shape
     ws = _empty((E.query('seg3d_k3_thin_wgrad_workspace_floats', N, D, H, W_, CT, CF),), thin)
-    dw = _empty(out_shape, thin)
+    dw = _empty(out_shape, thin) if out is None else out
     E.call('seg3d_k3_thin_wgrad', E.ptr(thin), E.ptr(fat), E.ptr(dw), E.ptr(ws), N, D, H, W_, CT, CF, s_ct, s_cf, flip,
-           E.stream_ptr())
+           int(out is not None), E.stream_ptr())
     return dw
 
 
@@ -259,7 +261,7 @@ def conv_dgrad(dyn, w, kind, addend=None):
     raise ValueError('unknown conv kind {}'.format(kind))
 
 
-def _wgrad_direct(P, Q, CA, CB, ks, stride, T, out_shape, sa, sb):
+def _wgrad_direct(P, Q, CA, CB, ks, stride, T, out_shape, sa, sb, out=None):
     N, Dp, Hp, Wp, _ = P.shape
     _, Dq, Hq, Wq, _ = Q.shape
     nfl = E.query('seg3d_wgrad_direct_workspace_floats', N, Dq, Hq, Wq, CA, CB, T)
@@ -267,42 +269,46 @@ def _wgrad_direct(P, Q, CA, CB, ks, stride, T, out_shape, sa, sb):
     chunks = ctypes.c_int(0)
     E.call('seg3d_wgrad_direct', E.ptr(P), E.ptr(Q), E.ptr(part), N, Dp, Hp, Wp, CA, CB, ks, stride,
            ctypes.byref(chunks), E.stream_ptr())
-    dw = _empty(out_shape, P)
-    E.call('seg3d_wgrad_reduce', E.ptr(part), E.ptr(dw), chunks.value, T, CA, CB, sa, sb, E.stream_ptr())
+    dw = _empty(out_shape, P) if out is None else out
+    E.call('seg3d_wgrad_reduce', E.ptr(part), E.ptr(dw), chunks.value, T, CA, CB, sa, sb, int(out is not None),
+           E.stream_ptr())
     return dw
 
 
-def conv_wgrad(xn, dyn, w_shape, kind):
-    """gradient w.r.t. the weight, returned in the reference layout `w_shape`"""
+def conv_wgrad(xn, dyn, w_shape, kind, out=None):
+    """gradient w.r.t. the weight in the reference layout `w_shape`: returned as a new tensor, or ADDED into `out`
+    (a contiguous tensor of that shape, e.g. the optimizer's flat-buffer slice) by the reduce kernel itself"""
     N, D, H, W_, Cin_x = xn.shape
+    if out is not None and (tuple(out.shape) != tuple(w_shape) or not out.is_contiguous()):
+        raise ValueError('weight-gradient destination must be contiguous with shape {}'.format(tuple(w_shape)))
     if kind == 'k3':
         Cout, Cin = w_shape[0], w_shape[1]
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             nfl = E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W_, Cin, Cout)
             ws = _empty((nfl,), xn)
-            dw = _empty(w_shape, xn)
+            dw = _empty(w_shape, xn) if out is None else out
             E.call('seg3d_conv3d_k3_mfma_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(dw), E.ptr(ws), N, D, H, W_, Cin, Cout,
-                   E.stream_ptr())
+                   int(out is not None), E.stream_ptr())
             return dw
         if not FORCE_DIRECT and Cin <= 8 and Cout % 4 == 0:      # stem: thin = x, fat = dy
-            return _thin_wgrad(xn, dyn, Cin, Cout, w_shape, 27, Cin * 27, 0)
+            return _thin_wgrad(xn, dyn, Cin, Cout, w_shape, 27, Cin * 27, 0, out)
         if not FORCE_DIRECT and Cout <= 8 and Cin % 4 == 0:      # head: thin = dy, fat = x, taps reversed
-            return _thin_wgrad(dyn, xn, Cout, Cin, w_shape, Cin * 27, 27, 1)
-        return _wgrad_direct(xn, dyn, Cin, Cout, 3, 1, 27, w_shape, 27, Cin * 27)
+            return _thin_wgrad(dyn, xn, Cout, Cin, w_shape, Cin * 27, 27, 1, out)
+        return _wgrad_direct(xn, dyn, Cin, Cout, 3, 1, 27, w_shape, 27, Cin * 27, out)
     if kind == 'k2s2':
         Cout, Cin = w_shape[0], w_shape[1]
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
-            return _k2_wgrad(xn, dyn, Cin, Cout, w_shape, 8, Cin * 8)
-        return _wgrad_direct(xn, dyn, Cin, Cout, 2, 2, 8, w_shape, 8, Cin * 8)
+            return _k2_wgrad(xn, dyn, Cin, Cout, w_shape, 8, Cin * 8, out)
+        return _wgrad_direct(xn, dyn, Cin, Cout, 2, 2, 8, w_shape, 8, Cin * 8, out)
     if kind == 'k1':
         Cout, Cin = w_shape[0], w_shape[1]
-        return _wgrad_direct(xn, dyn, Cin, Cout, 1, 1, 1, w_shape, 1, Cin)
+        return _wgrad_direct(xn, dyn, Cin, Cout, 1, 1, 1, w_shape, 1, Cin, out)
     if kind == 'convT':
         Cin, Cout = w_shape[0], w_shape[1]
         # dW(t, a=co, b=ci) = sum_i dy[2i + t][co] x[i][ci]  -> w[ci][co][t]
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
-            return _k2_wgrad(dyn, xn, Cout, Cin, w_shape, 8, Cout * 8)
-        return _wgrad_direct(dyn, xn, Cout, Cin, 2, 2, 8, w_shape, 8, Cout * 8)
+            return _k2_wgrad(dyn, xn, Cout, Cin, w_shape, 8, Cout * 8, out)
+        return _wgrad_direct(dyn, xn, Cout, Cin, 2, 2, 8, w_shape, 8, Cout * 8, out)
     raise ValueError('unknown conv kind {}'.format(kind))
 
 
@@ -331,9 +337,11 @@ def gn_apply(yn, mean_rstd, gamma, beta, resn, relu):
     return out
 
 
-def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_dbias=True):
+def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_dbias=True, sinks=(None, None, None)):
     """returns (dy, dres or None, dgamma, dbeta, dbias or None).  `outn` (the unit's forward output) is only read when
-    it cannot be recomputed from y, i.e. when a residual was added; pass None otherwise."""
+    it cannot be recomputed from y, i.e. when a residual was added; pass None otherwise.
+    sinks = (dgamma, dbeta, dbias) destinations ([C] tensors) the finalize kernel ADDS into; the matching return
+    value is then None."""
     N, D, H, W_, C = yn.shape
     S = D * H * W_
     nblk = E.query('seg3d_gn_bwd_blocks', S)
@@ -343,21 +351,31 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
            E.ptr(part), N, S, C, int(relu), E.stream_ptr())
     abx = _empty((N, C, 3), yn)
     s12 = _empty((N, 2), yn)
-    dgamma = _empty((C,), yn)
-    dbeta = _empty((C,), yn)
-    dbias = _empty((C,), yn) if want_dbias else None
+    sg, sb_, sc = sinks
+    for t in sinks:
+        if t is not None and (t.numel() != C or not t.is_contiguous()):
+            raise ValueError('GroupNorm gradient destination must be a contiguous [C] tensor')
+    dgamma = _empty((C,), yn) if sg is None else sg
+    dbeta = _empty((C,), yn) if sb_ is None else sb_
+    dbias = (_empty((C,), yn) if sc is None else sc) if want_dbias else None
+    acc_mask = (1 if sg is not None else 0) | (2 if sb_ is not None else 0) | (4 if (want_dbias and sc is not None) else 0)
     E.call('seg3d_gn_bwd_finalize', E.ptr(part), E.ptr(gamma), E.ptr(mean_rstd), E.ptr(abx), E.ptr(s12), E.ptr(dgamma),
-           E.ptr(dbeta), E.ptr(dbias), N, S, C, E.stream_ptr())
+           E.ptr(dbeta), E.ptr(dbias), N, S, C, acc_mask, E.stream_ptr())
     dy = torch.empty_like(yn)
     dres = torch.empty_like(yn) if want_dres else None
     E.call('seg3d_gn_bwd_apply', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(s12), E.ptr(gamma),
            E.ptr(beta), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), E.stream_ptr())
-    return dy, dres, dgamma, dbeta, dbias
+    return (dy, dres, dgamma if sg is None else None, dbeta if sb_ is None else None,
+            dbias if (want_dbias and sc is None) else None)
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # autograd functions
 # ------------------------------------------------------------------------------------------------------------------
+def _views(*sinks):
+    return tuple(None if s is None else s.view for s in sinks)
+
+
 class ResidualLink(object):
     """Side channel between the LAST unit of a residual block (which receives the block input as `residual`) and its
     FIRST unit (whose conv input is that same tensor).  In backward the last unit runs first and parks the gradient of
@@ -394,6 +412,7 @@ class ConvGnActFunction(torch.autograd.Function):
         ctx.w_shape = tuple(weight.shape)
         ctx.res_is_x = residual is not None and residual is x
         ctx.link_in, ctx.link_out = link_in, (link_out if residual is not None else None)
+        ctx.sinks = (G.lookup(weight), G.lookup(bias), G.lookup(gamma), G.lookup(beta))
         # the forward output is kept for backward only when a residual was added (otherwise the ReLU mask is
         # recomputed from y, saving one full-tensor read in each of the two GroupNorm backward passes)
         ctx.save_for_backward(xn, w, gamma.detach(), beta.detach(), yn, outn if residual is not None else None, mean_rstd)
@@ -403,9 +422,10 @@ class ConvGnActFunction(torch.autograd.Function):
     def backward(ctx, dout):
         xn, w, gamma, beta, yn, outn, mean_rstd = ctx.saved_tensors
         dn = to_ndhwc(dout)
+        sw, sb_, sg, sbt = ctx.sinks
         dy, dres, dgamma, dbeta, dbias = gn_backward(dn, outn, yn, mean_rstd, gamma, beta, ctx.relu,
                                                      want_dres=ctx.has_res and ctx.needs_input_grad[5],
-                                                     want_dbias=ctx.has_bias)
+                                                     want_dbias=ctx.has_bias, sinks=_views(sg, sbt, sb_))
         dx = None
         addend = None
         if ctx.res_is_x and dres is not None and ctx.needs_input_grad[0]:
@@ -418,7 +438,11 @@ class ConvGnActFunction(torch.autograd.Function):
             addend, ctx.link_in.grad = ctx.link_in.grad, None
         if ctx.needs_input_grad[0]:
             dx = from_ndhwc(conv_dgrad(dy, w, ctx.kind, addend=addend))
-        dw = conv_wgrad(xn, dy, ctx.w_shape, ctx.kind) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(xn, dy, ctx.w_shape, ctx.kind, out=None if sw is None else sw.view)
+            if sw is not None:
+                dw = None
         return (dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta,
                 from_ndhwc(dres) if dres is not None else None, None, None, None, None, None)
 
@@ -438,6 +462,7 @@ class ConvFunction(torch.autograd.Function):
         w = weight.detach()
         yn, _ = conv_forward(xn, w, None if bias is None else bias.detach(), kind)
         ctx.kind, ctx.has_bias, ctx.w_shape = kind, bias is not None, tuple(weight.shape)
+        ctx.sinks = (G.lookup(weight), G.lookup(bias))
         ctx.save_for_backward(xn, w)
         return from_ndhwc(yn)
 
@@ -446,10 +471,18 @@ class ConvFunction(torch.autograd.Function):
         xn, w = ctx.saved_tensors
         dn = to_ndhwc(dout)
         dx = from_ndhwc(conv_dgrad(dn, w, ctx.kind)) if ctx.needs_input_grad[0] else None
-        dw = conv_wgrad(xn, dn, ctx.w_shape, ctx.kind) if ctx.needs_input_grad[1] else None
+        sw, sb_ = ctx.sinks
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(xn, dn, ctx.w_shape, ctx.kind, out=None if sw is None else sw.view)
+            if sw is not None:
+                dw = None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dn.reshape(-1, dn.shape[-1]).sum(0)  # plumbing-only path (bias of a bare conv); fused path uses gn_bwd
+            if sb_ is not None:
+                sb_.view.add_(db.view_as(sb_.view))
+                db = None
         return dx, dw, db, None
 
 
@@ -467,6 +500,7 @@ class GroupNormFunction(torch.autograd.Function):
         mean_rstd = gn_stats(yn, None, eps)
         outn = gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), None, relu)
         ctx.relu = bool(relu)
+        ctx.sinks = (G.lookup(gamma), G.lookup(beta))
         ctx.save_for_backward(yn, mean_rstd, gamma.detach(), beta.detach())
         return from_ndhwc(outn)
 
@@ -474,8 +508,9 @@ class GroupNormFunction(torch.autograd.Function):
     def backward(ctx, dout):
         yn, mean_rstd, gamma, beta = ctx.saved_tensors
         dn = to_ndhwc(dout)
+        sg, sbt = ctx.sinks
         dy, _, dgamma, dbeta, _ = gn_backward(dn, None, yn, mean_rstd, gamma, beta, ctx.relu, want_dres=False,
-                                              want_dbias=False)
+                                              want_dbias=False, sinks=_views(sg, sbt, None))
         return from_ndhwc(dy), dgamma, dbeta, None, None
 
 

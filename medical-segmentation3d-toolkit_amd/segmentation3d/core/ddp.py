@@ -76,10 +76,15 @@ class GradientReducer(object):
                     hi, acc, members = off, 0, []
             if members:
                 self._add_bucket(bi, 0, hi, members)
+        # autograd runs a leaf's AccumulateGrad node (and this hook) once all of its uses have been processed, also
+        # when the producing function returned None because its kernel wrote the gradient straight into the flat
+        # buffer (gradient sinks, _grad_sink.py) -- so the hook is the "gradient ready" signal in both modes.  Should a
+        # hook not fire, finish_step() reduces the bucket after backward (correct, just not overlapped).
         self._handles = []
         for p in self._param_bucket:
             self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
         self._active = False
+        self.launched_in_backward = 0   # buckets whose all-reduce was enqueued from a hook during the last backward
 
     def _buckets_for(self, bi):
         return [b for b in self._buckets if b['buffer'] == bi]
@@ -99,6 +104,7 @@ class GradientReducer(object):
         """call before backward (after zero_grad)"""
         for b in self._buckets:
             b['pending'], b['work'] = b['nparams'], None
+        self.launched_in_backward = 0
         self._active = True
 
     def _launch(self, b):
@@ -112,6 +118,7 @@ class GradientReducer(object):
         b['pending'] -= 1
         if b['pending'] == 0 and b['work'] is None:
             self._launch(b)
+            self.launched_in_backward += 1
 
     def finish_step(self):
         """call after backward: reduces buckets whose hooks did not all fire, then waits (stream-ordered on GPUs).

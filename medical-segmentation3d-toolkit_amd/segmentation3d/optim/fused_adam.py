@@ -4,24 +4,28 @@ no weight decay, no amsgrad) executed as ONE HIP kernel over a flat parameter bu
 MI355X-first layout: all parameters of a group live in one contiguous fp32 buffer (likewise gradients, exp_avg,
 exp_avg_sq); `p.data` / `p.grad` are views into it.  One launch updates 14.56 M parameters (28 B/param of HBM traffic)
 and the data-parallel gradient all-reduce works on contiguous slices of the same buffer (core/ddp.py).
+With `direct_grads` (default) every parameter's slice of the gradient buffer is registered as a gradient sink
+(`_grad_sink.py`): the backward kernels accumulate into it themselves instead of autograd adding a temporary.
 `state_dict()` / `load_state_dict()` keep torch.optim.Adam's structure (`step`, `exp_avg`, `exp_avg_sq` per
 parameter), so `optimizer.pth` files are interchangeable with the reference's.
 """
 import torch
 
 from segmentation3d import _engine as E
+from segmentation3d import _grad_sink as G
 
 _ALIGN = 64  # floats; keeps every parameter view 256-byte aligned (kernels read gamma/beta/weights with 16-byte loads)
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, direct_grads=True):
         if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError('invalid Adam hyper-parameters')
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         super(FusedAdam, self).__init__(params, defaults)
         self._flat = []  # per group: dict(params, grads, exp_avg, exp_avg_sq, offsets, step)
         self.grad_scale = 1.0  # set to 1/world_size by the data-parallel wrapper after a sum all-reduce
+        self.direct_grads = bool(direct_grads)
         for group in self.param_groups:
             self._flat.append(self._flatten_group(group))
 
@@ -50,6 +54,8 @@ class FusedAdam(torch.optim.Optimizer):
             if p.grad is not None:
                 flat_g[off:off + n].copy_(p.grad.reshape(-1))
             p.grad = flat_g[off:off + n].view(p.shape)
+            if self.direct_grads:
+                G.register(p, p.grad)
             self.state[p] = {'step': torch.tensor(0.0), 'exp_avg': flat_m[off:off + n].view(p.shape),
                              'exp_avg_sq': flat_v[off:off + n].view(p.shape)}
         return {'list': ps, 'offsets': offsets, 'params': flat_p, 'grads': flat_g, 'exp_avg': flat_m,
@@ -80,16 +86,23 @@ class FusedAdam(torch.optim.Optimizer):
                 n = p.numel()
                 if p.grad is None or p.grad.data_ptr() != f['grads'].data_ptr() + 4 * off:
                     p.grad = f['grads'][off:off + n].view(p.shape)
+                    if self.direct_grads:
+                        G.register(p, p.grad)
 
     def _gather_stray_grads(self, f):
         for p, off in zip(f['list'], f['offsets']):
             n = p.numel()
             view = f['grads'][off:off + n]
             if p.grad is None:
-                view.zero_()
+                if not self.direct_grads:
+                    view.zero_()          # with sinks the kernels wrote here even though autograd never set .grad
                 p.grad = view.view(p.shape)
             elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad.reshape(-1))
+                # a stray tensor (someone assigned p.grad): what autograd put there joins what the sinks wrote
+                if self.direct_grads:
+                    view.add_(p.grad.reshape(-1))
+                else:
+                    view.copy_(p.grad.reshape(-1))
                 p.grad = view.view(p.shape)
             if p.data.data_ptr() != f['params'].data_ptr() + 4 * off:
                 # someone re-assigned p.data (e.g. load_state_dict keeps storage, .to() does not): re-adopt it
@@ -114,6 +127,13 @@ class FusedAdam(torch.optim.Optimizer):
             for p in f['list']:
                 self.state[p]['step'] = torch.tensor(float(f['step']))
         return loss
+
+    def release_grad_sinks(self):
+        """stop routing gradients into the flat buffer (e.g. before using torch.autograd.grad on these parameters)"""
+        self.direct_grads = False
+        for f in self._flat:
+            if f is not None:
+                G.unregister(f['list'])
 
     def load_state_dict(self, state_dict):
         super(FusedAdam, self).load_state_dict(state_dict)

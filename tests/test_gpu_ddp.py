@@ -41,7 +41,8 @@ def _worker(rank, world, port, out):
     torch.cuda.synchronize()
     flat = step.opt._flat[0]
     torch.save({'grads': flat['grads'].cpu(), 'params': flat['params'].cpu(), 'loss': float(loss),
-                'buckets': step.reducer.bucket_sizes()}, out.format(rank))
+                'buckets': step.reducer.bucket_sizes(), 'overlapped': step.reducer.launched_in_backward},
+               out.format(rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,6 +55,9 @@ def test_two_rank_train_step_matches_global_batch(hip_device, tmp_path):
     assert torch.equal(r0['params'], r1['params'])          # broadcast at start + identical reduced gradients
     assert torch.equal(r0['grads'], r1['grads'])
     assert len(r0['buckets']) == 4
+    # every bucket's all-reduce was enqueued from a gradient-ready hook DURING backward (the kernels write the
+    # gradients straight into the flat buffer; autograd still fires the leaf hooks)
+    assert r0['overlapped'] == 4 and r1['overlapped'] == 4
     from segmentation3d.core.seg_train import TrainStep
     ref = TrainStep('vnet', 1, 2, 'Dice', [0.5, 0.5], device=hip_device, seed=0, distributed=False)
     x, t = _data()

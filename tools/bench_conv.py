@@ -23,7 +23,7 @@ def run(kind, N, D, H, W, Cin, Cout, iters=10):
     else:
         ws = torch.empty(E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W, Cin, Cout), device=dev)
         dw = torch.empty(Cout, Cin, 3, 3, 3, device=dev)
-        fn = lambda: E.call('seg3d_conv3d_k3_mfma_wgrad', E.ptr(x), E.ptr(dy), E.ptr(dw), E.ptr(ws), N, D, H, W, Cin, Cout, E.stream_ptr())
+        fn = lambda: E.call('seg3d_conv3d_k3_mfma_wgrad', E.ptr(x), E.ptr(dy), E.ptr(dw), E.ptr(ws), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

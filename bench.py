@@ -87,7 +87,7 @@ class KernelTimer(object):
             a.record()
             rc = timer._orig(name, *args)
             b.record()
-            ma = E.query('seg3d_conv3d_k3_mfma_variant', N, D, H, W, Cout)
+            ma = E.query('seg3d_conv3d_k3_mfma_variant', N, D, H, W, Cin, Cout)
             timer.records.append(((N, D, H, W, Cin, Cout, ma), a, b))
             return rc
         E.call = call
@@ -108,6 +108,13 @@ class KernelTimer(object):
             e['ms'] += ms
             e['flops'] += flops
         return table
+
+
+def variant_kernel_name(v):
+    """seg3d_conv3d_k3_mfma_variant code -> kernel symbol as rocprofv3 prints it"""
+    if v >= 100:
+        return 'conv3d_k3_mfma2_kernel<{}, {}>'.format((v - 100) // 10, v % 10)
+    return 'conv3d_k3_mfma_kernel<{}>'.format(v)
 
 
 def pmc_traffic_gb(kernel_name):
@@ -245,10 +252,11 @@ def main():
             for k in v:
                 v[k] += e[k]
         dom = max(by_variant, key=lambda m: by_variant[m]['ms'])
-        traffic = pmc_traffic_gb('void conv3d_k3_mfma_kernel<{}>'.format(dom))
+        kname = variant_kernel_name(dom)
+        traffic = pmc_traffic_gb('void ' + kname)
         d = by_variant[dom]
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
-        roofline = {'kernel': 'conv3d_k3_mfma_kernel<{}>'.format(dom), 'bound': 'mfma', 'achieved': round(achieved, 2),
+        roofline = {'kernel': kname, 'bound': 'mfma', 'achieved': round(achieved, 2),
                     'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     'traffic': traffic, 'traffic_unit': 'GB per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, see profiles/)',
                     'launches_per_step': d['launches'] // 2,

@@ -66,7 +66,8 @@ int seg3d_wgrad_reduce(const float* part, float* dw, int chunks, int T, int A, i
 /* fp32 MFMA implicit-GEMM path for k3 s1 p1 with Cin % 4 == 0 (the FLOP-dominant C->C layers) */
 long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W, int Cin, int Cout);
 long long seg3d_conv3d_k3_mfma_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
-int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cout);
+/* kernel instantiation a shape runs: MA (1..4) = conv3d_k3_mfma_kernel<MA>; 100 + 10*MA + NB = conv3d_k3_mfma2_kernel<MA, NB> */
+int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp_mfma, const float* bias,
                              const float* addend /* optional, shape of y: y = conv + bias + addend */, float* y,
                              float* stats_partial, float* workspace /* split-K partials; NULL when the query returns 0 */,

@@ -26,6 +26,7 @@
 #include "seg3d_common.h"
 #include "seg3d_hip.h"
 #include <math.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -120,13 +121,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
   auto load_chunk = [&](int cib) {
     // branch-free: out-of-range lanes read a valid dummy address and are zeroed by a select, so the compiler keeps
     // all loads in flight instead of waiting inside exec-masked branches
+    // (the select itself happens in store_chunk: consuming a loaded value here would make the compiler wait for
+    // each load before issuing the next)
     const bool half_ok = cib * 8 + hh * 4 < Cin;
 #pragma unroll
     for (int e = 0; e < SEG3D_MAXE; ++e) {
       const bool ok = goff[e] >= 0 && half_ok;
-      const f32x4 val = *reinterpret_cast<const f32x4*>(x + (ok ? (i64)goff[e] + cib * 8 : (i64)0));
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      xstage[e] = ok ? val : zero;
+      xstage[e] = *reinterpret_cast<const f32x4*>(x + (ok ? (i64)goff[e] + cib * 8 : (i64)0));
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * SEG3D_W_CHUNK);
 #pragma unroll
@@ -135,11 +136,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
       wstage[k] = wsrc[idx < SEG3D_W_CHUNK / 4 ? idx : 0];
     }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int cib) {
+    const bool half_ok = cib * 8 + hh * 4 < Cin;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < SEG3D_MAXE; ++e) {
       const int eidx = tid + e * 256;
-      if (eidx < 2 * NV) *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) = xstage[e];
+      const bool ok = goff[e] >= 0 && half_ok;
+      if (eidx < 2 * NV) *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) = ok ? xstage[e] : zero;
     }
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
   const int cib0 = kpart ? blockIdx.z * cpk : 0;
   const int cib1 = kpart ? (cib0 + cpk < CIB ? cib0 + cpk : CIB) : CIB;
   load_chunk(cib0);
-  store_chunk();
+  store_chunk(cib0);
   __syncthreads();
   for (int cib = cib0; cib < cib1; ++cib) {
     if (cib + 1 < cib1) load_chunk(cib + 1);
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
     }
     if (cib + 1 < cib1) {
       __syncthreads();  // every wave is done reading chunk c
-      store_chunk();
+      store_chunk(cib + 1);
       __syncthreads();  // chunk c+1 visible
     }
   }
@@ -245,6 +249,345 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma_kernel(
       dst[0] = s[0];
       dst[1] = s[1];
     }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Forward / dgrad, second generation (conv3d_k3_mfma2_kernel): ONE persistent workgroup per CU, one wave per SIMD.
+//   Measured on MI355X (tools/ubench/mfma_shape.hip): an LDS-fed 32x32x2 loop sustains 154 TFLOP/s, so the matrix
+//   pipe is only kept waiting by what surrounds the loop; in-kernel stamps (tools/ubench/conv_stamp.hip) priced that
+//   at ~30 % of a short-K workgroup (prologue DMA burst, index math, dword store tail).  Here:
+//   * the next K-chunk (input halo tile + NB weight blocks) is brought in by LDS-DMA (global_load_lds_dwordx4: no
+//     staging registers, no ds_write pass) into the second of two LDS buffers while the MFMAs of the current chunk
+//     run, one 1-KiB piece per tap; halo voxels outside the volume read a 16-byte zero source instead;
+//   * one barrier per chunk (after the wave's own DMA count has drained) publishes the new buffer and frees the old;
+//   * the workgroup is persistent and walks work items (tile, column group) with a stride of gridDim.x: the LAST
+//     chunk of an item already fetches chunk 0 of the next item, so no item but the first pays a DMA prologue, and
+//     the epilogue's stores drain behind the next item's MFMAs;
+//   * the MFMA operands are swapped (A = weights, B = voxels): a lane then owns ONE voxel and 4 x 4 consecutive
+//     output channels of each accumulator, so the epilogue is 4 dwordx4 stores per accumulator instead of 16 dword
+//     stores and needs no LDS voxel table; bias / fused addend are float4 loads;
+//   * GroupNorm partial sums are written per wave (no workgroup reduction, no barrier);
+//   * a workgroup owns MA x 4 row blocks (voxels) x NB column blocks (32 output channels each): the input tile is
+//     staged once for NB*32 channels instead of once per 32.
+// LDS: 2 x { xs [2][NV][4] padded to 1 KiB, ws [NB][27][2][32][4] }  (<= 160 KB).  Needs Cin % 8 == 0, Cout % 4 == 0.
+// ----------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float seg3d_zero16[4];  // DMA source for zero padding
+
+#define SEG3D_V2_MAXPX 10  // input-tile DMA pieces per wave per chunk (40 pieces = 2560 float4 = 2 halves x 1280 voxels)
+
+// Diagnostic build only (tools/ubench/conv_stamp.hip defines SEG3D_STAMPS): wave 0 records s_memtime at phase
+// boundaries into a buffer nothing else reads.  The product library is built without it (no stamp executes).
+#ifdef SEG3D_STAMPS
+__device__ long long* seg3d_stamp_buf;
+#define SEG3D_STAMP(slot, k)                                                                                  \
+  do {                                                                                                        \
+    if (threadIdx.x == 0) seg3d_stamp_buf[(size_t)(slot) * 16 + (k)] = __builtin_amdgcn_s_memtime();           \
+  } while (0)
+#else
+#define SEG3D_STAMP(slot, k) do { } while (0)
+#endif
+
+__device__ __forceinline__ void seg3d_glds16(const float* src, float* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds(src, lds_dst_wave_uniform, 16, 0, 0);
+}
+
+template <int MA, int NB>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ stats, int N, int D, int H, int W, int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
+    int ntx, int ncog, int nitems, const float* __restrict__ addend) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HY = TY + 2, HX = TX + 2;
+  const int NV = (TZ + 2) * HY * HX;
+  const int MT = TZ * TY * TX;
+  const int XS = (8 * NV + 255) & ~255;  // floats; whole 1-KiB DMA pieces
+  const int BUF = XS + NB * SEG3D_W_CHUNK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int CIB = Cin >> 3;
+  const int G = gridDim.x;
+
+  // Index math without integer division: for 0 <= v < 2^20 and d <= 2^10, v / d == (int)((v + 0.5f) * (1.0f / d))
+  // exactly (v + 0.5 is at least 0.5/d away from a multiple of d; the float error stays below that).  With one wave
+  // per SIMD nothing hides such instructions, and a 32-bit division is ~35 of them.
+  const float rHX = 1.0f / (float)HX, rHY = 1.0f / (float)HY, rTX = 1.0f / (float)TX, rTY = 1.0f / (float)TY;
+  const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz, rNCOG = 1.0f / (float)ncog;
+  auto fdiv = [](int v, float r) { return (int)(((float)v + 0.5f) * r); };
+
+  // ---- per-lane constants that do not depend on the work item ----
+  // input-tile DMA pieces of this wave: piece p = wave + 4 j covers float4 entries e = 64 p + lane of [2][NV];
+  // hpos[j] = halo coordinates (hz << 20 | hy << 10 | hx), bit 30 = upper channel half, -1 = padding entry
+  const int NPX = XS >> 8;
+  const int nx = NPX > wave ? (NPX - wave + 3) >> 2 : 0;
+  int hpos[SEG3D_V2_MAXPX];
+#pragma unroll
+  for (int j = 0; j < SEG3D_V2_MAXPX; ++j) {
+    const int e = (wave + 4 * j) * 64 + lane;
+    hpos[j] = -1;
+    if (e < 2 * NV) {
+      const int hh = e >= NV;
+      const int v = e - hh * NV;
+      const int t = fdiv(v, rHX);
+      const int hx = v - t * HX;
+      const int hz = fdiv(t, rHY);
+      const int hy = t - hz * HY;
+      hpos[j] = (hh << 30) | (hz << 20) | (hy << 10) | hx;
+    }
+  }
+  // this lane's MA voxels (one per accumulator row block): LDS base of the A rows and tile-local coordinates
+  int abase[MA], vpos[MA];
+#pragma unroll
+  for (int m = 0; m < MA; ++m) {
+    const int idx = (wave + 4 * m) * 32 + li;
+    int vb = 0;
+    vpos[m] = -1;
+    if (idx < MT) {
+      const int t = fdiv(idx, rTX);
+      const int tx = idx - t * TX;
+      const int tz = fdiv(t, rTY);
+      const int ty = t - tz * TY;
+      vb = (tz * HY + ty) * HX + tx;
+      vpos[m] = (tz << 20) | (ty << 10) | tx;
+    }
+    abase[m] = (lh * NV + vb) * 4;
+  }
+  const int bbase = (lh * 32 + li) * 4;
+
+  // ---- work item state ----
+  int it_n = 0, it_z0 = 0, it_y0 = 0, it_x0 = 0, it_cog = 0, it_tile = 0;  // item whose DMA sources are set up
+  const float* xsrc[SEG3D_V2_MAXPX];
+  int xadv = 0;  // bit j: piece j advances by 8 channels per chunk (0 for zero-padding sources)
+  auto setup_item = [&](int item) {
+    const int tile_all = fdiv(item, rNCOG);
+    it_cog = item - tile_all * ncog;
+    int b = tile_all;
+    int q = fdiv(b, rNTX);
+    const int tix = b - q * ntx;
+    b = q;
+    q = fdiv(b, rNTY);
+    const int tiy = b - q * nty;
+    b = q;
+    q = fdiv(b, rNTZ);
+    const int tiz = b - q * ntz;
+    it_n = q;
+    it_tile = (tiz * nty + tiy) * ntx + tix;
+    it_z0 = tiz * TZ, it_y0 = tiy * TY, it_x0 = tix * TX;
+    xadv = 0;
+#pragma unroll
+    for (int j = 0; j < SEG3D_V2_MAXPX; ++j) {
+      xsrc[j] = seg3d_zero16;
+      const int hp = hpos[j];
+      const int gz = it_z0 + ((hp >> 20) & 1023) - 1, gy = it_y0 + ((hp >> 10) & 1023) - 1, gx = it_x0 + (hp & 1023) - 1;
+      if (hp >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        xsrc[j] = x + ((i64)(((it_n * D + gz) * H + gy) * W + gx) * Cin + ((hp >> 30) & 1) * 4);
+        xadv |= 1 << j;
+      }
+    }
+  };
+  auto dma_x = [&](int j, float* buf) {  // j compile-time after unrolling; issues the piece, then steps to the next chunk
+    seg3d_glds16(xsrc[j], buf + (wave + 4 * j) * 256);
+    xsrc[j] += ((xadv >> j) & 1) * 8;
+  };
+  constexpr int NPW = 27 * NB;  // weight pieces (1 KiB = one tap of one column block)
+  constexpr int MAXPW = (NPW + 3) / 4;
+  auto dma_w = [&](int j, const float* wchunk, float* buf) {  // wchunk: packed weights of (first column block, chunk)
+    const int piece = wave + 4 * j;
+    if (piece < NPW) {
+      const int nb = piece / 27, tap = piece - nb * 27;
+      seg3d_glds16(wchunk + (i64)nb * CIB * SEG3D_W_CHUNK + tap * 256 + lane * 4, buf + XS + piece * 256);
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  setup_item(item);
+  SEG3D_STAMP(blockIdx.x, 0);
+  {  // the only exposed DMA prologue of this workgroup: chunk 0 of its first item into buffer 0
+    const float* w0 = wp + (i64)(it_cog * NB) * CIB * SEG3D_W_CHUNK;
+#pragma unroll
+    for (int j = 0; j < SEG3D_V2_MAXPX; ++j)
+      if (j < nx) dma_x(j, lds);
+#pragma unroll
+    for (int j = 0; j < MAXPW; ++j) dma_w(j, w0, lds);
+  }
+  __syncthreads();  // drains this wave's DMA count (vmcnt) and publishes buffer 0
+  SEG3D_STAMP(blockIdx.x, 1);
+
+  int parity = 0;
+  for (;;) {
+    // the item being multiplied (its identity is needed again in the epilogue, after setup_item moved on)
+    const int cur_n = it_n, cur_z0 = it_z0, cur_y0 = it_y0, cur_x0 = it_x0, cur_cog = it_cog, cur_tile = it_tile;
+    const int next_item = item + G;
+    const bool more_items = next_item < nitems;
+
+    f32x16 acc[MA][NB];
+#pragma unroll
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+    // this lane's 16 bias values per column block, fetched now (no DMA is in flight here) and used in the epilogue
+    f32x4 bv[NB][4];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int co = (cur_cog * NB + q) * 32 + 4 * lh + 8 * g4;
+        const f32x4 val = *reinterpret_cast<const f32x4*>((bias && co < Cout) ? bias + co : seg3d_zero16);
+        bv[q][g4] = val;
+      }
+
+    for (int cib = 0; cib < CIB; ++cib) {
+      float* cur = lds + parity * BUF;
+      float* nxt = lds + (parity ^ 1) * BUF;
+      const bool last = cib + 1 == CIB;
+      const bool do_dma = !last || more_items;
+      const float* wnext;
+      if (last) {
+        if (more_items) setup_item(next_item);  // DMA sources now belong to the next item
+        wnext = wp + (i64)(it_cog * NB) * CIB * SEG3D_W_CHUNK;
+      } else {
+        wnext = wp + ((i64)(cur_cog * NB) * CIB + cib + 1) * SEG3D_W_CHUNK;
+      }
+      const float* xs = cur;
+      const float* ws = cur + XS;
+      f32x4 bw[NB], av[MA];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) bw[q] = *reinterpret_cast<const f32x4*>(ws + q * SEG3D_W_CHUNK + bbase);
+#pragma unroll
+      for (int m = 0; m < MA; ++m) av[m] = *reinterpret_cast<const f32x4*>(xs + abase[m]);
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        f32x4 bwn[NB], avn[MA];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) bwn[q] = bw[q];
+#pragma unroll
+        for (int m = 0; m < MA; ++m) avn[m] = av[m];
+        if (tap + 1 < 27) {  // operands of tap t+1 are read while tap t is multiplied
+          const int t1 = tap + 1;
+          const int kz = t1 / 9, ky = (t1 / 3) % 3, kx = t1 % 3;
+          const int tapoff = ((kz * HY + ky) * HX + kx) * 4;
+#pragma unroll
+          for (int q = 0; q < NB; ++q) bwn[q] = *reinterpret_cast<const f32x4*>(ws + q * SEG3D_W_CHUNK + t1 * 256 + bbase);
+#pragma unroll
+          for (int m = 0; m < MA; ++m) avn[m] = *reinterpret_cast<const f32x4*>(xs + abase[m] + tapoff);
+        }
+        if (do_dma) {  // one DMA piece of the next chunk per tap, behind the MFMAs
+          if (tap < SEG3D_V2_MAXPX) {
+            if (tap < nx) dma_x(tap, nxt);
+          } else if (tap - SEG3D_V2_MAXPX < MAXPW) {
+            dma_w(tap - SEG3D_V2_MAXPX, wnext, nxt);
+          }
+        }
+        // A = weights, B = voxels: D[co][voxel], a lane owns voxel (lane & 31) and channels 8 g + 4 (lane >> 5) + c
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int m = 0; m < MA; ++m)
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+              acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[q][r], av[m][r], acc[m][q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) bw[q] = bwn[q];
+#pragma unroll
+        for (int m = 0; m < MA; ++m) av[m] = avn[m];
+      }
+      if (do_dma) __syncthreads();  // own DMAs landed (vmcnt(0)), everyone done with `cur`, `nxt` visible
+      parity ^= 1;
+    }
+    SEG3D_STAMP(item, 2);
+
+    // ---- epilogue: bias (+ addend), dwordx4 stores, per-wave GroupNorm partial sums ----
+    // Loads first, stores last, nothing in between: on gfx9 stores count in vmcnt too, so a load placed after a store
+    // makes the compiler wait for that store's full round trip before the next one is issued.
+    float s0 = 0.f, s1 = 0.f;
+    int vo[MA];
+#pragma unroll
+    for (int m = 0; m < MA; ++m) {
+      const int vp = vpos[m];
+      const int gz = cur_z0 + ((vp >> 20) & 1023), gy = cur_y0 + ((vp >> 10) & 1023), gx = cur_x0 + (vp & 1023);
+      vo[m] = (vp >= 0 && gz < D && gy < H && gx < W) ? ((cur_n * D + gz) * H + gy) * W + gx : -1;
+    }
+    const int co_lane = cur_cog * NB * 32 + 4 * lh;  // + 32 q + 8 g4
+    if (addend) {
+      f32x4 ad[MA][NB][4];
+#pragma unroll
+      for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = co_lane + 32 * q + 8 * g4;
+            const bool ok = vo[m] >= 0 && co < Cout;
+            ad[m][q][g4] = *reinterpret_cast<const f32x4*>(addend + (ok ? (i64)vo[m] * Cout + co : (i64)0));
+          }
+#pragma unroll
+      for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[m][q][4 * g4 + c] += ad[m][q][g4][c];
+    }
+    // interior items (whole tile inside the volume, all 32-channel blocks complete) store unconditionally: straight-
+    // line code, 4 * MA * NB dwordx4 stores back to back; the per-lane test of edge items costs exec-mask branches
+    const bool whole = MT == 128 * MA && cur_z0 + TZ <= D && cur_y0 + TY <= H && cur_x0 + TX <= W &&
+                       (cur_cog + 1) * NB * 32 <= Cout;
+    if (whole) {
+#pragma unroll
+      for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] = acc[m][q][4 * g4 + c] + bv[q][g4][c];
+              s0 += v[c];
+              s1 += v[c] * v[c];
+            }
+            *reinterpret_cast<f32x4*>(y + ((i64)vo[m] * Cout + (co_lane + 32 * q + 8 * g4))) = v;
+          }
+    } else {
+#pragma unroll
+      for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = co_lane + 32 * q + 8 * g4;
+            if (vo[m] >= 0 && co < Cout) {
+              f32x4 v;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                v[c] = acc[m][q][4 * g4 + c] + bv[q][g4][c];
+                s0 += v[c];
+                s1 += v[c] * v[c];
+              }
+              *reinterpret_cast<f32x4*>(y + ((i64)vo[m] * Cout + co)) = v;
+            }
+          }
+    }
+    if (stats) {
+      s0 = wave_sum(s0);
+      s1 = wave_sum(s1);
+      if (lane == 0) {
+        const int tiles_per_sample = ntz * nty * ntx;
+        float* dst = stats + ((((i64)cur_n * tiles_per_sample + cur_tile) * ncog + cur_cog) * 4 + wave) * 2;
+        dst[0] = s0;
+        dst[1] = s1;
+      }
+    }
+    SEG3D_STAMP(item, 3);
+    if (!more_items) break;
+    item = next_item;
   }
 }
 
@@ -345,6 +688,90 @@ static int seg3d_fwd_ksplit(int N, int D, int H, int W, int Cin, int Cout) {
   return ks < 2 ? 1 : ks;
 }
 
+// ---- second-generation kernel: tile / column-block choice for ONE workgroup per CU -------------------------------
+static size_t seg3d_fwd2_lds_bytes(const Seg3dTile& t, int nb) {
+  const int nv = (t.tz + 2) * (t.ty + 2) * (t.tx + 2);
+  const int mt = t.tz * t.ty * t.tx;
+  const int xs = (8 * nv + 255) & ~255;
+  (void)mt;
+  return (size_t)(2 * (xs + nb * SEG3D_W_CHUNK)) * 4;
+}
+
+struct Seg3dFwdPlan {
+  int version;  // 1: two workgroups per CU, register-staged (also the split-K path); 2: one per CU, LDS-DMA
+  Seg3dTile t;
+  int ma, nb, ks;
+};
+
+// time model (cycles): 256 workgroups run at once, every round costs one workgroup's duration =
+// K-chunks x 27 taps x 4 x MA x NB MFMAs of 64 cycles + DMA issue + a fixed prologue/epilogue
+static bool seg3d_pick_tile_v2(int N, int D, int H, int W, int Cin, int Cout, Seg3dTile* tile, int* ma_out, int* nb_out) {
+  const int cand_z[] = {1, 2, 3, 4, 6, 8};
+  const int cand_y[] = {2, 3, 4, 6, 8, 12, 16};
+  const int cand_x[] = {4, 6, 8, 12, 16, 24, 32};
+  const int cobs = (Cout + 31) / 32, cib = (Cin + 7) / 8;
+  double best_cost = 1e30;
+  bool found = false;
+  for (int nb = 1; nb <= 2; ++nb) {
+    if (cobs % nb) continue;
+    for (int tz : cand_z)
+      for (int ty : cand_y)
+        for (int tx : cand_x) {
+          if (tz > D && tz != 1) continue;
+          const int mt = tz * ty * tx;
+          if (mt > 128 * (4 / nb) || mt < 32) continue;  // MA * NB <= 4 accumulators per wave (16 MFMAs per tap)
+          const int nv = (tz + 2) * (ty + 2) * (tx + 2);
+          if (2 * nv > SEG3D_V2_MAXPX * 256) continue;
+          Seg3dTile t = {tz, ty, tx};
+          if (seg3d_fwd2_lds_bytes(t, nb) > 160 * 1024) continue;
+          const int ma = ((mt + 31) / 32 + 3) / 4;
+          const double wgs = (double)N * seg3d_cdiv(D, tz) * seg3d_cdiv(H, ty) * seg3d_cdiv(W, tx) * (cobs / nb);
+          const double rounds = ceil(wgs / 256.0);
+          const double pieces = (((8 * nv + 255) >> 8) + 27 * nb) / 4.0;
+          const double per_wg = cib * (6912.0 * ma * nb + 60.0 * pieces + 400.0) + 9000.0;
+          const double cost = rounds * per_wg;
+          if (cost < best_cost) {
+            best_cost = cost;
+            *tile = t;
+            *ma_out = ma;
+            *nb_out = nb;
+            found = true;
+          }
+        }
+  }
+  return found;
+}
+
+static int seg3d_fwd_v2_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEG3D_FWD_V2");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout) {
+  Seg3dFwdPlan p;
+  p.ks = seg3d_fwd_ksplit(N, D, H, W, Cin, Cout);
+  p.version = 1;
+  p.nb = 1;
+  p.t = seg3d_pick_tile(N, D, H, W, (Cout + 31) / 32);
+  p.ma = ((p.t.tz * p.t.ty * p.t.tx + 31) / 32 + 3) / 4;
+  if (p.ks == 1 && (Cin & 7) == 0 && (Cout & 3) == 0 && seg3d_fwd_v2_enabled()) {
+    Seg3dTile t2;
+    int ma2, nb2;
+    if (seg3d_pick_tile_v2(N, D, H, W, Cin, Cout, &t2, &ma2, &nb2) &&
+        (i64)N * seg3d_cdiv(D, t2.tz) * seg3d_cdiv(H, t2.ty) * seg3d_cdiv(W, t2.tx) * ((Cout + 31) / 32 / nb2) < (1 << 20)) {
+      p.version = 2;
+      p.t = t2;
+      p.ma = ma2;
+      p.nb = nb2;
+    }
+  }
+  return p;
+}
+
 extern "C" long long seg3d_conv3d_k3_mfma_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
   const int ks = seg3d_fwd_ksplit(N, D, H, W, Cin, Cout);
   return ks > 1 ? (long long)ks * N * D * H * W * Cout : 0;
@@ -352,17 +779,18 @@ extern "C" long long seg3d_conv3d_k3_mfma_fwd_workspace_floats(int N, int D, int
 
 // GroupNorm partial (sum, sumsq) slots per sample that seg3d_conv3d_k3_mfma_fwd writes for this problem
 extern "C" long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W, int Cin, int Cout) {
-  if (seg3d_fwd_ksplit(N, D, H, W, Cin, Cout) > 1) return ((long long)D * H * W * Cout + SPLITK_CHUNK - 1) / SPLITK_CHUNK;
+  const Seg3dFwdPlan p = seg3d_fwd_plan(N, D, H, W, Cin, Cout);
+  if (p.ks > 1) return ((long long)D * H * W * Cout + SPLITK_CHUNK - 1) / SPLITK_CHUNK;
   const int cob = (Cout + 31) / 32;
-  Seg3dTile t = seg3d_pick_tile(N, D, H, W, cob);
-  return (long long)seg3d_cdiv(D, t.tz) * seg3d_cdiv(H, t.ty) * seg3d_cdiv(W, t.tx) * cob;
+  const long long tiles = (long long)seg3d_cdiv(D, p.t.tz) * seg3d_cdiv(H, p.t.ty) * seg3d_cdiv(W, p.t.tx);
+  return p.version == 2 ? tiles * (cob / p.nb) * 4 /* one slot per wave */ : tiles * cob;
 }
 
-// which template instantiation (accumulators per wave, 1..4) a given problem runs: lets profilers attribute time
-extern "C" int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cout) {
-  Seg3dTile t = seg3d_pick_tile(N, D, H, W, (Cout + 31) / 32);
-  const int subs = (t.tz * t.ty * t.tx + 31) / 32;
-  return (subs + 3) / 4;
+// which template instantiation a given problem runs (lets profilers attribute time): MA (row blocks per wave, 1..4)
+// for the first-generation kernel conv3d_k3_mfma_kernel<MA>; 100 + 10 MA + NB for conv3d_k3_mfma2_kernel<MA, NB>
+extern "C" int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cin, int Cout) {
+  const Seg3dFwdPlan p = seg3d_fwd_plan(N, D, H, W, Cin, Cout);
+  return p.version == 2 ? 100 + 10 * p.ma + p.nb : p.ma;
 }
 
 template <int MA>
@@ -389,6 +817,29 @@ static int launch_fwd(const float* x, const float* wp, const float* bias, float*
   return SEG3D_OK;
 }
 
+template <int MA, int NB>
+static int launch_fwd2(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
+                       int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, const float* addend) {
+  const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
+  const size_t lds = seg3d_fwd2_lds_bytes(t, NB);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_kernel<MA, NB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) {
+      seg3d_set_error("conv3d_k3_mfma2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SEG3D_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  const int ncog = (Cout + 31) / 32 / NB;
+  const int nitems = N * ntz * nty * ntx * ncog;
+  dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);  // persistent: one workgroup per CU walks the items
+  hipLaunchKernelGGL((conv3d_k3_mfma2_kernel<MA, NB>), grid, dim3(256), lds, s, x, wp, bias, y, stats, N, D, H, W, Cin,
+                     Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, addend);
+  return SEG3D_OK;
+}
+
 // x [N][D][H][W][Cin], wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 27), y [N][D][H][W][Cout];
 // stats (optional): [N][seg3d_conv3d_k3_mfma_stats_count][2] partial (sum, sumsq) of y per sample.
 // addend (optional, same shape as y): y = conv(x) + bias + addend -- used by the data-gradient of the first conv of a
@@ -401,12 +852,27 @@ extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const f
   SEG3D_REQUIRE((Cin % 4) == 0, "seg3d_conv3d_k3_mfma_fwd: Cin must be a multiple of 4 (got %d); use the direct kernel", Cin);
   SEG3D_REQUIRE((i64)N * D * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31),
                 "seg3d_conv3d_k3_mfma_fwd: tensor exceeds 2^31 elements");
-  const int cob = (Cout + 31) / 32;
-  Seg3dTile t = seg3d_pick_tile(N, D, H, W, cob);
-  const int subs = (t.tz * t.ty * t.tx + 31) / 32;
-  const int ma = (subs + 3) / 4;
+  const Seg3dFwdPlan plan = seg3d_fwd_plan(N, D, H, W, Cin, Cout);
+  const Seg3dTile t = plan.t;
+  const int ma = plan.ma;
   hipStream_t s = (hipStream_t)stream;
-  const int ks = seg3d_fwd_ksplit(N, D, H, W, Cin, Cout);
+  const int ks = plan.ks;
+  if (plan.version == 2) {
+    int rc2;
+    switch (plan.ma * 10 + plan.nb) {
+      case 11: rc2 = launch_fwd2<1, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
+      case 21: rc2 = launch_fwd2<2, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
+      case 31: rc2 = launch_fwd2<3, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
+      case 41: rc2 = launch_fwd2<4, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
+      case 12: rc2 = launch_fwd2<1, 2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
+      case 22: rc2 = launch_fwd2<2, 2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
+      default:
+        SEG3D_UNSUPPORTED("seg3d_conv3d_k3_mfma_fwd: internal plan error (ma=%d nb=%d)", plan.ma, plan.nb);
+    }
+    if (rc2 != SEG3D_OK) return rc2;
+    SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_fwd(v2)");
+    return SEG3D_OK;
+  }
   SEG3D_REQUIRE(ks == 1 || workspace, "seg3d_conv3d_k3_mfma_fwd: this shape runs split-K and needs the workspace "
                 "(seg3d_conv3d_k3_mfma_fwd_workspace_floats)");
   int rc;

@@ -34,7 +34,7 @@ _SIGNATURES = {
     'seg3d_wgrad_reduce': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p]),
     'seg3d_conv3d_k3_mfma_stats_count': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_fwd_workspace_floats': (_c_ll, [_c_int] * 6),
-    'seg3d_conv3d_k3_mfma_variant': (_c_int, [_c_int] * 5),
+    'seg3d_conv3d_k3_mfma_variant': (_c_int, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_fwd': (_c_int, [_c_p] * 7 + [_c_int] * 6 + [_c_p]),
     'seg3d_conv3d_k3_mfma_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 7 + [_c_p]),

@@ -1,0 +1,23 @@
+"""summarise a rocprofv3 --pmc counter_collection.csv per kernel (SQ wave-cycle breakdown + MFMA busy fraction)
+usage: python tools/pmc_summary.py <counter_collection.csv> [name filter]"""
+import csv, collections, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+flt = sys.argv[2] if len(sys.argv) > 2 else 'mfma'
+agg = collections.OrderedDict()
+for r in rows:
+    k = (r['Kernel_Name'][:48], r['Grid_Size'])
+    agg.setdefault(k, collections.defaultdict(list))[r['Counter_Name']].append(float(r['Counter_Value']))
+for k, d in agg.items():
+    if flt not in k[0]:
+        continue
+    m = {c: sum(v) / len(v) for c, v in d.items()}
+    wc = m.get('SQ_WAVE_CYCLES', 0.0)
+    line = '{} grid={} n={}'.format(k[0], k[1], len(next(iter(d.values()))))
+    if 'GRBM_GUI_ACTIVE' in m and 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
+        simd_cycles = m['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0        # GUI_ACTIVE is summed over 8 XCDs; 1024 SIMDs
+        line += '  mfma_busy={:.3f} gui_cycles/xcd={:.3g}'.format(m['SQ_VALU_MFMA_BUSY_CYCLES'] / simd_cycles, m['GRBM_GUI_ACTIVE'] / 8.0)
+    if wc:
+        for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_INST_LDS', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_VMEM', 'SQ_ACTIVE_INST_SCA', 'SQ_ACTIVE_INST_MISC'):
+            if c in m:
+                line += ' {}={:.3f}'.format(c.replace('SQ_', ''), m[c] / wc)
+    print(line)

@@ -944,7 +944,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
 
   // Register-prefetch pipeline over the tile loop: the global loads of tile t+1 are issued before the MFMA block of
   // tile t (branch-free, clamped addresses) and written to LDS after it, so HBM/L2 latency hides behind the matrix work.
+  // (the zero-select of out-of-range entries happens in store_tile from a bit mask: consuming a loaded value right
+  // here would make the compiler wait for each load before issuing the next)
   f32x4 xst[SEG3D_WG_XE], yst[SEG3D_WG_YE];
+  unsigned okmask = 0;
   auto load_tile = [&](int tile) {
     int b = tile;
     const int tix = b % ntx; b /= ntx;
@@ -952,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
     const int tiz = b % ntz;
     const int n = b / ntz;
     const int z0 = tiz * SEG3D_WG_TZ, y0 = tiy * SEG3D_WG_TY, x0 = tix * SEG3D_WG_TX;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    okmask = 0;
 #pragma unroll
     for (int e = 0; e < SEG3D_WG_XE; ++e) {
       const int eidx = tid + e * 256;
@@ -963,9 +966,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
       const int hz = t / SEG3D_WG_HY;
       const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
       const bool ok = eidx < SEG3D_WG_NV * 8 && xq_ok && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const f32x4 val = *reinterpret_cast<const f32x4*>(
+      xst[e] = *reinterpret_cast<const f32x4*>(
           x + (ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * Cin + ci0 + 4 * q : (i64)0));
-      xst[e] = ok ? val : zero;
+      okmask |= (ok ? 1u : 0u) << e;
     }
 #pragma unroll
     for (int e = 0; e < SEG3D_WG_YE; ++e) {
@@ -977,21 +980,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
       const int tz = t / SEG3D_WG_TY;
       const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
       const bool ok = yq_ok && gz < D && gy < H && gx < W;
-      const f32x4 val = *reinterpret_cast<const f32x4*>(
+      yst[e] = *reinterpret_cast<const f32x4*>(
           dy + (ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * Cout + co0 + 4 * q : (i64)0));
-      yst[e] = ok ? val : zero;
+      okmask |= (ok ? 1u : 0u) << (16 + e);
     }
   };
   auto store_tile = [&]() {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < SEG3D_WG_XE; ++e) {
       const int eidx = tid + e * 256;
-      if (eidx < SEG3D_WG_NV * 8) *reinterpret_cast<f32x4*>(xs + (eidx >> 3) * 32 + 4 * q) = xst[e];
+      if (eidx < SEG3D_WG_NV * 8)
+        *reinterpret_cast<f32x4*>(xs + (eidx >> 3) * 32 + 4 * q) = ((okmask >> e) & 1u) ? xst[e] : zero;
     }
 #pragma unroll
     for (int e = 0; e < SEG3D_WG_YE; ++e) {
       const int eidx = tid + e * 256;
-      *reinterpret_cast<f32x4*>(dys + (eidx >> 3) * 32 + 4 * q) = yst[e];
+      *reinterpret_cast<f32x4*>(dys + (eidx >> 3) * 32 + 4 * q) = ((okmask >> (16 + e)) & 1u) ? yst[e] : zero;
     }
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
@@ -1026,6 +1031,238 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
     if (tap < 27) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[tap * 1024 + mfma_row(r, lh) * 32 + li] = acc[j][r];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Weight gradient, second generation (conv3d_k3_wgrad2_kernel): the same recipe as conv3d_k3_mfma2_kernel.
+//   ONE persistent workgroup per CU (one wave per SIMD); a workgroup owns one 32-channel block of x, NB 32-channel
+//   blocks of dy and one spatial slab (tiles slab, slab + slabs, ...), keeping its 7 x NB accumulators per wave (taps
+//   7w..7w+6) in registers across all its tiles.  The next tile (x halo tile [360][32] + dy tile [NB][128][32]) arrives
+//   by LDS-DMA into the second LDS buffer while the current one is multiplied: one 1-KiB piece every third k-pair,
+//   its address arithmetic done right there in the shadow of the MFMAs (no integer division, no staging registers,
+//   no ds_write pass); one barrier per tile.  The x tile is staged once for NB*32 output channels.
+// ----------------------------------------------------------------------------------------------------------------
+#define SEG3D_WG2_XP (SEG3D_WG_NV / 8)   // 45 DMA pieces: 8 voxels x 32 channels each
+#define SEG3D_WG2_YP (SEG3D_WG_MT / 8)   // 16 DMA pieces per 32-channel block of dy
+
+template <int NB>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    float* __restrict__ part, int N, int D, int H, int W,
+                                                                    int Cin, int Cout, int ntz, int nty, int ntx, int ntiles,
+                                                                    int slabs, int COG) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int XS = SEG3D_WG_NV * 32;                 // floats
+  constexpr int BUF = XS + NB * SEG3D_WG_MT * 32;
+  constexpr int NP = SEG3D_WG2_XP + NB * SEG3D_WG2_YP;  // pieces per tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int slab = blockIdx.x % slabs;
+  const int pg = blockIdx.x / slabs;                   // (ci block, co group)
+  const int cib = pg / COG, cog = pg % COG;
+  const int ci0 = cib * 32, co0 = cog * NB * 32;
+  const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz;
+  auto fdiv = [](int v, float r) { return (int)(((float)v + 0.5f) * r); };  // exact for the small ranges used here
+
+  int tapoff[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    int tap = wave * 7 + j;
+    if (tap > 26) tap = 26;  // idle slot of wave 3 recomputes tap 26 into a discarded accumulator
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    tapoff[j] = ((kz * SEG3D_WG_HY + ky) * SEG3D_WG_HX + kx) * 32;
+  }
+  f32x16 acc[7][NB];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][q][r] = 0.f;
+
+  // one DMA piece of `tile` into `buf`: piece p = wave + 4 g; lane -> voxel 8 p' + (lane >> 3), channels 4 (lane & 7)..+3
+  const int lv = lane >> 3, lq = lane & 7;
+  int tn = 0, tz0 = 0, ty0 = 0, tx0 = 0;  // origin of the tile being fetched
+  auto set_tile = [&](int tile) {
+    int b = tile;
+    int q = fdiv(b, rNTX);
+    const int tix = b - q * ntx;
+    b = q;
+    q = fdiv(b, rNTY);
+    const int tiy = b - q * nty;
+    b = q;
+    q = fdiv(b, rNTZ);
+    const int tiz = b - q * ntz;
+    tn = q;
+    tz0 = tiz * SEG3D_WG_TZ, ty0 = tiy * SEG3D_WG_TY, tx0 = tix * SEG3D_WG_TX;
+  };
+  auto issue_piece = [&](int g, float* buf) {
+    const int p = wave + 4 * g;
+    if (p < SEG3D_WG2_XP) {
+      const int v = p * 8 + lv;                                   // halo voxel 0..359: (hz, hy, hx) in 6 x 6 x 10
+      const int t = fdiv(v, 1.0f / (float)SEG3D_WG_HX);
+      const int hx = v - t * SEG3D_WG_HX;
+      const int hz = fdiv(t, 1.0f / (float)SEG3D_WG_HY);
+      const int hy = t - hz * SEG3D_WG_HY;
+      const int gz = tz0 + hz - 1, gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+      const bool ok = ci0 + 4 * lq < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float* src = ok ? x + ((i64)(((tn * D + gz) * H + gy) * W + gx) * Cin + ci0 + 4 * lq) : seg3d_zero16;
+      seg3d_glds16(src, buf + p * 256);
+    } else if (p < NP) {
+      const int pp = p - SEG3D_WG2_XP;
+      const int nb = pp / SEG3D_WG2_YP;
+      const int v = (pp - nb * SEG3D_WG2_YP) * 8 + lv;            // tile voxel 0..127: (tz, ty, tx) in 4 x 4 x 8
+      const int gz = tz0 + (v >> 5), gy = ty0 + ((v >> 3) & 3), gx = tx0 + (v & 7);
+      const int co = co0 + nb * 32 + 4 * lq;
+      const bool ok = co < Cout && gz < D && gy < H && gx < W;
+      const float* src = ok ? dy + ((i64)(((tn * D + gz) * H + gy) * W + gx) * Cout + co) : seg3d_zero16;
+      seg3d_glds16(src, buf + XS + pp * 256);
+    }
+  };
+  constexpr int NG = (NP + 3) / 4;  // piece groups per wave per tile (<= 20): one every third k-pair
+
+  // Fast path for tiles that lie completely inside the volume (all of them when D, H, W are multiples of 4, 4, 8):
+  // a piece's source is  tile origin (uniform)  +  a tile-invariant per-lane offset, and it is zero padding exactly
+  // when its halo face lies outside the volume -- 5 instructions per piece instead of ~40.
+  int prel[NG], pflag[NG];  // float offset from the tile-origin voxel; face bits (bit 6: channel slice out of range)
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int p = wave + 4 * g;
+    prel[g] = 0;
+    pflag[g] = -1;
+    if (p < SEG3D_WG2_XP) {
+      const int v = p * 8 + lv;
+      const int t = fdiv(v, 1.0f / (float)SEG3D_WG_HX);
+      const int hx = v - t * SEG3D_WG_HX;
+      const int hz = fdiv(t, 1.0f / (float)SEG3D_WG_HY);
+      const int hy = t - hz * SEG3D_WG_HY;
+      prel[g] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + ci0 + 4 * lq;
+      pflag[g] = (hz == 0 ? 1 : 0) | (hz == SEG3D_WG_TZ + 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == SEG3D_WG_TY + 1 ? 8 : 0) |
+                 (hx == 0 ? 16 : 0) | (hx == SEG3D_WG_TX + 1 ? 32 : 0) | (ci0 + 4 * lq < Cin ? 0 : 64);
+    } else if (p < NP) {
+      const int pp = p - SEG3D_WG2_XP;
+      const int nb = pp / SEG3D_WG2_YP;
+      const int v = (pp - nb * SEG3D_WG2_YP) * 8 + lv;
+      const int co = co0 + nb * 32 + 4 * lq;
+      prel[g] = (((v >> 5) * H + ((v >> 3) & 3)) * W + (v & 7)) * Cout + co;
+      pflag[g] = co < Cout ? 0 : 64;
+    }
+  }
+  auto issue_piece_fast = [&](int g, float* buf, const float* xbase, const float* ybase, int faces) {
+    const int p = wave + 4 * g;
+    if (p < NP) {
+      const float* base = p < SEG3D_WG2_XP ? xbase : ybase;  // uniform
+      const float* src = (pflag[g] & faces) ? seg3d_zero16 : base + prel[g];
+      seg3d_glds16(src, buf + p * 256);
+    }
+  };
+
+  int tile = slab;
+  if (tile < ntiles) {
+    set_tile(tile);
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) issue_piece(g, lds);
+  }
+  __syncthreads();
+  int parity = 0;
+#ifdef SEG3D_STAMPS
+  int stamp_k = 0;
+#endif
+  for (; tile < ntiles; tile += slabs) {
+#ifdef SEG3D_STAMPS
+    if (stamp_k < 5) SEG3D_STAMP(blockIdx.x, 3 * stamp_k);
+#endif
+    const float* cur = lds + parity * BUF;
+    float* nxt = lds + (parity ^ 1) * BUF;
+    const bool more = tile + slabs < ntiles;
+    if (more) set_tile(tile + slabs);
+    // the tile being fetched: inside the volume?  which of its halo faces stick out?
+    const bool regular = tz0 + SEG3D_WG_TZ <= D && ty0 + SEG3D_WG_TY <= H && tx0 + SEG3D_WG_TX <= W;
+    const int faces = 64 | (tz0 == 0 ? 1 : 0) | (tz0 + SEG3D_WG_TZ >= D ? 2 : 0) | (ty0 == 0 ? 4 : 0) |
+                      (ty0 + SEG3D_WG_TY >= H ? 8 : 0) | (tx0 == 0 ? 16 : 0) | (tx0 + SEG3D_WG_TX >= W ? 32 : 0);
+    const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
+    const float* xbase = x + origin * Cin;
+    const float* ybase = dy + origin * Cout;
+    if (more && !regular) {  // tiles sticking out of the volume (dims not multiples of 4, 4, 8): generic path, up front
+#pragma unroll 1
+      for (int g = 0; g < NG; ++g) issue_piece(g, nxt);
+    }
+    const float* xa = cur + lh * 32 + li;          // + voxel * 32 + tap offset
+    const float* yb = cur + XS + lh * 32 + li;     // + nb * 4096 + voxel * 32
+    // voxel pair (2 kp, 2 kp + 1) lies in one row of the 4 x 4 x 8 tile, so the lane half only shifts by one voxel.
+    // Operands of pair kp+1 are read while pair kp is multiplied (one wave per SIMD: nothing else hides LDS latency).
+    auto xoff = [](int kp) {
+      const int v0 = 2 * kp;
+      return (((v0 >> 5) * SEG3D_WG_HY + ((v0 >> 3) & 3)) * SEG3D_WG_HX + (v0 & 7)) * 32;
+    };
+    // two pairs ahead: the scheduler interleaves reads and MFMAs one to one, so a distance of one pair leaves a read
+    // only ~2 MFMAs of cover
+    float a1[7], b1[NB], a2[7], b2[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      b1[q] = yb[q * SEG3D_WG_MT * 32];
+      b2[q] = yb[q * SEG3D_WG_MT * 32 + 2 * 32];
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      a1[j] = xa[xoff(0) + tapoff[j]];
+      a2[j] = xa[xoff(1) + tapoff[j]];
+    }
+#pragma unroll
+    for (int kp = 0; kp < SEG3D_WG_MT / 2; ++kp) {
+      float a[7], bvv[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        bvv[q] = b1[q];
+        b1[q] = b2[q];
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        a[j] = a1[j];
+        a1[j] = a2[j];
+      }
+      if (kp + 2 < SEG3D_WG_MT / 2) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) b2[q] = yb[q * SEG3D_WG_MT * 32 + (2 * kp + 4) * 32];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) a2[j] = xa[xoff(kp + 2) + tapoff[j]];
+      }
+#ifndef SEG3D_EXPERIMENT_NODMA
+      if (more && regular && kp % 3 == 0 && kp / 3 < NG) issue_piece_fast(kp / 3, nxt, xbase, ybase, faces);
+#endif
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int q = 0; q < NB; ++q) acc[j][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bvv[q], acc[j][q], 0, 0, 0);
+      if (NB > 1) __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from hoisting reads of many pairs (spills)
+    }
+#ifdef SEG3D_STAMPS
+    if (stamp_k < 5) SEG3D_STAMP(blockIdx.x, 3 * stamp_k + 1);
+#endif
+    if (more) __syncthreads();  // own DMAs landed (vmcnt(0)), everyone done with `cur`, `nxt` visible
+#ifdef SEG3D_STAMPS
+    if (stamp_k < 5) SEG3D_STAMP(blockIdx.x, 3 * stamp_k + 2);
+    ++stamp_k;
+#endif
+    parity ^= 1;
+  }
+
+  // part[slab][pair = cib * COB32 + cob][tap][ci row][co col]
+  const int COB32 = COG * NB;
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int pair = cib * COB32 + cog * NB + q;
+    float* dst = part + ((i64)slab * (COB32 * ((Cin + 31) / 32)) + pair) * 27 * 1024;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int tap = wave * 7 + j;
+      if (tap < 27) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[tap * 1024 + mfma_row(r, lh) * 32 + li] = acc[j][q][r];
+      }
     }
   }
 }
@@ -1068,9 +1305,72 @@ static int seg3d_wgrad_slabs(int N, int D, int H, int W, int npairs) {
   return slabs;
 }
 
+struct Seg3dWgradPlan {
+  int version;  // 1: two workgroups per CU, register-staged; 2: one persistent workgroup per CU, LDS-DMA
+  int nb;       // 32-channel blocks of dy per workgroup (version 2)
+  int slabs;
+};
+
+static int seg3d_wgrad_v2_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEG3D_WGRAD_V2");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+static Seg3dWgradPlan seg3d_wgrad_plan(int N, int D, int H, int W, int Cin, int Cout) {
+  const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
+  const int npairs = CIB32 * COB32;
+  Seg3dWgradPlan p;
+  p.version = 1;
+  p.nb = 1;
+  p.slabs = seg3d_wgrad_slabs(N, D, H, W, npairs);
+  if (seg3d_wgrad_v2_enabled()) {
+    const int ntiles = N * seg3d_cdiv(D, SEG3D_WG_TZ) * seg3d_cdiv(H, SEG3D_WG_TY) * seg3d_cdiv(W, SEG3D_WG_TX);
+    p.version = 2;
+    p.nb = (COB32 % 2 == 0) ? 2 : 1;
+    {
+      static int forced = -1;  // experiment switch
+      if (forced < 0) {
+        const char* e = getenv("SEG3D_WGRAD_NB");
+        forced = e ? atoi(e) : 0;
+      }
+      if (forced != 2) p.nb = 1;  // NB = 2 spills in the fully unrolled loop: opt-in until that is fixed
+    }
+    const int npg = CIB32 * (COB32 / p.nb);
+    int slabs = 256 / npg;  // one resident workgroup per CU over the whole grid
+    if (slabs > (ntiles + 1) / 2) slabs = (ntiles + 1) / 2;  // small levels: >= 2 tiles per workgroup
+    if (slabs < 1) slabs = 1;
+    p.slabs = slabs;
+  }
+  return p;
+}
+
 extern "C" long long seg3d_conv3d_k3_mfma_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
   const int npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
-  return (long long)seg3d_wgrad_slabs(N, D, H, W, npairs) * npairs * 27 * 1024;
+  return (long long)seg3d_wgrad_plan(N, D, H, W, Cin, Cout).slabs * npairs * 27 * 1024;
+}
+
+template <int NB>
+static int launch_wgrad2(const float* x, const float* dy, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
+                         int ntz, int nty, int ntx, int ntiles, int slabs, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad2_kernel<NB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) {
+      seg3d_set_error("conv3d_k3_wgrad2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SEG3D_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  const int CIB32 = (Cin + 31) / 32, COG = (Cout + 31) / 32 / NB;
+  const size_t lds = (size_t)2 * (SEG3D_WG_NV * 32 + NB * SEG3D_WG_MT * 32) * 4;
+  hipLaunchKernelGGL((conv3d_k3_wgrad2_kernel<NB>), dim3((unsigned)(slabs * CIB32 * COG)), dim3(256), lds, s, x, dy, workspace,
+                     N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, COG);
+  return SEG3D_OK;
 }
 
 // dw is written in the reference Conv3d layout [Cout][Cin][3][3][3]  (sa = 27 for ci, sb = Cin*27 for co).
@@ -1084,10 +1384,19 @@ extern "C" int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float
   const int npairs = CIB32 * COB32;
   const int ntz = seg3d_cdiv(D, SEG3D_WG_TZ), nty = seg3d_cdiv(H, SEG3D_WG_TY), ntx = seg3d_cdiv(W, SEG3D_WG_TX);
   const int ntiles = N * ntz * nty * ntx;
-  const int slabs = seg3d_wgrad_slabs(N, D, H, W, npairs);
+  SEG3D_REQUIRE((i64)N * D * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31),
+                "seg3d_conv3d_k3_mfma_wgrad: tensor exceeds 2^31 elements");
+  const Seg3dWgradPlan plan = seg3d_wgrad_plan(N, D, H, W, Cin, Cout);
+  const int slabs = plan.slabs;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv3d_k3_wgrad_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s, x, dy, workspace, N, D, H, W, Cin,
-                     Cout, ntz, nty, ntx, ntiles, COB32);
+  if (plan.version == 2) {
+    const int rc = plan.nb == 2 ? launch_wgrad2<2>(x, dy, workspace, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, s)
+                                : launch_wgrad2<1>(x, dy, workspace, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, s);
+    if (rc != SEG3D_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(conv3d_k3_wgrad_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s, x, dy, workspace, N, D, H, W,
+                       Cin, Cout, ntz, nty, ntx, ntiles, COB32);
+  }
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_wgrad");
   const i64 total = (i64)npairs * 27 * 1024;  // padded (32 x 32 per pair) partial elements, 64 per workgroup
   hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dw, slabs,

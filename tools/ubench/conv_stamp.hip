@@ -55,5 +55,30 @@ int main(int argc, char** argv) {
   printf("  items %lld, workgroups %lld\n  first-item DMA prologue  %8.0f cycles\n  item period (steady)     %8.0f cycles\n"
          "    MFMA chunks            %8.0f\n    epilogue               %8.0f\n",
          nit, nwg, nwg ? pro / nwg : 0.0, np ? period / np : 0.0, np ? mfma / np : 0.0, nit ? epi / nit : 0.0);
+  // ---- weight gradient (conv3d_k3_wgrad2_kernel): per-tile stamps of the first 5 tiles of every workgroup ----
+  {
+    float *dyb, *dw, *ws;
+    (void)hipMalloc(&dyb, ny * 4); (void)hipMemcpy(dyb, x, (ny < nx ? ny : nx) * 4, hipMemcpyDeviceToDevice);
+    (void)hipMalloc(&dw, (size_t)Cout * Cin * 27 * 4);
+    (void)hipMalloc(&ws, (size_t)seg3d_conv3d_k3_mfma_wgrad_workspace_floats(N, D, H, W, Cin, Cout) * 4);
+    (void)hipMemset(stamps, 0, nst * 16 * 8);
+    for (int r = 0; r < 3; ++r) seg3d_conv3d_k3_mfma_wgrad(x, dyb, dw, ws, N, D, H, W, Cin, Cout, 0, nullptr);
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < 10; ++r) seg3d_conv3d_k3_mfma_wgrad(x, dyb, dw, ws, N, D, H, W, Cin, Cout, 0, nullptr);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+    printf("wgrad: %.3f ms, %.1f TFLOP/s (stamped build)\n", ms, 2.0 * N * D * H * W * 27 * Cin * Cout / ms / 1e9);
+    (void)hipMemcpy(h.data(), stamps, nst * 16 * 8, hipMemcpyDeviceToHost);
+    double loop = 0, bar = 0, gap = 0; long long nl = 0, ng = 0;
+    for (size_t b = 0; b < 256; ++b) {
+      const long long* t = &h[b * 16];
+      for (int k = 1; k < 4; ++k) {   // skip the first tile (cold)
+        if (t[3 * k] && t[3 * k + 1] && t[3 * k + 2]) { loop += (double)(t[3 * k + 1] - t[3 * k]); bar += (double)(t[3 * k + 2] - t[3 * k + 1]); ++nl; }
+        if (t[3 * k + 2] && t[3 * k + 3]) { gap += (double)(t[3 * k + 3] - t[3 * k + 2]); ++ng; }
+      }
+    }
+    printf("  per tile: MFMA loop %8.0f cycles (ideal 28672), vmcnt+barrier %6.0f, next-tile setup %6.0f\n",
+           nl ? loop / nl : 0.0, nl ? bar / nl : 0.0, ng ? gap / ng : 0.0);
+  }
   return 0;
 }

@@ -45,6 +45,17 @@ int seg3d_pack_weights_tapmajor(const float* w, float* wp, int A, int B, int BP,
 int seg3d_pack_weights_mfma(const float* w, float* wp, int A, int B, int T, long long sa, long long sb, int flip,
                             void* stream);
 long long seg3d_packed_mfma_floats(int A, int B, int T);
+/* the same pack for many weight tensors in one launch: `jobs_device` is a DEVICE array of njobs descriptors sorted by
+ * first_block, first_block[k+1] = first_block[k] + seg3d_pack_job_blocks(A, B, T) of job k; total_blocks = their sum */
+typedef struct Seg3dPackJob {
+  const float* w;        /* weight tensor (reference layout) */
+  float* wp;             /* packed destination, seg3d_packed_mfma_floats(A, B, T) floats */
+  long long sa, sb;      /* element strides of the reduction-side / output-side channel in w */
+  long long first_block; /* first workgroup of this job */
+  int A, B, T, flip;
+} Seg3dPackJob;
+long long seg3d_pack_job_blocks(int A, int B, int T);
+int seg3d_pack_weights_mfma_multi(const Seg3dPackJob* jobs_device, int njobs, long long total_blocks, void* stream);
 
 /* ---- convolutions ---------------------------------------------------------------------------------------------
  * nn.Conv3d k3 s1 p1  : network/module/conv_gn_relu3.py:10, vnet_inblock.py:9, vnet_outblock.py:13

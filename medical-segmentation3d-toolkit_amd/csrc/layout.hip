@@ -147,6 +147,57 @@ extern "C" int seg3d_pack_weights_mfma(const float* w, float* wp, int A, int B, 
   return SEG3D_OK;
 }
 
+// Many weight tensors in ONE launch (after an optimizer step every conv weight has to be re-packed, for the forward
+// and for the data-gradient orientation: 52 tiny launches per V-Net step otherwise).  `jobs` is a device array;
+// job k owns the workgroups [first_block[k], first_block[k+1]) and each workgroup packs 1024 consecutive elements.
+__global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob* __restrict__ jobs, int njobs) {
+  __shared__ int sjob;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = njobs - 1;  // last job whose first_block <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    sjob = lo;
+  }
+  __syncthreads();
+  const Seg3dPackJob jb = jobs[sjob];
+  const int AB = (jb.A + 7) / 8, BB = (jb.B + 31) / 32, T = jb.T;
+  const i64 total = (i64)BB * AB * T * 256;
+  const i64 base = ((i64)blockIdx.x - jb.first_block) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const i64 idx = base + k * 256 + threadIdx.x;
+    if (idx >= total) break;
+    const int r = (int)(idx & 3);
+    const int j = (int)((idx >> 2) & 31);
+    const int h = (int)((idx >> 7) & 1);
+    i64 rest = idx >> 8;
+    const int t = (int)(rest % T);
+    rest /= T;
+    const int ab = (int)(rest % AB);
+    const int bb = (int)(rest / AB);
+    const int a = ab * 8 + h * 4 + r, b = bb * 32 + j;
+    float v = 0.f;
+    if (a < jb.A && b < jb.B) v = jb.w[a * jb.sa + b * jb.sb + (jb.flip ? T - 1 - t : t)];
+    jb.wp[idx] = v;
+  }
+}
+
+extern "C" long long seg3d_pack_job_blocks(int A, int B, int T) {
+  return ((long long)((B + 31) / 32) * ((A + 7) / 8) * T * 256 + 1023) / 1024;
+}
+
+extern "C" int seg3d_pack_weights_mfma_multi(const Seg3dPackJob* jobs_device, int njobs, long long total_blocks,
+                                             void* stream) {
+  SEG3D_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31),
+                "seg3d_pack_weights_mfma_multi: bad arguments");
+  hipLaunchKernelGGL(pack_mfma_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device,
+                     njobs);
+  SEG3D_LAUNCH_CHECK("seg3d_pack_weights_mfma_multi");
+  return SEG3D_OK;
+}
+
 extern "C" long long seg3d_packed_mfma_floats(int A, int B, int T) {
   return (long long)((B + 31) / 32) * ((A + 7) / 8) * T * 256;
 }

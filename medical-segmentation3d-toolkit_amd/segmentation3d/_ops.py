@@ -71,7 +71,96 @@ def _pack_tapmajor(w, A, B, T, sa, sb, flip=0):
     return wp
 
 
+class _PackJob(ctypes.Structure):   # mirrors Seg3dPackJob (include/seg3d_hip.h)
+    _fields_ = [('w', ctypes.c_void_p), ('wp', ctypes.c_void_p), ('sa', ctypes.c_longlong), ('sb', ctypes.c_longlong),
+                ('first_block', ctypes.c_longlong), ('A', ctypes.c_int), ('B', ctypes.c_int), ('T', ctypes.c_int),
+                ('flip', ctypes.c_int)]
+
+
+class PackedWeightCache(object):
+    """Packed (MFMA-layout) images of conv weights kept across calls.
+
+    Every C->C conv packs its weight twice per train step (forward and data-gradient orientation): 52 tiny launches
+    for the V-Net.  With the cache enabled (`weight_cache(True)`; core/seg_train.TrainStep, bench.py and the
+    sliding-window inference path do it) an image is packed on first use and then re-used while it is current:
+      * `repack_all()` -- called by FusedAdam.step() after its kernel -- refreshes ALL registered images with ONE
+        launch (seg3d_pack_weights_mfma_multi) and marks them current;
+      * `invalidate()` marks everything stale (parameters rewritten behind autograd's back: checkpoint load,
+        broadcast, weight init); a stale image is re-packed in place on its next use, so pointers captured in a
+        hipGraph stay valid;
+      * an in-place torch update of a parameter (torch.optim.*) bumps `tensor._version`, which is part of the check.
+    The cache is OFF by default: code that edits `param.data` in place (no version bump) must call `invalidate()`.
+    """
+
+    def __init__(self):
+        self.enabled = False
+        self.entries = {}     # key -> dict(w, wp, args, epoch, version)
+        self.epoch = 0
+        self._table = None    # (device uint8 tensor, njobs, total_blocks), rebuilt when entries change
+
+    def invalidate(self):
+        self.epoch += 1
+
+    def clear(self):
+        self.entries, self._table = {}, None
+        self.epoch += 1
+
+    def get(self, w, A, B, T, sa, sb, flip):
+        key = (w.data_ptr(), w.device.index, A, B, T, sa, sb, flip)
+        e = self.entries.get(key)
+        if e is not None and e['epoch'] == self.epoch and e['version'] == w._version:
+            return e['wp']
+        if e is None:
+            n = E.query('seg3d_packed_mfma_floats', A, B, T)
+            e = {'w': w, 'wp': _empty((n,), w), 'args': (A, B, T, sa, sb, flip)}
+            self.entries[key] = e
+            self._table = None
+        e['w'] = w
+        E.call('seg3d_pack_weights_mfma', E.ptr(w), E.ptr(e['wp']), A, B, T, sa, sb, flip, E.stream_ptr())
+        e['epoch'], e['version'] = self.epoch, w._version
+        return e['wp']
+
+    def repack_all(self):
+        """weights were just rewritten in place (optimizer step): refresh every registered image with one launch"""
+        self.epoch += 1
+        if not self.entries:
+            return
+        if self._table is None:
+            jobs, first = (_PackJob * len(self.entries))(), 0
+            dev = None
+            for k, e in enumerate(self.entries.values()):
+                A, B, T, sa, sb, flip = e['args']
+                jobs[k] = _PackJob(e['w'].data_ptr(), e['wp'].data_ptr(), sa, sb, first, A, B, T, flip)
+                first += E.query('seg3d_pack_job_blocks', A, B, T)
+                dev = e['wp'].device
+            host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+            self._table = (host.to(dev), len(self.entries), first)
+        table, njobs, blocks = self._table
+        E.call('seg3d_pack_weights_mfma_multi', E.ptr(table), njobs, blocks, E.stream_ptr())
+        for e in self.entries.values():
+            e['epoch'], e['version'] = self.epoch, e['w']._version
+
+
+PACK_CACHE = PackedWeightCache()
+
+
+def weight_cache(enabled):
+    """turn the packed-weight cache on/off (see PackedWeightCache); returns the previous setting"""
+    prev = PACK_CACHE.enabled
+    PACK_CACHE.enabled = bool(enabled)
+    if not enabled:
+        PACK_CACHE.clear()
+    return prev
+
+
 def _pack_mfma(w, A, B, T, sa, sb, flip=0):
+    if PACK_CACHE.enabled and not torch.cuda.is_current_stream_capturing():
+        return PACK_CACHE.get(w, A, B, T, sa, sb, flip)
+    if PACK_CACHE.enabled:   # inside a hipGraph capture: only a current image may be used (no allocation, no launch)
+        key = (w.data_ptr(), w.device.index, A, B, T, sa, sb, flip)
+        e = PACK_CACHE.entries.get(key)
+        if e is not None and e['epoch'] == PACK_CACHE.epoch and e['version'] == w._version:
+            return e['wp']
     n = E.query('seg3d_packed_mfma_floats', A, B, T)
     wp = _empty((n,), w)
     E.call('seg3d_pack_weights_mfma', E.ptr(w), E.ptr(wp), A, B, T, sa, sb, flip, E.stream_ptr())

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from segmentation3d import _engine as E
+from segmentation3d import _ops
 from segmentation3d.utils.image3d import Image3d
 from segmentation3d.utils.image_tools import image_partition_by_fixed_size
 from segmentation3d.utils.model_io import get_checkpoint_folder, strip_module_prefix
@@ -174,35 +175,44 @@ def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, 
     if batches:
         batcher.plan(batches)
     graph, first = None, 0
-    with torch.no_grad():
-        if use_graph and len(batches) > 2:
-            # warm-up on a side stream (allocator, lazy code-object loading), then capture gather -> net -> scatter
-            # once.  The warm-up batch is accumulated for real: it simply is the first batch of the job.
-            stream = torch.cuda.Stream()
-            stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):
-                batcher.select(0)
-                static_in = batcher.gather_current()
-                batcher.scatter_current(net(static_in).contiguous())
-            torch.cuda.current_stream().wait_stream(stream)
-            first = 1
-            # capture with n_valid = 0 in the control block so the captured launch itself accumulates nothing
-            batcher._ctl.zero_()
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                batcher.gather_current(out=static_in)
-                batcher.scatter_current(net(static_in).contiguous())
-        for b in range(first, len(batches)):
-            batcher.select(b)
-            if graph is not None:
-                graph.replay()
-            else:
-                batcher.scatter_current(net(batcher.gather_current()).contiguous())
-        if sharded:
-            torch.distributed.all_reduce(batcher.acc, group=process_group)
-            torch.distributed.all_reduce(batcher.count, group=process_group)
-        probs, mask = batcher.finalize()
+    # the weights do not change during a volume: keep their packed (MFMA-layout) images across batches, so neither
+    # the eager batches nor the captured graph re-pack 26 tensors per forward
+    cache_was_on = _ops.weight_cache(True)
+    try:
+        with torch.no_grad():
+            if use_graph and len(batches) > 2:
+                # warm-up on a side stream (allocator, lazy code-object loading, packed weights), then capture
+                # gather -> net -> scatter once.  The warm-up batch is accumulated for real: it simply is the first
+                # batch of the job.
+                stream = torch.cuda.Stream()
+                stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(stream):
+                    batcher.select(0)
+                    static_in = batcher.gather_current()
+                    batcher.scatter_current(net(static_in).contiguous())
+                torch.cuda.current_stream().wait_stream(stream)
+                first = 1
+                # capture with n_valid = 0 in the control block so the captured launch itself accumulates nothing
+                batcher._ctl.zero_()
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    batcher.gather_current(out=static_in)
+                    batcher.scatter_current(net(static_in).contiguous())
+            for b in range(first, len(batches)):
+                batcher.select(b)
+                if graph is not None:
+                    graph.replay()
+                else:
+                    batcher.scatter_current(net(batcher.gather_current()).contiguous())
+            if sharded:
+                torch.distributed.all_reduce(batcher.acc, group=process_group)
+                torch.distributed.all_reduce(batcher.count, group=process_group)
+            probs, mask = batcher.finalize()
+    finally:
+        if not cache_was_on:
+            torch.cuda.synchronize()   # the images were allocated on the warm-up stream: nothing may still read them
+            _ops.weight_cache(False)
     return probs, mask, batcher
 
 

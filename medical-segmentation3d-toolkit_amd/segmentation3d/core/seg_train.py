@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from segmentation3d import _ops
 from segmentation3d.core.ddp import GradientReducer
 from segmentation3d.loss.cross_entropy_loss import CrossEntropyLoss
 from segmentation3d.loss.focal_loss import FocalLoss
@@ -46,6 +47,7 @@ class TrainStep(object):
         net_module.parameters_kaiming_init(self.net)                                    # core/seg_train.py:75
         self.net = self.net.to(self.device)
         self.opt = FusedAdam(self.net.parameters(), lr=lr, betas=betas)                 # core/seg_train.py:83
+        _ops.weight_cache(True)   # packed conv weights are refreshed by FusedAdam.step() with one launch per step
         self.loss_func = build_loss(loss_name, num_classes, obj_weight, focal_gamma, use_gpu=True)
         if distributed is None:
             distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -54,6 +56,7 @@ class TrainStep(object):
             self.reducer = GradientReducer(self.opt.flat_grads(), self.opt.flat_layout(), num_buckets=num_buckets)
             self.reducer.broadcast_parameters([f['params'] for f in self.opt._flat if f is not None], src=0)
             self.opt.grad_scale = 1.0 / self.reducer.world_size
+            _ops.PACK_CACHE.invalidate()   # the broadcast rewrote the parameters
 
     def __call__(self, crops, masks):
         """one optimisation step; returns the (device) loss tensor of this rank's batch"""

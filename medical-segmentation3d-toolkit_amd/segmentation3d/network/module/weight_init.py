@@ -6,6 +6,8 @@ beta = 0 because the reference only matches 'BatchNorm' / 'Linear' besides the c
 """
 import torch.nn as nn
 
+from segmentation3d import _ops
+
 _CONV_TAGS = ('Conv3d', 'ConvTranspose3d')
 
 
@@ -20,6 +22,7 @@ def _zero_bias(module):
 
 
 def kaiming_weight_init(m, bn_std=0.02):
+    _ops.PACK_CACHE.invalidate()   # `.data` edits below do not bump version counters
     if _is_conv(m) or 'Linear' in type(m).__name__:
         nn.init.kaiming_normal_(m.weight)
         _zero_bias(m)
@@ -29,6 +32,7 @@ def kaiming_weight_init(m, bn_std=0.02):
 
 
 def gaussian_weight_init(m, conv_std=0.01, bn_std=0.01):
+    _ops.PACK_CACHE.invalidate()
     if _is_conv(m):
         m.weight.data.normal_(0, conv_std)
         _zero_bias(m)

@@ -108,6 +108,8 @@ class FusedAdam(torch.optim.Optimizer):
                 # someone re-assigned p.data (e.g. load_state_dict keeps storage, .to() does not): re-adopt it
                 f['params'][off:off + n].copy_(p.data.reshape(-1))
                 p.data = f['params'][off:off + n].view(p.shape)
+                from segmentation3d import _ops
+                _ops.PACK_CACHE.invalidate()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -115,6 +117,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        touched = False
         for group, f in zip(self.param_groups, self._flat):
             if f is None:
                 continue
@@ -124,8 +127,17 @@ class FusedAdam(torch.optim.Optimizer):
             E.call('seg3d_adam_step', E.ptr(f['params']), E.ptr(f['grads']), E.ptr(f['exp_avg']), E.ptr(f['exp_avg_sq']),
                    f['total'], f['step'], float(group['lr']), float(beta1), float(beta2), float(group['eps']),
                    float(group['weight_decay']), float(self.grad_scale), E.stream_ptr())
+            touched = True
             for p in f['list']:
                 self.state[p]['step'] = torch.tensor(float(f['step']))
+        if touched:
+            # the kernel rewrote the parameters without touching their version counters: refresh (one launch) or
+            # invalidate the packed conv-weight images
+            from segmentation3d import _ops
+            if _ops.PACK_CACHE.enabled:
+                _ops.PACK_CACHE.repack_all()
+            else:
+                _ops.PACK_CACHE.invalidate()
         return loss
 
     def release_grad_sinks(self):

@@ -73,11 +73,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const float* _
   const int li = lane & 31, lh = lane >> 5;
   const int CIB = (Cin + 7) >> 3;
   const int cob = blockIdx.y;
+  // index decoding by float reciprocal (seg3d_fdiv): a workgroup owns ONE tile, so this prologue is paid per tile
+  const float rHX = 1.0f / (float)HX, rHY = 1.0f / (float)HY, rTX = 1.0f / (float)TX, rTY = 1.0f / (float)TY;
   int b = blockIdx.x;
-  const int tix = b % ntx; b /= ntx;
-  const int tiy = b % nty; b /= nty;
-  const int tiz = b % ntz;
-  const int n = b / ntz;
+  int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
+  const int tix = b - qd * ntx; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)nty);
+  const int tiy = b - qd * nty; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)ntz);
+  const int tiz = b - qd * ntz;
+  const int n = qd;
   const int z0 = tiz * TZ, y0 = tiy * TY, x0 = tix * TX;
 
   int goff[K2_MAXE];
@@ -88,19 +93,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const float* _
     goff[e] = -1;
     if (eidx < 2 * NV) {
       const int v = eidx >> 1;
-      const int hx = v % HX;
-      const int t = v / HX;
-      const int hy = t % HY;
-      const int hz = t / HY;
+      const int t = seg3d_fdiv(v, rHX);
+      const int hx = v - t * HX;
+      const int hz = seg3d_fdiv(t, rHY);
+      const int hy = t - hz * HY;
       const int gz = 2 * z0 + hz, gy = 2 * y0 + hy, gx = 2 * x0 + hx;
       if (gz < Di && gy < Hi && gx < Wi) goff[e] = (((n * Di + gz) * Hi + gy) * Wi + gx) * Cin + hh * 4;
     }
   }
   for (int idx = tid; idx < MT; idx += 256) {
-    const int tx = idx % TX;
-    const int t = idx / TX;
-    const int ty = t % TY;
-    const int tz = t / TY;
+    const int t = seg3d_fdiv(idx, rTX);
+    const int tx = idx - t * TX;
+    const int tz = seg3d_fdiv(t, rTY);
+    const int ty = t - tz * TY;
     const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
     voff[idx] = (gz < Do && gy < Ho && gx < Wo) ? ((n * Do + gz) * Ho + gy) * Wo + gx : -1;
   }
@@ -109,10 +114,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const float* _
     const int idx = wave * 32 + li;
     int vb = 0;
     if (idx < MT) {
-      const int tx = idx % TX;
-      const int t = idx / TX;
-      const int ty = t % TY;
-      const int tz = t / TY;
+      const int t = seg3d_fdiv(idx, rTX);
+      const int tx = idx - t * TX;
+      const int tz = seg3d_fdiv(t, rTY);
+      const int ty = t - tz * TY;
       vb = ((2 * tz) * HY + 2 * ty) * HX + 2 * tx;
     }
     abase = (lh * NV + vb) * 4;
@@ -122,25 +127,40 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const float* _
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int cib = 0; cib < CIB; ++cib) {
-    __syncthreads();
+  // Register-prefetch pipeline: all loads of chunk c+1 are issued back to back (branch-free, clamped addresses; the
+  // zero-select happens at the LDS store) before the MFMAs of chunk c, so a workgroup keeps 32 KB in flight -- at the
+  // top level this kernel is HBM-bound and a load consumed right where it is issued serialises on memory latency.
+  f32x4 xst[K2_MAXE], wst[2];
+  auto load_chunk = [&](int cib) {
     const bool half_ok = cib * 8 + hh * 4 < Cin;
 #pragma unroll
     for (int e = 0; e < K2_MAXE; ++e) {
-      const int eidx = tid + e * 256;
-      if (eidx < 2 * NV) {
-        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (goff[e] >= 0 && half_ok) val = *reinterpret_cast<const f32x4*>(x + (i64)goff[e] + cib * 8);
-        *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) = val;
-      }
+      const bool ok = goff[e] >= 0 && half_ok;
+      xst[e] = *reinterpret_cast<const f32x4*>(x + (ok ? (i64)goff[e] + cib * 8 : (i64)0));
     }
-    {
-      const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * K2_W_CHUNK);
-      f32x4* wdst = reinterpret_cast<f32x4*>(ws);
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * K2_W_CHUNK);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) wdst[tid + k * 256] = wsrc[tid + k * 256];
+    for (int k = 0; k < 2; ++k) wst[k] = wsrc[tid + k * 256];
+  };
+  auto store_chunk = [&](int cib) {
+    const bool half_ok = cib * 8 + hh * 4 < Cin;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < K2_MAXE; ++e) {
+      const int eidx = tid + e * 256;
+      if (eidx < 2 * NV)
+        *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) = (goff[e] >= 0 && half_ok) ? xst[e] : zero;
     }
+    f32x4* wdst = reinterpret_cast<f32x4*>(ws);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) wdst[tid + k * 256] = wst[k];
+  };
+  load_chunk(0);
+  for (int cib = 0; cib < CIB; ++cib) {
+    __syncthreads();  // previous chunk fully consumed (also publishes voff on the first pass)
+    store_chunk(cib);
     __syncthreads();
+    if (cib + 1 < CIB) load_chunk(cib + 1);
 #pragma unroll
     for (int tap = 0; tap < 8; ++tap) {
       const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
@@ -148,30 +168,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const float* _
       const f32x4 bw = *reinterpret_cast<const f32x4*>(ws + tap * 256 + bbase);
       const f32x4 av = *reinterpret_cast<const f32x4*>(xs + abase + tapoff);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bw[r], acc, 0, 0, 0);
+      // A = weights, B = voxels: D[co][voxel] -- a lane owns voxel (lane & 31) and channels 8 g + 4 (lane >> 5) + c
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[r], av[r], acc, 0, 0, 0);
     }
   }
 
-  const int co = cob * 32 + li;
-  const bool co_ok = co < Cout;
-  const float bv = (bias && co_ok) ? bias[co] : 0.f;
+  // epilogue: 4 dwordx4 stores per lane (the lane's voxel, 4 x 4 consecutive channels) instead of 16 dword stores --
+  // at the top level this kernel is HBM-bound and the store INSTRUCTION rate was a third of its time
   float s[2] = {0.f, 0.f};
-  // two passes: every store reads its own accumulator register (no shared temporary -> no vmcnt wait per store)
-  int ooff[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int idx = wave * 32 + k2_row(r, lh);
+  {
+    const int idx = wave * 32 + li;
     const int vo = idx < MT ? voff[idx] : -1;
-    const bool ok = vo >= 0 && co_ok;
-    ooff[r] = ok ? vo * Cout + co : -1;
-    acc[r] += bv;
-    const float val = ok ? acc[r] : 0.f;
-    s[0] += val;
-    s[1] += val * val;
-  }
+    const int co0 = cob * 32 + 4 * lh;
 #pragma unroll
-  for (int r = 0; r < 16; ++r)
-    if (ooff[r] >= 0) y[(i64)ooff[r]] = acc[r];
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int co = co0 + 8 * g4;
+      if (vo >= 0 && co < Cout) {   // Cout % 4 == 0 (host-checked)
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + co);
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[c] = acc[4 * g4 + c] + bv[c];
+          s[0] += v[c];
+          s[1] += v[c] * v[c];
+        }
+        *reinterpret_cast<f32x4*>(y + ((i64)vo * Cout + co)) = v;
+      }
+    }
+  }
   if (stats) {
     __syncthreads();
     block_sum_256<2>(s, xs);
@@ -195,7 +220,8 @@ extern "C" int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp, const
                                           int Do, int Ho, int Wo, int Cin, int Cout, void* stream) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k2s2_mfma_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && Do > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k2s2_mfma_fwd: bad dims");
-  SEG3D_REQUIRE((Cin % 4) == 0, "seg3d_conv3d_k2s2_mfma_fwd: Cin must be a multiple of 4 (got %d)", Cin);
+  SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
+                "seg3d_conv3d_k2s2_mfma_fwd: Cin and Cout must be multiples of 4 (got %d, %d)", Cin, Cout);
   SEG3D_REQUIRE((i64)N * Do * Ho * Wo * 8 * Cin < (1ll << 31) && (i64)N * Do * Ho * Wo * Cout < (1ll << 31),
                 "seg3d_conv3d_k2s2_mfma_fwd: tensor exceeds 2^31 elements");
   K2Tile t = k2_pick_tile(Do, Ho, Wo);
@@ -229,20 +255,23 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const float* 
   const int CIB = (Cin + 7) >> 3;
   const int cob = blockIdx.y;
   int b = blockIdx.x;
-  const int tix = b % ntx; b /= ntx;
-  const int tiy = b % nty; b /= nty;
-  const int tiz = b % ntz;
-  const int n = b / ntz;
+  int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
+  const int tix = b - qd * ntx; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)nty);
+  const int tiy = b - qd * nty; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)ntz);
+  const int tiz = b - qd * ntz;
+  const int n = qd;
   const int z0 = tiz * TZ, y0 = tiy * TY, x0 = tix * TX;
 
   // one staged float4 per thread: voxel tid >> 1, half tid & 1
   const int sv = tid >> 1, hh = tid & 1;
   int goff = -1;
   if (sv < MT) {
-    const int tx = sv % TX;
-    const int t = sv / TX;
-    const int ty = t % TY;
-    const int tz = t / TY;
+    const int t = seg3d_fdiv(sv, 1.0f / (float)TX);
+    const int tx = sv - t * TX;
+    const int tz = seg3d_fdiv(t, 1.0f / (float)TY);
+    const int ty = t - tz * TY;
     const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
     if (gz < Di && gy < Hi && gx < Wi) {
       goff = (((n * Di + gz) * Hi + gy) * Wi + gx) * Cin + hh * 4;
@@ -259,56 +288,94 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const float* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  // register prefetch of the next chunk (one float4 of x + two of weights per thread) behind the 32 MFMAs of this one
+  f32x4 xst, wst[2];
+  auto load_chunk = [&](int cib) {
+    const bool ok = goff >= 0 && cib * 8 + hh * 4 < Cin;
+    xst = *reinterpret_cast<const f32x4*>(x + (ok ? (i64)goff + cib * 8 : (i64)0));
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * K2_W_CHUNK);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) wst[k] = wsrc[tid + k * 256];
+  };
+  load_chunk(0);
   for (int cib = 0; cib < CIB; ++cib) {
     __syncthreads();
     if (sv < MT) {
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (goff >= 0 && cib * 8 + hh * 4 < Cin) val = *reinterpret_cast<const f32x4*>(x + (i64)goff + cib * 8);
-      *reinterpret_cast<f32x4*>(xs + (hh * MT + sv) * 4) = val;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(xs + (hh * MT + sv) * 4) = (goff >= 0 && cib * 8 + hh * 4 < Cin) ? xst : zero;
     }
     {
-      const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * K2_W_CHUNK);
       f32x4* wdst = reinterpret_cast<f32x4*>(ws);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) wdst[tid + k * 256] = wsrc[tid + k * 256];
+      for (int k = 0; k < 2; ++k) wdst[tid + k * 256] = wst[k];
     }
     __syncthreads();
+    if (cib + 1 < CIB) load_chunk(cib + 1);
     f32x4 av = {0.f, 0.f, 0.f, 0.f};
     if (wave * 32 + li < MT) av = *reinterpret_cast<const f32x4*>(xs + abase);
 #pragma unroll
     for (int tap = 0; tap < 8; ++tap) {
       const f32x4 bw = *reinterpret_cast<const f32x4*>(ws + tap * 256 + bbase);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bw[r], acc[tap], 0, 0, 0);
+      for (int r = 0; r < 4; ++r) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[r], av[r], acc[tap], 0, 0, 0);
     }
   }
 
-  const int co = cob * 32 + li;
-  const bool co_ok = co < Cout;
-  const float bv = (bias && co_ok) ? bias[co] : 0.f;
+  // epilogue (operands swapped: D[co][voxel]): per tap 4 dwordx4 stores of the lane's voxel, 32 per lane instead of
+  // 128 dword stores.  Bias first, stores last, no load in between (stores count in vmcnt on gfx9).
   float s[2] = {0.f, 0.f};
-  int ob[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int idx = wave * 32 + k2_row(r, lh);
+  {
+    const int idx = wave * 32 + li;
     const int o = idx < MT ? obase[idx] : -1;
-    const bool ok = o >= 0 && co_ok;
-    ob[r] = ok ? o : -1;
+    const int co0 = cob * 32 + 4 * lh;
+    f32x4 bv[4];
 #pragma unroll
-    for (int tap = 0; tap < 8; ++tap) {
-      acc[tap][r] += bv;
-      const float val = ok ? acc[tap][r] : 0.f;
-      s[0] += val;
-      s[1] += val * val;
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int co = co0 + 8 * g4;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      bv[g4] = zero;
+      if (bias && co < Cout) bv[g4] = *reinterpret_cast<const f32x4*>(bias + co);
     }
-  }
+    const int ng = (Cout - cob * 32 + 7) / 8 < 4 ? (Cout - cob * 32 + 7) / 8 : 4;   // uniform; Cout % 8 == 0 fast path
+    if ((Cout & 7) == 0) {
+      if (o >= 0) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    if (ob[r] >= 0) {
+        for (int tap = 0; tap < 8; ++tap) {
+          const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
+          float* dst = y + ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co0;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            if (g4 < ng) {
+              f32x4 v;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                v[c] = acc[tap][4 * g4 + c] + bv[g4][c];
+                s[0] += v[c];
+                s[1] += v[c] * v[c];
+              }
+              *reinterpret_cast<f32x4*>(dst + 8 * g4) = v;
+            }
+          }
+        }
+      }
+    } else {
 #pragma unroll
       for (int tap = 0; tap < 8; ++tap) {
         const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
-        y[((i64)ob[r] + (kz * Ho + ky) * Wo + kx) * Cout + co] = acc[tap][r];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int co = co0 + 8 * g4;
+          if (o >= 0 && co < Cout) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] = acc[tap][4 * g4 + c] + bv[g4][c];
+              s[0] += v[c];
+              s[1] += v[c] * v[c];
+            }
+            *reinterpret_cast<f32x4*>(y + ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co) = v;
+          }
+        }
       }
     }
   }
@@ -335,7 +402,8 @@ extern "C" int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp, cons
                                            int N, int Di, int Hi, int Wi, int Cin, int Cout, void* stream) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_convT3d_k2s2_mfma_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && Di > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "seg3d_convT3d_k2s2_mfma_fwd: bad dims");
-  SEG3D_REQUIRE((Cin % 4) == 0, "seg3d_convT3d_k2s2_mfma_fwd: Cin must be a multiple of 4 (got %d)", Cin);
+  SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
+                "seg3d_convT3d_k2s2_mfma_fwd: Cin and Cout must be multiples of 4 (got %d, %d)", Cin, Cout);
   SEG3D_REQUIRE((i64)N * Di * Hi * Wi * 8 * Cout < (1ll << 31) && (i64)N * Di * Hi * Wi * Cin < (1ll << 31),
                 "seg3d_convT3d_k2s2_mfma_fwd: tensor exceeds 2^31 elements");
   K2Tile t = k2_pick_tile(Di, Hi, Wi);
@@ -392,14 +460,46 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
   // keeps the memory system busy
   constexpr int PE = (K2W_NV * 8) / 256, QE = (K2W_MT * 8) / 256;
   f32x4 pst[PE], qst[QE];
+  unsigned okmask = 0;  // zero-select deferred to store_tile: a select right at the load would serialise the loads
+  // tile-invariant part of every entry's address (tile dims are compile-time constants: shifts and masks only); a
+  // tile inside the volume adds its origin to these -- two instructions per load instead of ~70 of index arithmetic,
+  // which at 64 MFMAs per tile and wave decided the kernel's speed
+  int prel[PE], qrel[QE];
+#pragma unroll
+  for (int e = 0; e < PE; ++e) {
+    const int v = (tid + e * 256) >> 3;
+    const int hx = v % K2W_HX, hy = (v / K2W_HX) % K2W_HY, hz = v / (K2W_HX * K2W_HY);
+    prel[e] = ((hz * Hp + hy) * Wp + hx) * CA + a0 + 4 * q;
+  }
+#pragma unroll
+  for (int e = 0; e < QE; ++e) {
+    const int v = (tid + e * 256) >> 3;
+    const int tx = v % K2W_TX, ty = (v / K2W_TX) % K2W_TY, tz = v / (K2W_TX * K2W_TY);
+    qrel[e] = ((tz * Hq + ty) * Wq + tx) * CB + b0 + 4 * q;
+  }
+  const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz;
   auto load_tile = [&](int tile) {
     int b = tile;
-    const int tix = b % ntx; b /= ntx;
-    const int tiy = b % nty; b /= nty;
-    const int tiz = b % ntz;
-    const int n = b / ntz;
+    int qd = seg3d_fdiv(b, rNTX);
+    const int tix = b - qd * ntx; b = qd;
+    qd = seg3d_fdiv(b, rNTY);
+    const int tiy = b - qd * nty; b = qd;
+    qd = seg3d_fdiv(b, rNTZ);
+    const int tiz = b - qd * ntz;
+    const int n = qd;
     const int z0 = tiz * K2W_TZ, y0 = tiy * K2W_TY, x0 = tix * K2W_TX;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (z0 + K2W_TZ <= Dq && y0 + K2W_TY <= Hq && x0 + K2W_TX <= Wq) {  // whole tile inside the volume
+      const float* pbase = P + ((((i64)n * Dp + 2 * z0) * Hp + 2 * y0) * Wp + 2 * x0) * CA;
+      const float* qbase = Q + ((((i64)n * Dq + z0) * Hq + y0) * Wq + x0) * CB;
+      const unsigned pm = pq_ok ? (1u << PE) - 1u : 0u, qm = qq_ok ? ((1u << QE) - 1u) << PE : 0u;
+#pragma unroll
+      for (int e = 0; e < PE; ++e) pst[e] = *reinterpret_cast<const f32x4*>(pq_ok ? pbase + prel[e] : P);
+#pragma unroll
+      for (int e = 0; e < QE; ++e) qst[e] = *reinterpret_cast<const f32x4*>(qq_ok ? qbase + qrel[e] : Q);
+      okmask = pm | qm;
+      return;
+    }
+    okmask = 0;
 #pragma unroll
     for (int e = 0; e < PE; ++e) {
       const int v = (tid + e * 256) >> 3;
@@ -409,9 +509,9 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
       const int hz = t / K2W_HY;
       const int gz = 2 * z0 + hz, gy = 2 * y0 + hy, gx = 2 * x0 + hx;
       const bool ok = pq_ok && gz < Dp && gy < Hp && gx < Wp;
-      const f32x4 val = *reinterpret_cast<const f32x4*>(
+      pst[e] = *reinterpret_cast<const f32x4*>(
           P + (ok ? ((((i64)n * Dp + gz) * Hp + gy) * Wp + gx) * CA + a0 + 4 * q : (i64)0));
-      pst[e] = ok ? val : zero;
+      okmask |= (ok ? 1u : 0u) << e;
     }
 #pragma unroll
     for (int e = 0; e < QE; ++e) {
@@ -422,16 +522,19 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
       const int tz = t / K2W_TY;
       const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
       const bool ok = qq_ok && gz < Dq && gy < Hq && gx < Wq;
-      const f32x4 val = *reinterpret_cast<const f32x4*>(
+      qst[e] = *reinterpret_cast<const f32x4*>(
           Q + (ok ? ((((i64)n * Dq + gz) * Hq + gy) * Wq + gx) * CB + b0 + 4 * q : (i64)0));
-      qst[e] = ok ? val : zero;
+      okmask |= (ok ? 1u : 0u) << (PE + e);
     }
   };
   auto store_tile = [&]() {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < PE; ++e) *reinterpret_cast<f32x4*>(ps + ((tid + e * 256) >> 3) * 32 + 4 * q) = pst[e];
+    for (int e = 0; e < PE; ++e)
+      *reinterpret_cast<f32x4*>(ps + ((tid + e * 256) >> 3) * 32 + 4 * q) = ((okmask >> e) & 1u) ? pst[e] : zero;
 #pragma unroll
-    for (int e = 0; e < QE; ++e) *reinterpret_cast<f32x4*>(qs + ((tid + e * 256) >> 3) * 32 + 4 * q) = qst[e];
+    for (int e = 0; e < QE; ++e)
+      *reinterpret_cast<f32x4*>(qs + ((tid + e * 256) >> 3) * 32 + 4 * q) = ((okmask >> (PE + e)) & 1u) ? qst[e] : zero;
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

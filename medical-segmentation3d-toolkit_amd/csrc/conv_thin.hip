@@ -446,6 +446,8 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
   constexpr int TE = (TH_NV * CT + 255) / 256, FE = (TH_MT * 8) / 256;
   float tst[TE];
   f32x4 fst[FE];
+  static_assert(TE + FE <= 32, "okmask is 32 bits");
+  unsigned okmask = 0;  // zero-select deferred to store_tile: a select right at the load would serialise the loads
   auto load_tile = [&](int tile) {
     int b = tile;
     const int tix = b % ntx; b /= ntx;
@@ -453,6 +455,7 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
     const int tiz = b % ntz;
     const int n = b / ntz;
     const int z0 = tiz * TH_TZ, y0 = tiy * TH_TY, x0 = tix * TH_TX;
+    okmask = 0;
 #pragma unroll
     for (int k = 0; k < TE; ++k) {
       const int e = tid + k * 256;
@@ -463,10 +466,9 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
       const int hz = t / TH_HY;
       const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
       const bool ok = e < TH_NV * CT && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const float val = thin[ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * CT + a : (i64)0];
-      tst[k] = ok ? val : 0.f;
+      tst[k] = thin[ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * CT + a : (i64)0];
+      okmask |= (ok ? 1u : 0u) << k;
     }
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < FE; ++k) {
       const int v = (tid + k * 256) >> 3;
@@ -476,19 +478,21 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
       const int tz = t / TH_TY;
       const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
       const bool ok = fq_ok && gz < D && gy < H && gx < W;
-      const f32x4 val = *reinterpret_cast<const f32x4*>(
+      fst[k] = *reinterpret_cast<const f32x4*>(
           fat + (ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * CF + cf0 + 4 * q : (i64)0));
-      fst[k] = ok ? val : zero;
+      okmask |= (ok ? 1u : 0u) << (TE + k);
     }
   };
   auto store_tile = [&]() {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < TE; ++k) {
       const int e = tid + k * 256;
-      if (e < TH_NV * CT) ts[e] = tst[k];
+      if (e < TH_NV * CT) ts[e] = ((okmask >> k) & 1u) ? tst[k] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < FE; ++k) *reinterpret_cast<f32x4*>(fs + ((tid + k * 256) >> 3) * 32 + 4 * q) = fst[k];
+    for (int k = 0; k < FE; ++k)
+      *reinterpret_cast<f32x4*>(fs + ((tid + k * 256) >> 3) * 32 + 4 * q) = ((okmask >> (TE + k)) & 1u) ? fst[k] : zero;
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

@@ -275,7 +275,7 @@ def conv_forward(xn, w, bias, kind, want_stats=False):
         if D % 2 or H % 2 or W_ % 2:
             raise ValueError('Conv3d k2 s2 needs even spatial dims, got {}'.format((D, H, W_)))
         y = _empty((N, D // 2, H // 2, W_ // 2, Cout), xn)
-        if _use_mfma(Cin, Cout):
+        if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             return _k2_gather(xn, w, bias, y, Cin, Cout, 8, Cin * 8, want_stats)
         wp = _pack_tapmajor(w, Cin, Cout, 8, 8, Cin * 8)
         E.call('seg3d_conv3d_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout, 2, 2,
@@ -293,7 +293,7 @@ def conv_forward(xn, w, bias, kind, want_stats=False):
         Cout = w.shape[1]
         _check_w(w, (Cin, Cout, 2, 2, 2), kind)
         y = _empty((N, 2 * D, 2 * H, 2 * W_, Cout), xn)
-        if _use_mfma(Cin, Cout):
+        if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             return _k2_scatter(xn, w, bias, y, Cin, Cout, Cout * 8, 8, want_stats)
         wp = _pack_tapmajor(w, Cin, Cout, 8, Cout * 8, 8)
         E.call('seg3d_convT3d_k2s2_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout,
@@ -324,7 +324,7 @@ def conv_dgrad(dyn, w, kind, addend=None):
         Cout, Cin = w.shape[0], w.shape[1]
         # dx[2v + t][ci] = sum_co dy[v][co] w[co][ci][t]  == transposed conv of dy
         dx = _empty((N, 2 * D, 2 * H, 2 * W_, Cin), dyn)
-        if _use_mfma(Cout, Cin):
+        if _use_mfma(Cout, Cin) and Cin % 4 == 0:
             return _k2_scatter(dyn, w, None, dx, Cout, Cin, Cin * 8, 8, False)[0]
         wp = _pack_tapmajor(w, Cout, Cin, 8, Cin * 8, 8)
         E.call('seg3d_convT3d_k2s2_fwd_direct', E.ptr(dyn), E.ptr(wp), None, E.ptr(dx), N, D, H, W_, Cout, Cin,
@@ -341,7 +341,7 @@ def conv_dgrad(dyn, w, kind, addend=None):
         Cin, Cout = w.shape[0], w.shape[1]
         # dx[i][ci] = sum_{t,co} dy[2i + t][co] w[ci][co][t]  == k2 s2 conv of dy
         dx = _empty((N, D // 2, H // 2, W_ // 2, Cin), dyn)
-        if _use_mfma(Cout, Cin):
+        if _use_mfma(Cout, Cin) and Cin % 4 == 0:
             return _k2_gather(dyn, w, None, dx, Cout, Cin, 8, Cout * 8, False)[0]
         wp = _pack_tapmajor(w, Cout, Cin, 8, 8, Cout * 8)
         E.call('seg3d_conv3d_fwd_direct', E.ptr(dyn), E.ptr(wp), None, E.ptr(dx), N, D, H, W_, Cout, Cin, 2, 2,

@@ -166,6 +166,12 @@ int seg3d_patch_scatter_accumulate(const float* probs, const int* starts_xyz, co
                                    long long max_box_voxels, void* stream);
 int seg3d_finalize_argmax(float* acc, const float* count, signed char* mask, int C, long long voxels, void* stream);
 
+/* ---- evaluation metric: utils/metrics.py:5-37 cal_dsc, core/seg_eval.py:8-57 ---------------
+ * counts[3k..3k+2] += (area_gt, area_seg, intersection) of labels_host[k] over two label volumes of n elements;
+ * the caller zeroes counts first.  dtype: 0 int8, 1 uint8, 2 int16, 3 int32, 4 float32.  1..16 labels per call. */
+int seg3d_label_overlap_counts(const void* gt, const void* seg, int dtype, long long n, const int* labels_host, int nlabels,
+                               unsigned long long* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

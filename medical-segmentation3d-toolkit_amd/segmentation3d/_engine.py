@@ -28,6 +28,7 @@ _SIGNATURES = {
     'seg3d_pack_weights_mfma': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p]),
     'seg3d_packed_mfma_floats': (_c_ll, [_c_int, _c_int, _c_int]),
     'seg3d_pack_job_blocks': (_c_ll, [_c_int, _c_int, _c_int]),
+    'seg3d_label_overlap_counts': (_c_int, [_c_p, _c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p]),
     'seg3d_pack_weights_mfma_multi': (_c_int, [_c_p, _c_int, _c_ll, _c_p]),
     'seg3d_conv3d_fwd_direct': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p]),
     'seg3d_convT3d_k2s2_fwd_direct': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 6 + [_c_p]),
@@ -135,7 +136,7 @@ def require_device(*tensors):
             raise Seg3dEngineError(
                 'segmentation3d HIP engine needs tensors on a ROCm device (got device={}); '
                 'there is no CPU path in this package'.format(t.device))
-        if t.dtype != torch.float32 and t.dtype not in (torch.int32, torch.int8, torch.float64):
+        if t.dtype not in (torch.float32, torch.int32, torch.int8, torch.float64, torch.uint8, torch.int16, torch.int64):
             raise TypeError('unsupported dtype {}'.format(t.dtype))
 
 

@@ -70,3 +70,20 @@ def state_dict_like(shapes, seed, gain_sqrt2=True):
         else:
             out[name] = normal(seed, name, shape, std=0.1)
     return out
+
+
+def metric_label_cases():
+    """(name, gt, seg, labels, threshold): label volumes from the deterministic generator (shared with the tests)"""
+    cases = []
+    g = labels(301, 'metric/gt', (40, 48, 56), 4).astype(np.int8)
+    s_ = labels(302, 'metric/seg', (40, 48, 56), 4).astype(np.int8)
+    mix = np.where(uniform(303, 'metric/mix', (40, 48, 56)) < 0.7, g, s_).astype(np.int8)   # 70 % agreement
+    cases.append(('agree70_int8', g, mix, [0, 1, 2, 3, 7], 1000))
+    cases.append(('threshold_edges', g, mix, [1, 2], int((g == 1).sum())))          # area_gt == threshold -> TP side
+    cases.append(('threshold_above', g, mix, [1, 2], int((g == 1).sum()) + 1))      # area_gt < threshold
+    only_seg = np.where(g == 3, 0, g).astype(np.int8)
+    cases.append(('label_missing_in_gt', only_seg, mix, [3], 50))                    # FP
+    cases.append(('label_missing_in_seg', mix, only_seg, [3], 50))                   # FN
+    cases.append(('float_labels', g.astype(np.float32), mix.astype(np.float32), [0, 2], 10))
+    cases.append(('int16_odd_size', g[:37, :41, :53].astype(np.int16), mix[:37, :41, :53].astype(np.int16), [0, 1, 2, 3], 10))
+    return cases

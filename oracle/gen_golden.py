@@ -210,6 +210,29 @@ def gen_partitions():
         json.dump(out, f)
 
 
+def gen_metrics():
+    src = open(os.path.join(REF, 'segmentation3d', 'utils', 'metrics.py')).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'cal_dsc'][0]
+
+    class _NoSitk(object):      # the function only asks `isinstance(x, sitk.Image)`; numpy arrays never are
+        class Image(object):
+            pass
+    ns = {'np': np, 'sitk': _NoSitk}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'metrics.py', 'exec'), ns)  # runs in memory only
+    ref_fn = ns['cal_dsc']
+    out = {}
+    for name, gt, seg, labels, threshold in detgen.metric_label_cases():
+        res = []
+        for l in labels:
+            dsc, typ = ref_fn(gt, seg, l, threshold)
+            res.append([int(l), float(dsc), typ])
+        out[name] = {'threshold': int(threshold), 'results': res}
+        print('metric', name, res)
+    with open(os.path.join(OUT, 'metrics.json'), 'w') as f:
+        json.dump(out, f)
+
+
 def gen_shapes():
     from segmentation3d.network import vnet, vbnet
     out = {}
@@ -226,7 +249,7 @@ def gen_shapes():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['blocks', 'nets', 'losses', 'partitions', 'shapes']
+    which = sys.argv[1:] or ['blocks', 'nets', 'losses', 'partitions', 'shapes', 'metrics']
     if 'blocks' in which:
         gen_blocks()
     if 'nets' in which:
@@ -237,3 +260,5 @@ if __name__ == '__main__':
         gen_partitions()
     if 'shapes' in which:
         gen_shapes()
+    if 'metrics' in which:
+        gen_metrics()

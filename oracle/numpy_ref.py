@@ -130,3 +130,24 @@ def sliding_window_inference(volume, net_fn, num_classes, spacing, partition_siz
         accumulate_patch(acc, count, s, e, p[0])
     probs, mask = finalize(acc, count)
     return probs, mask, (starts, ends)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# evaluation metric
+# ---------------------------------------------------------------------------------------------------------------------
+def cal_dsc(gt, seg, label, threshold):
+    """restatement of utils/metrics.py:5-37: (dice, type) with the TN / FP / FN / TP typing by voxel-count threshold"""
+    g, s = (np.asarray(gt) == label), (np.asarray(seg) == label)
+    area_gt, area_seg = int(g.sum()), int(s.sum())
+    if area_gt < threshold and area_seg < threshold:
+        return 1.0, 'TN'
+    if area_gt < threshold and area_seg >= threshold:
+        return 0.0, 'FP'
+    if area_gt >= threshold and area_seg < threshold:
+        return 0.0, 'FN'
+    return 2 * int((g & s).sum()) / (area_gt + area_seg), 'TP'
+
+
+def label_overlap_counts(gt, seg, labels):
+    g, s = np.asarray(gt), np.asarray(seg)
+    return [(int((g == l).sum()), int((s == l).sum()), int(((g == l) & (s == l)).sum())) for l in labels]

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
         bv[q][g4] = val;
       }
 
+    f32x4 ad[MA][NB][4];  // fused addend values of this item (loaded at the start of its last chunk)
     for (int cib = 0; cib < CIB; ++cib) {
       float* cur = lds + parity * BUF;
       float* nxt = lds + (parity ^ 1) * BUF;
@@ -449,6 +450,24 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
       const bool do_dma = !last || more_items;
       const float* wnext;
       if (last) {
+        if (addend) {
+          // fused addend (dgrad of a residual block's first conv): fetched NOW, before this chunk's DMAs are issued,
+          // so the loads complete behind the MFMAs of the last chunk instead of stalling the epilogue
+#pragma unroll
+          for (int m = 0; m < MA; ++m) {
+            const int vp = vpos[m];
+            const int gz = cur_z0 + ((vp >> 20) & 1023), gy = cur_y0 + ((vp >> 10) & 1023), gx = cur_x0 + (vp & 1023);
+            const int vom = (vp >= 0 && gz < D && gy < H && gx < W) ? ((cur_n * D + gz) * H + gy) * W + gx : -1;
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+#pragma unroll
+              for (int g4 = 0; g4 < 4; ++g4) {
+                const int co = cur_cog * NB * 32 + 4 * lh + 32 * q + 8 * g4;
+                const bool ok = vom >= 0 && co < Cout;
+                ad[m][q][g4] = *reinterpret_cast<const f32x4*>(addend + (ok ? (i64)vom * Cout + co : (i64)0));
+              }
+          }
+        }
         if (more_items) setup_item(next_item);  // DMA sources now belong to the next item
         wnext = wp + (i64)(it_cog * NB) * CIB * SEG3D_W_CHUNK;
       } else {
@@ -515,17 +534,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
     }
     const int co_lane = cur_cog * NB * 32 + 4 * lh;  // + 32 q + 8 g4
     if (addend) {
-      f32x4 ad[MA][NB][4];
-#pragma unroll
-      for (int m = 0; m < MA; ++m)
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int co = co_lane + 32 * q + 8 * g4;
-            const bool ok = vo[m] >= 0 && co < Cout;
-            ad[m][q][g4] = *reinterpret_cast<const f32x4*>(addend + (ok ? (i64)vo[m] * Cout + co : (i64)0));
-          }
 #pragma unroll
       for (int m = 0; m < MA; ++m)
 #pragma unroll
@@ -1044,18 +1052,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
 //   its address arithmetic done right there in the shadow of the MFMAs (no integer division, no staging registers,
 //   no ds_write pass); one barrier per tile.  The x tile is staged once for NB*32 output channels.
 // ----------------------------------------------------------------------------------------------------------------
-#define SEG3D_WG2_XP (SEG3D_WG_NV / 8)   // 45 DMA pieces: 8 voxels x 32 channels each
-#define SEG3D_WG2_YP (SEG3D_WG_MT / 8)   // 16 DMA pieces per 32-channel block of dy
-
-template <int NB>
+// Tile shapes: 4x4x8 (default), and 4x4x4 / 2x6x6 for levels whose extent they divide where 4x4x8 would leave half-empty
+// tiles (12^3, 6^3): every tile then takes the fast DMA path and no MFMA row is wasted.
+template <int NB, int TZ, int TY, int TX>
 __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                     float* __restrict__ part, int N, int D, int H, int W,
                                                                     int Cin, int Cout, int ntz, int nty, int ntx, int ntiles,
                                                                     int slabs, int COG) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int XS = SEG3D_WG_NV * 32;                 // floats
-  constexpr int BUF = XS + NB * SEG3D_WG_MT * 32;
-  constexpr int NP = SEG3D_WG2_XP + NB * SEG3D_WG2_YP;  // pieces per tile
+  constexpr int HY = TY + 2, HX = TX + 2;
+  constexpr int NVH = (TZ + 2) * HY * HX;              // halo voxels of the x tile
+  constexpr int MTV = TZ * TY * TX;                    // voxels of the dy tile
+  constexpr int XPC = NVH / 8, YPC = MTV / 8;          // 1-KiB DMA pieces (8 voxels x 32 channels) of x / of one dy block
+  static_assert(NVH % 8 == 0 && MTV % 8 == 0 && TX % 2 == 0, "tile shape");
+  constexpr int XS = NVH * 32;                         // floats
+  constexpr int BUF = XS + NB * MTV * 32;
+  constexpr int NP = XPC + NB * YPC;  // pieces per tile
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1073,7 +1085,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
     int tap = wave * 7 + j;
     if (tap > 26) tap = 26;  // idle slot of wave 3 recomputes tap 26 into a discarded accumulator
     const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-    tapoff[j] = ((kz * SEG3D_WG_HY + ky) * SEG3D_WG_HX + kx) * 32;
+    tapoff[j] = ((kz * HY + ky) * HX + kx) * 32;
   }
   f32x16 acc[7][NB];
 #pragma unroll
@@ -1097,25 +1109,25 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
     q = fdiv(b, rNTZ);
     const int tiz = b - q * ntz;
     tn = q;
-    tz0 = tiz * SEG3D_WG_TZ, ty0 = tiy * SEG3D_WG_TY, tx0 = tix * SEG3D_WG_TX;
+    tz0 = tiz * TZ, ty0 = tiy * TY, tx0 = tix * TX;
   };
   auto issue_piece = [&](int g, float* buf) {
     const int p = wave + 4 * g;
-    if (p < SEG3D_WG2_XP) {
-      const int v = p * 8 + lv;                                   // halo voxel 0..359: (hz, hy, hx) in 6 x 6 x 10
-      const int t = fdiv(v, 1.0f / (float)SEG3D_WG_HX);
-      const int hx = v - t * SEG3D_WG_HX;
-      const int hz = fdiv(t, 1.0f / (float)SEG3D_WG_HY);
-      const int hy = t - hz * SEG3D_WG_HY;
+    if (p < XPC) {
+      const int v = p * 8 + lv;                                   // halo voxel: (hz, hy, hx)
+      const int t = fdiv(v, 1.0f / (float)HX);
+      const int hx = v - t * HX;
+      const int hz = fdiv(t, 1.0f / (float)HY);
+      const int hy = t - hz * HY;
       const int gz = tz0 + hz - 1, gy = ty0 + hy - 1, gx = tx0 + hx - 1;
       const bool ok = ci0 + 4 * lq < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
       const float* src = ok ? x + ((i64)(((tn * D + gz) * H + gy) * W + gx) * Cin + ci0 + 4 * lq) : seg3d_zero16;
       seg3d_glds16(src, buf + p * 256);
     } else if (p < NP) {
-      const int pp = p - SEG3D_WG2_XP;
-      const int nb = pp / SEG3D_WG2_YP;
-      const int v = (pp - nb * SEG3D_WG2_YP) * 8 + lv;            // tile voxel 0..127: (tz, ty, tx) in 4 x 4 x 8
-      const int gz = tz0 + (v >> 5), gy = ty0 + ((v >> 3) & 3), gx = tx0 + (v & 7);
+      const int pp = p - XPC;
+      const int nb = pp / YPC;
+      const int v = (pp - nb * YPC) * 8 + lv;            // tile voxel: (tz, ty, tx)
+      const int gz = tz0 + v / (TX * TY), gy = ty0 + (v / TX) % TY, gx = tx0 + v % TX;
       const int co = co0 + nb * 32 + 4 * lq;
       const bool ok = co < Cout && gz < D && gy < H && gx < W;
       const float* src = ok ? dy + ((i64)(((tn * D + gz) * H + gy) * W + gx) * Cout + co) : seg3d_zero16;
@@ -1133,28 +1145,28 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
     const int p = wave + 4 * g;
     prel[g] = 0;
     pflag[g] = -1;
-    if (p < SEG3D_WG2_XP) {
+    if (p < XPC) {
       const int v = p * 8 + lv;
-      const int t = fdiv(v, 1.0f / (float)SEG3D_WG_HX);
-      const int hx = v - t * SEG3D_WG_HX;
-      const int hz = fdiv(t, 1.0f / (float)SEG3D_WG_HY);
-      const int hy = t - hz * SEG3D_WG_HY;
+      const int t = fdiv(v, 1.0f / (float)HX);
+      const int hx = v - t * HX;
+      const int hz = fdiv(t, 1.0f / (float)HY);
+      const int hy = t - hz * HY;
       prel[g] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + ci0 + 4 * lq;
-      pflag[g] = (hz == 0 ? 1 : 0) | (hz == SEG3D_WG_TZ + 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == SEG3D_WG_TY + 1 ? 8 : 0) |
-                 (hx == 0 ? 16 : 0) | (hx == SEG3D_WG_TX + 1 ? 32 : 0) | (ci0 + 4 * lq < Cin ? 0 : 64);
+      pflag[g] = (hz == 0 ? 1 : 0) | (hz == TZ + 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == TY + 1 ? 8 : 0) |
+                 (hx == 0 ? 16 : 0) | (hx == TX + 1 ? 32 : 0) | (ci0 + 4 * lq < Cin ? 0 : 64);
     } else if (p < NP) {
-      const int pp = p - SEG3D_WG2_XP;
-      const int nb = pp / SEG3D_WG2_YP;
-      const int v = (pp - nb * SEG3D_WG2_YP) * 8 + lv;
+      const int pp = p - XPC;
+      const int nb = pp / YPC;
+      const int v = (pp - nb * YPC) * 8 + lv;
       const int co = co0 + nb * 32 + 4 * lq;
-      prel[g] = (((v >> 5) * H + ((v >> 3) & 3)) * W + (v & 7)) * Cout + co;
+      prel[g] = (((v / (TX * TY)) * H + (v / TX) % TY) * W + v % TX) * Cout + co;
       pflag[g] = co < Cout ? 0 : 64;
     }
   }
   auto issue_piece_fast = [&](int g, float* buf, const float* xbase, const float* ybase, int faces) {
     const int p = wave + 4 * g;
     if (p < NP) {
-      const float* base = p < SEG3D_WG2_XP ? xbase : ybase;  // uniform
+      const float* base = p < XPC ? xbase : ybase;  // uniform
       const float* src = (pflag[g] & faces) ? seg3d_zero16 : base + prel[g];
       seg3d_glds16(src, buf + p * 256);
     }
@@ -1180,9 +1192,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
     const bool more = tile + slabs < ntiles;
     if (more) set_tile(tile + slabs);
     // the tile being fetched: inside the volume?  which of its halo faces stick out?
-    const bool regular = tz0 + SEG3D_WG_TZ <= D && ty0 + SEG3D_WG_TY <= H && tx0 + SEG3D_WG_TX <= W;
-    const int faces = 64 | (tz0 == 0 ? 1 : 0) | (tz0 + SEG3D_WG_TZ >= D ? 2 : 0) | (ty0 == 0 ? 4 : 0) |
-                      (ty0 + SEG3D_WG_TY >= H ? 8 : 0) | (tx0 == 0 ? 16 : 0) | (tx0 + SEG3D_WG_TX >= W ? 32 : 0);
+    const bool regular = tz0 + TZ <= D && ty0 + TY <= H && tx0 + TX <= W;
+    const int faces = 64 | (tz0 == 0 ? 1 : 0) | (tz0 + TZ >= D ? 2 : 0) | (ty0 == 0 ? 4 : 0) |
+                      (ty0 + TY >= H ? 8 : 0) | (tx0 == 0 ? 16 : 0) | (tx0 + TX >= W ? 32 : 0);
     const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
     const float* xbase = x + origin * Cin;
     const float* ybase = dy + origin * Cout;
@@ -1192,19 +1204,19 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
     }
     const float* xa = cur + lh * 32 + li;          // + voxel * 32 + tap offset
     const float* yb = cur + XS + lh * 32 + li;     // + nb * 4096 + voxel * 32
-    // voxel pair (2 kp, 2 kp + 1) lies in one row of the 4 x 4 x 8 tile, so the lane half only shifts by one voxel.
+    // voxel pair (2 kp, 2 kp + 1) lies in one row of the tile (TX even), so the lane half only shifts by one voxel.
     // Operands of pair kp+1 are read while pair kp is multiplied (one wave per SIMD: nothing else hides LDS latency).
     auto xoff = [](int kp) {
       const int v0 = 2 * kp;
-      return (((v0 >> 5) * SEG3D_WG_HY + ((v0 >> 3) & 3)) * SEG3D_WG_HX + (v0 & 7)) * 32;
+      return (((v0 / (TX * TY)) * HY + (v0 / TX) % TY) * HX + v0 % TX) * 32;
     };
     // two pairs ahead: the scheduler interleaves reads and MFMAs one to one, so a distance of one pair leaves a read
     // only ~2 MFMAs of cover
     float a1[7], b1[NB], a2[7], b2[NB];
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-      b1[q] = yb[q * SEG3D_WG_MT * 32];
-      b2[q] = yb[q * SEG3D_WG_MT * 32 + 2 * 32];
+      b1[q] = yb[q * MTV * 32];
+      b2[q] = yb[q * MTV * 32 + 2 * 32];
     }
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
@@ -1212,7 +1224,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
       a2[j] = xa[xoff(1) + tapoff[j]];
     }
 #pragma unroll
-    for (int kp = 0; kp < SEG3D_WG_MT / 2; ++kp) {
+    for (int kp = 0; kp < MTV / 2; ++kp) {
       float a[7], bvv[NB];
 #pragma unroll
       for (int q = 0; q < NB; ++q) {
@@ -1224,9 +1236,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
         a[j] = a1[j];
         a1[j] = a2[j];
       }
-      if (kp + 2 < SEG3D_WG_MT / 2) {
+      if (kp + 2 < MTV / 2) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) b2[q] = yb[q * SEG3D_WG_MT * 32 + (2 * kp + 4) * 32];
+        for (int q = 0; q < NB; ++q) b2[q] = yb[q * MTV * 32 + (2 * kp + 4) * 32];
 #pragma unroll
         for (int j = 0; j < 7; ++j) a2[j] = xa[xoff(kp + 2) + tapoff[j]];
       }
@@ -1309,6 +1321,7 @@ struct Seg3dWgradPlan {
   int version;  // 1: two workgroups per CU, register-staged; 2: one persistent workgroup per CU, LDS-DMA
   int nb;       // 32-channel blocks of dy per workgroup (version 2)
   int slabs;
+  int tz, ty, tx;  // spatial tile (version 2; version 1 is 4 x 4 x 8)
 };
 
 static int seg3d_wgrad_v2_enabled() {
@@ -1326,9 +1339,17 @@ static Seg3dWgradPlan seg3d_wgrad_plan(int N, int D, int H, int W, int Cin, int 
   Seg3dWgradPlan p;
   p.version = 1;
   p.nb = 1;
+  p.tz = SEG3D_WG_TZ, p.ty = SEG3D_WG_TY, p.tx = SEG3D_WG_TX;
   p.slabs = seg3d_wgrad_slabs(N, D, H, W, npairs);
   if (seg3d_wgrad_v2_enabled()) {
-    const int ntiles = N * seg3d_cdiv(D, SEG3D_WG_TZ) * seg3d_cdiv(H, SEG3D_WG_TY) * seg3d_cdiv(W, SEG3D_WG_TX);
+    // a tile shape that divides the level: no half-empty tiles, every tile on the fast DMA path
+    if (D % 4 == 0 && H % 4 == 0 && W % 8 == 0) {
+    } else if (D % 4 == 0 && H % 4 == 0 && W % 4 == 0) {
+      p.tz = 4, p.ty = 4, p.tx = 4;
+    } else if (D % 2 == 0 && H % 6 == 0 && W % 6 == 0) {
+      p.tz = 2, p.ty = 6, p.tx = 6;
+    }
+    const int ntiles = N * seg3d_cdiv(D, p.tz) * seg3d_cdiv(H, p.ty) * seg3d_cdiv(W, p.tx);
     p.version = 2;
     p.nb = (COB32 % 2 == 0) ? 2 : 1;
     {
@@ -1353,12 +1374,14 @@ extern "C" long long seg3d_conv3d_k3_mfma_wgrad_workspace_floats(int N, int D, i
   return (long long)seg3d_wgrad_plan(N, D, H, W, Cin, Cout).slabs * npairs * 27 * 1024;
 }
 
-template <int NB>
+template <int NB, int TZ, int TY, int TX>
 static int launch_wgrad2(const float* x, const float* dy, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
-                         int ntz, int nty, int ntx, int ntiles, int slabs, hipStream_t s) {
+                         int slabs, hipStream_t s) {
+  const int ntz = seg3d_cdiv(D, TZ), nty = seg3d_cdiv(H, TY), ntx = seg3d_cdiv(W, TX);
+  const int ntiles = N * ntz * nty * ntx;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad2_kernel<NB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad2_kernel<NB, TZ, TY, TX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     if (e != hipSuccess) {
       seg3d_set_error("conv3d_k3_wgrad2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1367,8 +1390,8 @@ static int launch_wgrad2(const float* x, const float* dy, float* workspace, int 
     configured = true;
   }
   const int CIB32 = (Cin + 31) / 32, COG = (Cout + 31) / 32 / NB;
-  const size_t lds = (size_t)2 * (SEG3D_WG_NV * 32 + NB * SEG3D_WG_MT * 32) * 4;
-  hipLaunchKernelGGL((conv3d_k3_wgrad2_kernel<NB>), dim3((unsigned)(slabs * CIB32 * COG)), dim3(256), lds, s, x, dy, workspace,
+  const size_t lds = (size_t)2 * ((TZ + 2) * (TY + 2) * (TX + 2) * 32 + NB * TZ * TY * TX * 32) * 4;
+  hipLaunchKernelGGL((conv3d_k3_wgrad2_kernel<NB, TZ, TY, TX>), dim3((unsigned)(slabs * CIB32 * COG)), dim3(256), lds, s, x, dy, workspace,
                      N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, COG);
   return SEG3D_OK;
 }
@@ -1390,8 +1413,11 @@ extern "C" int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float
   const int slabs = plan.slabs;
   hipStream_t s = (hipStream_t)stream;
   if (plan.version == 2) {
-    const int rc = plan.nb == 2 ? launch_wgrad2<2>(x, dy, workspace, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, s)
-                                : launch_wgrad2<1>(x, dy, workspace, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, s);
+    int rc;
+    if (plan.tx == 4) rc = launch_wgrad2<1, 4, 4, 4>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
+    else if (plan.tx == 6) rc = launch_wgrad2<1, 2, 6, 6>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
+    else if (plan.nb == 2) rc = launch_wgrad2<2, 4, 4, 8>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
+    else rc = launch_wgrad2<1, 4, 4, 8>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
     if (rc != SEG3D_OK) return rc;
   } else {
     hipLaunchKernelGGL(conv3d_k3_wgrad_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s, x, dy, workspace, N, D, H, W,

@@ -19,7 +19,9 @@ def run(kind, N, D, H, W, Cin, Cout, iters=10):
         nws = E.query('seg3d_conv3d_k3_mfma_fwd_workspace_floats', N, D, H, W, Cin, Cout)
         wsp = torch.empty(max(nws, 1), device=dev)
         st = torch.empty(N, cnt, 2, device=dev)
-        fn = lambda: E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(x), E.ptr(wp), E.ptr(b), None, E.ptr(y), E.ptr(st), E.ptr(wsp), N, D, H, W, Cin, Cout, E.stream_ptr())
+        ad = torch.randn(N, D, H, W, Cout, device=dev) if '--addend' in sys.argv else None
+        nostats = '--nostats' in sys.argv
+        fn = lambda: E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(x), E.ptr(wp), None if nostats else E.ptr(b), E.ptr(ad), E.ptr(y), None if nostats else E.ptr(st), E.ptr(wsp), N, D, H, W, Cin, Cout, E.stream_ptr())
     else:
         ws = torch.empty(E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W, Cin, Cout), device=dev)
         dw = torch.empty(Cout, Cin, 3, 3, 3, device=dev)

@@ -9,6 +9,7 @@ Fused unit (the reference's `ConvGnRelu3`, network/module/conv_gn_relu3.py:4-20,
 InputBlock/DownBlock/UpBlock/OutputBlock):   out = act( GN_1(conv(x) + b) [+ residual] )
 """
 import ctypes
+import os
 
 import torch
 
@@ -459,6 +460,57 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# weight gradients on a side stream
+# ------------------------------------------------------------------------------------------------------------------
+# In backward the data-gradient chain (GroupNorm backward -> dgrad -> GroupNorm backward -> ...) is the critical path;
+# a weight gradient only feeds the optimizer.  When its destination is a gradient sink (no tensor goes back to
+# autograd) it is enqueued on a second HIP stream: the MFMA-bound weight-gradient kernel then shares the chip with the
+# HBM-bound GroupNorm / stride-2 / thin kernels of the main stream instead of running in series with them.
+# The main stream joins the side stream when backward finishes (engine callback); consumers that read gradients DURING
+# backward (the bucketed all-reduce, core/ddp.py) call wgrad_stream_join() themselves.
+WGRAD_SIDE_STREAM = os.environ.get('SEG3D_WGRAD_SIDE_STREAM', '1') != '0'
+_SIDE_STREAMS = {}
+_JOIN_QUEUED_FOR = [-1]   # id of the backward pass (graph task) whose end-of-backward join is already queued
+
+
+def _side_stream(device):
+    st = _SIDE_STREAMS.get(device.index)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[device.index] = st
+    return st
+
+
+def wgrad_stream_join():
+    """make the current stream wait for every weight gradient issued on the side stream so far"""
+    cur = torch.cuda.current_stream()
+    st = _SIDE_STREAMS.get(cur.device.index)
+    if st is not None:
+        cur.wait_stream(st)
+
+
+def _join_after_backward():
+    wgrad_stream_join()
+
+
+def _wgrad_to_sink(xn, dyn, w_shape, kind, sink_view):
+    """conv_wgrad accumulated into `sink_view`, on the side stream when enabled"""
+    if not WGRAD_SIDE_STREAM or torch.cuda.is_current_stream_capturing():
+        conv_wgrad(xn, dyn, w_shape, kind, out=sink_view)
+        return
+    side = _side_stream(dyn.device)
+    side.wait_stream(torch.cuda.current_stream())       # x and dy are complete on the main stream
+    with torch.cuda.stream(side):
+        conv_wgrad(xn, dyn, w_shape, kind, out=sink_view)
+    xn.record_stream(side)                               # the allocator must not recycle them before the side stream is done
+    dyn.record_stream(side)
+    task = torch._C._current_graph_task_id()
+    if task != _JOIN_QUEUED_FOR[0]:                      # once per backward pass (also after one that raised)
+        _JOIN_QUEUED_FOR[0] = task
+        torch.autograd.Variable._execution_engine.queue_callback(_join_after_backward)
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # autograd functions
 # ------------------------------------------------------------------------------------------------------------------
 def _views(*sinks):
@@ -529,9 +581,10 @@ class ConvGnActFunction(torch.autograd.Function):
             dx = from_ndhwc(conv_dgrad(dy, w, ctx.kind, addend=addend))
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(xn, dy, ctx.w_shape, ctx.kind, out=None if sw is None else sw.view)
             if sw is not None:
-                dw = None
+                _wgrad_to_sink(xn, dy, ctx.w_shape, ctx.kind, sw.view)
+            else:
+                dw = conv_wgrad(xn, dy, ctx.w_shape, ctx.kind)
         return (dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta,
                 from_ndhwc(dres) if dres is not None else None, None, None, None, None, None)
 

@@ -56,6 +56,10 @@ class GradientReducer(object):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.group = process_group
+        self._join = None
+        if flat_buffers and flat_buffers[0].is_cuda:
+            from segmentation3d import _ops
+            self._join = _ops.wgrad_stream_join
         self.world_size = dist.get_world_size(process_group)
         self.buffers = flat_buffers
         self._buckets = []          # dict(buffer, lo, hi, pending, nparams, work)
@@ -108,6 +112,8 @@ class GradientReducer(object):
         self._active = True
 
     def _launch(self, b):
+        if self._join is not None:
+            self._join()    # weight gradients written on the side stream (segmentation3d._ops) must have landed
         view = self.buffers[b['buffer']][b['lo']:b['hi']]
         b['work'] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 

@@ -50,6 +50,9 @@ def parse():
     ap.add_argument('--infer-volume', default='512,512,400', help='X,Y,Z of the synthetic inference volume')
     ap.add_argument('--infer-batch', type=int, default=8)
     ap.add_argument('--kernel-report', default='', help='write the per-shape kernel timing table to this json file')
+    ap.add_argument('--no-wgrad-overlap', action='store_true',
+                    help='enqueue weight-gradient kernels on the main stream (no second HIP stream): use this under '
+                         'rocprofv3 --kernel-trace, which serialises concurrent dispatches and distorts their durations')
     return ap.parse_args()
 
 
@@ -211,6 +214,9 @@ def main():
 
     from segmentation3d.core.seg_train import TrainStep
     weights = [1.0 / args.classes] * args.classes
+    if args.no_wgrad_overlap:
+        from segmentation3d import _ops as _ops_cfg
+        _ops_cfg.WGRAD_SIDE_STREAM = False
     step = TrainStep(args.net, args.in_channels, args.classes, args.loss, weights if args.loss == 'Dice' else None,
                      device=device, seed=0)
     x, t = synthetic_batch(args.batch, args.in_channels, args.classes, args.patch, device, 1000 + rank)
@@ -241,10 +247,19 @@ def main():
     if not args.no_roofline:
         # two extra, instrumented steps AFTER the timed region; every rank runs them (the gradient all-reduce is a
         # collective), rank 0 reports
-        with KernelTimer() as kt:
-            for _ in range(2):
-                step(x, t)
-        table = kt.summary()
+        # Per-kernel durations are taken with the weight-gradient side stream OFF: with it, an event pair around a launch on
+        # the main stream also spans the time the kernel waits for (or shares the chip with) a weight-gradient kernel of
+        # the other stream, which says nothing about the kernel itself.  `value` above is measured with the overlap on.
+        from segmentation3d import _ops
+        overlap_was = _ops.WGRAD_SIDE_STREAM
+        _ops.WGRAD_SIDE_STREAM = False
+        try:
+            with KernelTimer() as kt:
+                for _ in range(2):
+                    step(x, t)
+            table = kt.summary()
+        finally:
+            _ops.WGRAD_SIDE_STREAM = overlap_was
     if not args.no_roofline and rank == 0:
         by_variant = {}
         for key, e in table.items():
@@ -262,7 +277,9 @@ def main():
                     'launches_per_step': d['launches'] // 2,
                     'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                     'gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
-                    'share_of_step_ms': round(d['ms'] / 2, 3)}
+                    'share_of_step_ms': round(d['ms'] / 2, 3),
+                    'note': 'launch durations from 2 instrumented steps with the weight-gradient side stream off '
+                            '(kernels back to back on one stream); value/ms_per_step are measured with it on'}
         kernels = [{'N_D_H_W_Cin_Cout_variant': list(k), 'launches_per_step': e['launches'] // 2,
                     'avg_ms': round(e['ms'] / e['launches'], 4),
                     'tflops': round(e['flops'] / (e['ms'] * 1e-3) / 1e12, 2)} for k, e in sorted(table.items())]
@@ -289,7 +306,8 @@ def main():
                                    'fp32, random-init weights'.format(args.net, args.in_channels, args.classes, args.loss,
                                                                       args.batch, args.patch),
                        'global_batch': world * args.batch, 'patch': args.patch,
-                       'parallelism': 'dp{} (bucketed RCCL all-reduce overlapped with backward)'.format(world) if world > 1 else 'single GPU'},
+                       'parallelism': 'dp{} (bucketed RCCL all-reduce overlapped with backward)'.format(world) if world > 1 else 'single GPU',
+                       'wgrad_overlap': not args.no_wgrad_overlap},
             'final_loss': round(final_loss, 6),
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'infer': infer,
         }

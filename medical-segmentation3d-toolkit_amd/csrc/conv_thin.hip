@@ -268,13 +268,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
                                                                       int N, int D, int H, int W, int Cin, int Cout,
                                                                       int ntz, int nty, int ntx) {
   __shared__ __attribute__((aligned(16))) float xs[8 * TO_NV];      // [2][NV][4]
-  __shared__ __attribute__((aligned(16))) float ws[27 * 8 * CO];    // [tap][8][CO]
   const int tid = threadIdx.x;
   int b = blockIdx.x;
-  const int tix = b % ntx; b /= ntx;
-  const int tiy = b % nty; b /= nty;
-  const int tiz = b % ntz;
-  const int n = b / ntz;
+  int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
+  const int tix = b - qd * ntx; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)nty);
+  const int tiy = b - qd * nty; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)ntz);
+  const int tiz = b - qd * ntz;
+  const int n = qd;
   const int z0 = tiz * TO_TZ, y0 = tiy * TO_TY, x0 = tix * TO_TX;
   const int CIB = (Cin + 7) >> 3;
   const int hh = tid & 1;
@@ -285,10 +287,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
     goff[e] = -1;
     if (eidx < 2 * TO_NV) {
       const int v = eidx >> 1;
-      const int hx = v % TO_HX;
-      const int t = v / TO_HX;
-      const int hy = t % TO_HY;
-      const int hz = t / TO_HY;
+      const int t = seg3d_fdiv(v, 1.0f / (float)TO_HX);
+      const int hx = v - t * TO_HX;
+      const int hz = seg3d_fdiv(t, 1.0f / (float)TO_HY);
+      const int hy = t - hz * TO_HY;
       const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
       if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
         goff[e] = (((n * D + gz) * H + gy) * W + gx) * Cin + hh * 4;
@@ -302,20 +304,34 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
 #pragma unroll
   for (int c = 0; c < CO; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
 
-  for (int cib = 0; cib < CIB; ++cib) {
-    __syncthreads();
+  // HBM-bound kernel: the 9 loads of the next chunk are issued back to back (branch-free, zero-select at the LDS
+  // store) BEFORE the FMAs of the current chunk, and the weights -- identical for every lane -- are read straight from
+  // global memory with wave-uniform addresses (scalar loads) instead of 16 LDS broadcasts per tap.
+  f32x4 xst[TO_E];
+  auto load_chunk = [&](int cib) {
     const bool half_ok = cib * 8 + hh * 4 < Cin;
 #pragma unroll
     for (int e = 0; e < TO_E; ++e) {
-      const int eidx = tid + e * 256;
-      if (eidx < 2 * TO_NV) {
-        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (goff[e] >= 0 && half_ok) val = *reinterpret_cast<const f32x4*>(x + (i64)goff[e] + cib * 8);
-        *reinterpret_cast<f32x4*>(xs + (hh * TO_NV + (eidx >> 1)) * 4) = val;
+      const bool ok = goff[e] >= 0 && half_ok;
+      xst[e] = *reinterpret_cast<const f32x4*>(x + (ok ? (i64)goff[e] + cib * 8 : (i64)0));
+    }
+  };
+  load_chunk(0);
+  for (int cib = 0; cib < CIB; ++cib) {
+    __syncthreads();
+    {
+      const bool half_ok = cib * 8 + hh * 4 < Cin;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < TO_E; ++e) {
+        const int eidx = tid + e * 256;
+        if (eidx < 2 * TO_NV)
+          *reinterpret_cast<f32x4*>(xs + (hh * TO_NV + (eidx >> 1)) * 4) = (goff[e] >= 0 && half_ok) ? xst[e] : zero;
       }
     }
-    for (int k = tid; k < 27 * 8 * CO; k += 256) ws[k] = wq[(i64)cib * 27 * 8 * CO + k];
     __syncthreads();
+    if (cib + 1 < CIB) load_chunk(cib + 1);
+    const float* __restrict__ wchunk = wq + (i64)cib * 27 * 8 * CO;
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
@@ -328,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
           const f32x4 a01 = *reinterpret_cast<const f32x4*>(xs + TO_NV * 4 + vb0 + tapoff);
           const f32x4 a10 = *reinterpret_cast<const f32x4*>(xs + vb1 + tapoff);
           const f32x4 a11 = *reinterpret_cast<const f32x4*>(xs + TO_NV * 4 + vb1 + tapoff);
-          const float* wt = ws + tap * 8 * CO;
+          const float* wt = wchunk + tap * 8 * CO;   // wave-uniform address: scalar loads
 #pragma unroll
           for (int a = 0; a < 4; ++a)
 #pragma unroll

@@ -48,7 +48,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--infer-volume', default='512,512,400', help='X,Y,Z of the synthetic inference volume')
-    ap.add_argument('--infer-batch', type=int, default=8)
+    ap.add_argument('--infer-batch', type=int, default=16)
     ap.add_argument('--kernel-report', default='', help='write the per-shape kernel timing table to this json file')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='enqueue weight-gradient kernels on the main stream (no second HIP stream): use this under '

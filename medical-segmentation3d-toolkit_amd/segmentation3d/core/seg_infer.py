@@ -158,8 +158,26 @@ def shard_batches(batches, rank, world_size):
     return [b for i, b in enumerate(batches) if i % world_size == rank]
 
 
+def _forward_two_streams(net, batch, side):
+    """forward of one patch batch as two half batches on two HIP streams: while one half runs an MFMA-bound conv, the
+    other half's HBM-bound GroupNorm / stride-2 / head kernels share the chip (patches are independent; GroupNorm(1, C)
+    is per sample, so the result is identical).  Works eagerly and under hipGraph capture (fork / join by events)."""
+    P = batch.shape[0]
+    if side is None or P < 2:
+        return net(batch).contiguous()
+    h = P // 2
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out_b = net(batch[h:])
+    out_a = net(batch[:h])
+    cur.wait_stream(side)
+    out_b.record_stream(cur)
+    return torch.cat([out_a, out_b], 0)
+
+
 def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, batch_size=8, use_graph=True,
-                             process_group=None, shard=False):
+                             process_group=None, shard=False, two_streams=True):
     """run `net` over all patches of a device-resident volume; returns (probs [C,Z,Y,X], mask int8 [Z,Y,X], batcher).
     With shard=True under an initialised torch.distributed group every rank processes its share of the batches and
     the accumulators are summed with one all-reduce before the final divide + arg-max (float summation order then
@@ -178,6 +196,7 @@ def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, 
     # the weights do not change during a volume: keep their packed (MFMA-layout) images across batches, so neither
     # the eager batches nor the captured graph re-pack 26 tensors per forward
     cache_was_on = _ops.weight_cache(True)
+    side = torch.cuda.Stream() if (two_streams and P >= 2) else None
     try:
         with torch.no_grad():
             if use_graph and len(batches) > 2:
@@ -189,7 +208,7 @@ def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, 
                 with torch.cuda.stream(stream):
                     batcher.select(0)
                     static_in = batcher.gather_current()
-                    batcher.scatter_current(net(static_in).contiguous())
+                    batcher.scatter_current(_forward_two_streams(net, static_in, side))
                 torch.cuda.current_stream().wait_stream(stream)
                 first = 1
                 # capture with n_valid = 0 in the control block so the captured launch itself accumulates nothing
@@ -198,13 +217,13 @@ def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, 
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     batcher.gather_current(out=static_in)
-                    batcher.scatter_current(net(static_in).contiguous())
+                    batcher.scatter_current(_forward_two_streams(net, static_in, side))
             for b in range(first, len(batches)):
                 batcher.select(b)
                 if graph is not None:
                     graph.replay()
                 else:
-                    batcher.scatter_current(net(batcher.gather_current()).contiguous())
+                    batcher.scatter_current(_forward_two_streams(net, batcher.gather_current(), side))
             if sharded:
                 torch.distributed.all_reduce(batcher.acc, group=process_group)
                 torch.distributed.all_reduce(batcher.count, group=process_group)

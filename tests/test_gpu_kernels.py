@@ -33,6 +33,10 @@ CONV_K3_CASES = [
     (1, 16, 4, 4, 8, 16),     # thin-out, 4 outputs
     (1, 8, 16, 4, 8, 8),      # thin-in with 8 channels / generic MFMA boundary
     (4, 1, 16, 16, 16, 16),
+    (1, 16, 16, 12, 12, 12),  # weight-gradient tile 4x4x4 (extent divisible by 4, not by 8)
+    (2, 32, 64, 6, 6, 6),     # weight-gradient tile 2x6x6; split-K forward
+    (1, 24, 40, 4, 12, 20),   # partial 32-channel blocks on both sides
+    (1, 16, 64, 8, 8, 16),    # two output-channel blocks
 ]
 
 
@@ -61,6 +65,29 @@ def test_conv3d_k3_fwd_bwd(hip_device, case, force_direct):
     e = dict(out=max_err(out, ref), dx=rel_err(dx, rdx), dw=rel_err(dw, rdw), db=rel_err(db, rdb))
     report(name, **e)
     assert e['out'] < 1e-4 and e['dx'] < 1e-4 and e['dw'] < 2e-4 and e['db'] < 1e-4, e
+
+
+def test_conv_k3_mfma_addend_and_accumulate_flags(hip_device):
+    """C-ABI flags of the second-generation kernels: `addend` of seg3d_conv3d_k3_mfma_fwd (y = conv + bias + addend, the
+    fused residual-path gradient) and `accumulate` of seg3d_conv3d_k3_mfma_wgrad (dw += ..., gradient sinks), checked
+    against the same entry points without the flag"""
+    from segmentation3d import _ops, _engine as E
+    for (N, D, H, W, Cin, Cout) in [(2, 8, 12, 16, 32, 32), (1, 6, 6, 6, 16, 24), (1, 12, 12, 12, 64, 64)]:
+        x = _t(5, 'flagx', (N, D, H, W, Cin)).to(hip_device)
+        dy = _t(6, 'flagdy', (N, D, H, W, Cout)).to(hip_device)
+        ad = _t(7, 'flagad', (N, D, H, W, Cout)).to(hip_device)
+        w = (_t(8, 'flagw', (Cout, Cin, 3, 3, 3)) * 0.05).to(hip_device)
+        b = _t(9, 'flagb', (Cout,)).to(hip_device)
+        y0, _ = _ops._conv_k3_generic(x, w, b, Cin, Cout, 27, Cin * 27, 0, False)
+        y1, _ = _ops._conv_k3_generic(x, w, b, Cin, Cout, 27, Cin * 27, 0, False, addend=ad)
+        assert max_err(y1, y0 + ad) < 1e-5
+        dw0 = _ops.conv_wgrad(x, dy, (Cout, Cin, 3, 3, 3), 'k3')
+        base = _t(10, 'flagbase', (Cout, Cin, 3, 3, 3)).to(hip_device)
+        acc = base.clone()
+        _ops.conv_wgrad(x, dy, (Cout, Cin, 3, 3, 3), 'k3', out=acc)
+        assert rel_err(acc - base, dw0) < 1e-5
+        report('flags_{}x{}x{}x{}_{}_{}'.format(N, D, H, W, Cin, Cout),
+               variant=float(E.query('seg3d_conv3d_k3_mfma_variant', N, D, H, W, Cin, Cout)))
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 48, 6, 10, 20), (1, 128, 64, 4, 4, 4), (4, 256, 256, 6, 6, 6)])

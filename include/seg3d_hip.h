@@ -172,6 +172,22 @@ int seg3d_finalize_argmax(float* acc, const float* count, signed char* mask, int
 int seg3d_label_overlap_counts(const void* gt, const void* seg, int dtype, long long n, const int* labels_host, int nlabels,
                                unsigned long long* counts, void* stream);
 
+/* ---- pre/post-processing around the patch path: utils/image_tools.py:329-432, 481-510 ----------
+ * resample: dst[z][y][x] (Xo, Yo, Zo) = src sampled at the continuous index c = M * (x, y, z, 1), M = 12 doubles on the
+ * HOST (row-major 3 x 4); ITK semantics: inside iff -0.5 <= c < size - 0.5, else `pad`; linear (clamped 8-neighbourhood)
+ * or nearest neighbour (round half up). */
+int seg3d_resample_affine(const float* src, float* dst, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo,
+                          const double* affine_host, int linear, float pad, void* stream);
+/* box_device[6] initialised to {INT_MAX x3, -1 x3} -> inclusive (xmin, ymin, zmin, xmax, ymax, zmax) of the voxels whose
+ * value is in labels_host (nlabels == 0: every voxel > 0); untouched when nothing is selected */
+int seg3d_mask_bounding_box(const signed char* mask, int X, int Y, int Z, const int* labels_host, int nlabels,
+                            int* box_device, void* stream);
+/* 26-connected components of (mask == label): keep the largest (mode 0; ties: first in raster order) or every component
+ * with >= threshold voxels (mode 1); out = (combine ? out : 0) + value * kept.  workspace: seg3d_ccl_workspace_ints ints */
+long long seg3d_ccl_workspace_ints(long long voxels);
+int seg3d_ccl26_select(const signed char* mask, int label, int X, int Y, int Z, int mode, int threshold, int value,
+                       int combine, signed char* out, int* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

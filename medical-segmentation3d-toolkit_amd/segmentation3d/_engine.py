@@ -30,6 +30,10 @@ _SIGNATURES = {
     'seg3d_pack_job_blocks': (_c_ll, [_c_int, _c_int, _c_int]),
     'seg3d_label_overlap_counts': (_c_int, [_c_p, _c_p, _c_int, _c_ll, _c_p, _c_int, _c_p, _c_p]),
     'seg3d_pack_weights_mfma_multi': (_c_int, [_c_p, _c_int, _c_ll, _c_p]),
+    'seg3d_resample_affine': (_c_int, [_c_p, _c_p] + [_c_int] * 6 + [_c_p, _c_int, _c_f, _c_p]),
+    'seg3d_mask_bounding_box': (_c_int, [_c_p, _c_int, _c_int, _c_int, _c_p, _c_int, _c_p, _c_p]),
+    'seg3d_ccl_workspace_ints': (_c_ll, [_c_ll]),
+    'seg3d_ccl26_select': (_c_int, [_c_p] + [_c_int] * 8 + [_c_p, _c_p, _c_p]),
     'seg3d_conv3d_fwd_direct': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 8 + [_c_p]),
     'seg3d_convT3d_k2s2_fwd_direct': (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 6 + [_c_p]),
     'seg3d_wgrad_direct_workspace_floats': (_c_ll, [_c_int] * 7),

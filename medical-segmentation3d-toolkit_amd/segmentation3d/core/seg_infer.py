@@ -302,31 +302,50 @@ def segmentation_voi(model, iso_image, start_voxel, end_voxel, use_gpu=True):
     return maps
 
 
-def segmentation_volume(model, cfg, image, bbox_start_voxel, bbox_end_voxel, use_gpu=True, batch_size=8):
-    """segment a whole volume (reference: seg_infer.py:249-350).
+def _physical_to_index(frame, point):
+    """sitk TransformPhysicalPointToIndex: nearest index (round half up per axis)"""
+    spacing, origin, direction = (np.asarray(v, dtype=np.float64) for v in frame)
+    c = np.diag(1.0 / spacing) @ np.linalg.inv(direction.reshape(3, 3)) @ (np.asarray(point, dtype=np.float64) - origin)
+    return [int(np.floor(v + 0.5)) for v in c]
 
-    Scope of this round: the image must already be at the model's spacing (the reference's ITK resampling to the
-    model spacing and back, image_tools.py:329-377, is the next row of the scope table).  The size is padded with
-    zeros up to a multiple of max_stride exactly as `resample_spacing` does for an image at the target spacing.
+
+def _index_to_physical(frame, index):
+    spacing, origin, direction = (np.asarray(v, dtype=np.float64) for v in frame)
+    return origin + direction.reshape(3, 3) @ (spacing * np.asarray(index, dtype=np.float64))
+
+
+def segmentation_volume(model, cfg, image, bbox_start_voxel, bbox_end_voxel, use_gpu=True, batch_size=8):
+    """segment a whole volume (reference: seg_infer.py:249-350), everything between the upload of the image and the
+    download of the probability maps / mask on the device:
+      resample to the model spacing, size up to a multiple of max_stride (image_tools.py:348-377)  -> seg3d_resample_affine
+      partition (host index arithmetic), one batched gather -> net -> scatter per hipGraph replay, divide by overlap
+      resample the class probabilities back onto the image grid, padding 1.0 for class 0 and 0.0 otherwise (:330-333)
+      arg-max -> int8 mask (:336-339); largest component / small-component removal (:342-348)
+    `use_gpu` is kept for signature compatibility (the reference shrinks spacing / partitions on the CPU path only).
     Returns (mean_probs: list of Image3d, mask: Image3d int8).
     """
+    from segmentation3d.utils import image_tools
     assert isinstance(image, Image3d)
-    spacing = [float(s) for s in model['spacing']]
-    if any(abs(a - b) > 1e-4 * max(a, b) for a, b in zip(image.GetSpacing(), spacing)):
-        raise NotImplementedError('image spacing {} differs from the model spacing {}: on-device resampling is not '
-                                  'built yet (SURVEY.md section 8f row f1)'.format(image.GetSpacing(), spacing))
-    ms = int(model['max_stride'])
-    X, Y, Z = image.GetSize()
-    Xp, Yp, Zp = [(v + ms - 1) // ms * ms for v in (X, Y, Z)]
     dev = model['device']
-    vol = torch.zeros((Zp, Yp, Xp), dtype=torch.float32, device=dev)
-    vol[:Z, :Y, :X] = torch.from_numpy(np.ascontiguousarray(image.array, dtype=np.float32)).to(dev)
+    ms = int(model['max_stride'])
+    num_classes = int(model['out_channels'])
+    spacing = [float(s) for s in model['spacing']]
+    img_frame = (image.GetSpacing(), image.GetOrigin(), image.GetDirection())
+    iso_frame = (spacing, image.GetOrigin(), image.GetDirection())
+    X, Y, Z = image.GetSize()
+    Xp, Yp, Zp = image_tools.resampled_size((X, Y, Z), image.GetSpacing(), spacing, ms)
+    src = torch.from_numpy(np.array(image.array, dtype=np.float32, order='C')).to(dev)
+    interp = model.get('interpolation', 'LINEAR') or 'LINEAR'
+    vol = image_tools.resample_device(src, img_frame, (Xp, Yp, Zp), iso_frame, interp, 0.0)
     if cfg.partition_type == 'DISABLE':
         starts, box = [[0, 0, 0]], (Xp, Yp, Zp)
     elif cfg.partition_type == 'SIZE':
         if bbox_start_voxel is not None and bbox_end_voxel is not None:
-            s0 = [max(0, int(v)) for v in bbox_start_voxel]
-            e0 = [min(int(v), lim) for v, lim in zip(bbox_end_voxel, (Xp, Yp, Zp))]
+            # bounding box given in image voxels -> iso grid (seg_infer.py:292-303)
+            s0 = _physical_to_index(iso_frame, _index_to_physical(img_frame, [float(v) for v in bbox_start_voxel]))
+            e0 = _physical_to_index(iso_frame, _index_to_physical(img_frame, [float(v) for v in bbox_end_voxel]))
+            s0 = [max(0, v) for v in s0]
+            e0 = [min(v, lim) for v, lim in zip(e0, (Xp, Yp, Zp))]
         else:
             s0, e0 = [0, 0, 0], [Xp, Yp, Zp]
         starts, ends = image_partition_by_fixed_size(((Xp, Yp, Zp), spacing), s0, e0, list(cfg.partition_size),
@@ -335,20 +354,32 @@ def segmentation_volume(model, cfg, image, bbox_start_voxel, bbox_end_voxel, use
     else:
         raise ValueError('Unsupported partition type!')
     norm = model['crop_normalizer_dicts'][0] if model['crop_normalizer_dicts'] else None
-    probs, mask, _ = sliding_window_inference(model['net'], vol, starts, box, model['out_channels'], norm,
-                                              batch_size=min(batch_size, max(1, len(starts))))
-    probs = probs[:, :Z, :Y, :X]
-    mask = mask[:Z, :Y, :X]
-    frame = (image.GetSpacing(), image.GetOrigin(), image.GetDirection())
-    mean_probs = [Image3d(probs[c].cpu().numpy(), *frame) for c in range(model['out_channels'])]
-    return mean_probs, Image3d(mask.cpu().numpy(), *frame)
+    probs, _, batcher = sliding_window_inference(model['net'], vol, starts, box, num_classes, norm,
+                                                 batch_size=min(batch_size, max(1, len(starts))))
+    # (voxels no patch covered -- bounding-box runs -- have count 0: as in the reference their probabilities are 0 * inf =
+    # NaN and the arg-max there is class 0)
+    # back to the image grid (identity when the image already is at the model spacing and a stride multiple)
+    same_grid = (Xp, Yp, Zp) == (X, Y, Z) and all(abs(a - b) <= 1e-9 * max(abs(a), abs(b), 1.0)
+                                                 for a, b in zip(image.GetSpacing(), spacing))
+    if same_grid:
+        out_probs = probs
+    else:
+        out_probs = torch.stack([image_tools.resample_device(probs[c], iso_frame, (X, Y, Z), img_frame, 'LINEAR',
+                                                              1.0 if c == 0 else 0.0) for c in range(num_classes)])
+    mask = out_probs.argmax(0).to(torch.int8)       # first maximum wins, like tensor.max(0) in the reference
+    labels = list(range(1, num_classes))
+    if getattr(cfg, 'pick_largest_cc', False) and labels:
+        mask = image_tools.connected_component_filter_device(mask, labels, 'largest')
+    if getattr(cfg, 'remove_small_cc', 0) and cfg.remove_small_cc > 0 and labels:
+        mask = image_tools.connected_component_filter_device(mask, labels, 'min_size', int(cfg.remove_small_cc))
+    mean_probs = [Image3d(out_probs[c].cpu().numpy(), *img_frame) for c in range(num_classes)]
+    return mean_probs, Image3d(mask.cpu().numpy(), *img_frame)
 
 
 def segmentation(input_path, model_folder, output_folder, seg_name, gpu_id, return_mask, save_mask, save_image,
                  save_prob):
-    """volumetric image segmentation engine for MetaImage files (reference: seg_infer.py:353-493).
-    Single-scale configurations ('coarse' or 'fine'); the coarse->fine cascade needs the bounding-box / connected
-    component post-processing that is scoped as next."""
+    """volumetric image segmentation engine for MetaImage files (reference: seg_infer.py:353-493): single-scale
+    ('coarse' / 'fine') or the coarse -> fine cascade ('DISABLE') through the coarse mask's bounding box."""
     from segmentation3d.utils.mha_io import read_mha, write_mha
     begin = time.time()
     models = load_models(model_folder, gpu_id)
@@ -361,16 +392,31 @@ def segmentation(input_path, model_folder, output_folder, seg_name, gpu_id, retu
     else:
         raise ValueError('Unsupported input path.')
     scale = models['infer_cfg'].general.single_scale
-    if scale == 'DISABLE':
-        raise NotImplementedError('coarse-to-fine cascade is not built yet; set general.single_scale to coarse or fine')
-    model = models['coarse_model'] if scale == 'coarse' else models['fine_model']
-    cfg = models['infer_cfg'].coarse if scale == 'coarse' else models['infer_cfg'].fine
+    if scale not in ('coarse', 'fine', 'DISABLE'):
+        raise ValueError('Unsupported scale type!')
     masks, total = [], 0.0
     for i, path in enumerate(paths):
         print('{}: {}'.format(i, path))
         image = read_mha(path)
         begin = time.time()
-        mean_probs, mask = segmentation_volume(model, cfg, image, None, None, True)
+        if scale == 'coarse':
+            mean_probs, mask = segmentation_volume(models['coarse_model'], models['infer_cfg'].coarse, image, None, None, True)
+        elif scale == 'fine':
+            mean_probs, mask = segmentation_volume(models['fine_model'], models['infer_cfg'].fine, image, None, None, True)
+        else:
+            # coarse -> fine cascade (seg_infer.py:428-444): the coarse mask's bounding box restricts the fine pass
+            from segmentation3d.utils.image_tools import get_bounding_box
+            print('Coarse segmentation: ')
+            _, mask = segmentation_volume(models['coarse_model'], models['infer_cfg'].coarse, image, None, None, True)
+            start_voxel, end_voxel = get_bounding_box(mask, None)
+            if start_voxel is None:
+                start_voxel, end_voxel = [0, 0, 0], list(mask.GetSize())
+            bbox_ratio = 100
+            for idx in range(3):
+                bbox_ratio *= (end_voxel[idx] - start_voxel[idx]) / mask.GetSize()[idx]
+            print('Fine segmentation (bbox ratio: {:.2f}%): '.format(bbox_ratio))
+            mean_probs, mask = segmentation_volume(models['fine_model'], models['infer_cfg'].fine, image, start_voxel,
+                                                   end_voxel, True)
         torch.cuda.synchronize()
         total += time.time() - begin
         if return_mask:

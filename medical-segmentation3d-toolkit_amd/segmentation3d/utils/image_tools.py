@@ -4,11 +4,19 @@ Only the five functions that define the sliding-window semantics are provided (S
   image_partition_by_fixed_size  (image_tools.py:163-218)   pure index arithmetic, host side
   add_image_region / add_image_value (image_tools.py:435-469) -> device kernels, see core/seg_infer.py
   convert_image_to_tensor / convert_tensor_to_image (image_tools.py:274-326)
-The ITK geometry functions (resample, crop, connected components, bounding box) are outside this round's scope.
+plus the geometry functions around the patch path, on the device:
+  resample / resample_spacing                         (image_tools.py:329-377)  trilinear / NN, ITK inside test and padding
+  pick_largest_connected_component / remove_small_connected_component (image_tools.py:380-432)  26-connectivity
+  get_bounding_box                                    (image_tools.py:481-510)
+Images are `Image3d` (numpy [z, y, x] + spacing / origin / direction); the `*_device` variants take and return device
+tensors so that core/seg_infer.segmentation_volume keeps the whole chain on the GPU.
 """
+import ctypes
+
 import numpy as np
 import torch
 
+from segmentation3d import _engine as E
 from segmentation3d.utils.image3d import Image3d, image_size_spacing
 
 
@@ -74,3 +82,129 @@ def convert_tensor_to_image(tensor, dtype=None):
     if tensor.dim() == 4:
         return [Image3d(data[i]) for i in range(data.shape[0])]
     raise ValueError('Only supports 3-dimsional or 4-dimensional image volume')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# geometry on the device
+# ---------------------------------------------------------------------------------------------------------------------
+def _device():
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def index_affine(src_frame, dst_frame):
+    """3 x 4 matrix M with  c_src = M @ (x, y, z, 1)  for an index (x, y, z) of the destination grid: destination
+    index -> physical point -> continuous source index, as sitk.Resample does with an identity transform.
+    frame = (spacing, origin, direction), direction row-major 3 x 3"""
+    s_sp, s_or, s_dir = (np.asarray(v, dtype=np.float64) for v in src_frame)
+    d_sp, d_or, d_dir = (np.asarray(v, dtype=np.float64) for v in dst_frame)
+    Ds, Dd = s_dir.reshape(3, 3), d_dir.reshape(3, 3)
+    to_src = np.diag(1.0 / s_sp) @ np.linalg.inv(Ds)
+    M = np.zeros((3, 4))
+    M[:, :3] = to_src @ Dd @ np.diag(d_sp)
+    M[:, 3] = to_src @ (d_or - s_or)
+    return M
+
+
+def resample_device(src, src_frame, out_size, dst_frame, interp_method, padding_value=0.0):
+    """src: float32 device tensor [Z, Y, X]; returns the float32 device tensor [Zo, Yo, Xo] of the destination grid"""
+    if interp_method not in ('LINEAR', 'NN'):
+        raise ValueError('Unsupported interpolation type.')
+    E.require_device(src)
+    src = src.contiguous()
+    Zi, Yi, Xi = src.shape
+    Xo, Yo, Zo = (int(v) for v in out_size)
+    dst = torch.empty((Zo, Yo, Xo), dtype=torch.float32, device=src.device)
+    M = np.ascontiguousarray(index_affine(src_frame, dst_frame), dtype=np.float64)
+    E.call('seg3d_resample_affine', E.ptr(src), E.ptr(dst), Xi, Yi, Zi, Xo, Yo, Zo,
+           M.ctypes.data_as(ctypes.c_void_p), int(interp_method == 'LINEAR'), float(padding_value), E.stream_ptr())
+    return dst
+
+
+def _frame(image):
+    return (image.GetSpacing(), image.GetOrigin(), image.GetDirection())
+
+
+def resample(image, reference, interp_method, padding_value=0.0):
+    """Resample `image` onto the grid of `reference` (reference: image_tools.py:329-345)"""
+    assert isinstance(image, Image3d) and isinstance(reference, Image3d)
+    src = torch.from_numpy(np.array(image.array, dtype=np.float32, order='C')).to(_device())
+    out = resample_device(src, _frame(image), reference.GetSize(), _frame(reference), interp_method, padding_value)
+    return Image3d(out.cpu().numpy(), *_frame(reference))
+
+
+def resampled_size(in_size, in_spacing, out_spacing, max_stride):
+    """output size of resample_spacing (image_tools.py:361-365): round half up, then up to a multiple of max_stride"""
+    out = [int(in_size[d] * in_spacing[d] / out_spacing[d] + 0.5) for d in range(3)]
+    return [max_stride * (v // max_stride + 1) if v % max_stride else v for v in out]
+
+
+def resample_spacing(image, resampled_spacing, max_stride, interp_method):
+    """Resample to a new spacing, same origin / direction, size a multiple of max_stride (image_tools.py:348-377);
+    voxels beyond the input extent take ITK's default pixel value 0"""
+    assert isinstance(image, Image3d)
+    out_spacing = [float(v) for v in resampled_spacing]
+    out_size = resampled_size(image.GetSize(), image.GetSpacing(), out_spacing, max_stride)
+    dst_frame = (out_spacing, image.GetOrigin(), image.GetDirection())
+    src = torch.from_numpy(np.array(image.array, dtype=np.float32, order='C')).to(_device())
+    out = resample_device(src, _frame(image), out_size, dst_frame, interp_method, 0.0)
+    return Image3d(out.cpu().numpy(), *dst_frame)
+
+
+def connected_component_filter_device(mask, labels, mode, threshold=0):
+    """mask: int8 device tensor [Z, Y, X]; per label keeps the largest 26-connected component (mode 'largest') or the
+    components with at least `threshold` voxels (mode 'min_size'); composition as in the reference: the FIRST label's
+    voxels become 1, every other label keeps its own value (image_tools.py:399-403, 429-431)"""
+    assert isinstance(labels, list)
+    E.require_device(mask)
+    if mask.dtype != torch.int8:
+        raise TypeError('mask must be int8')
+    mask = mask.contiguous()
+    Z, Y, X = mask.shape
+    out = torch.zeros_like(mask)
+    if not labels:
+        return out
+    ws = torch.empty(E.query('seg3d_ccl_workspace_ints', mask.numel()), dtype=torch.int32, device=mask.device)
+    for k, label in enumerate(labels):
+        E.call('seg3d_ccl26_select', E.ptr(mask), int(label), X, Y, Z, 0 if mode == 'largest' else 1, int(threshold),
+               1 if k == 0 else int(label), int(k > 0), E.ptr(out), E.ptr(ws), E.stream_ptr())
+    return out
+
+
+def _mask_to_device(mask):
+    assert isinstance(mask, Image3d)
+    return torch.from_numpy(np.array(mask.array, dtype=np.int8, order='C')).to(_device())
+
+
+def pick_largest_connected_component(mask, labels):
+    """keep, for every label, only its largest 26-connected component (image_tools.py:380-405)"""
+    out = connected_component_filter_device(_mask_to_device(mask), labels, 'largest')
+    return Image3d(out.cpu().numpy().astype(mask.array.dtype), *_frame(mask))
+
+
+def remove_small_connected_component(mask, labels, threshold):
+    """drop, for every label, the 26-connected components smaller than `threshold` voxels (image_tools.py:408-432)"""
+    out = connected_component_filter_device(_mask_to_device(mask), labels, 'min_size', threshold)
+    return Image3d(out.cpu().numpy().astype(mask.array.dtype), *_frame(mask))
+
+
+def get_bounding_box_device(mask, selected_labels):
+    """mask: int8 device tensor [Z, Y, X] -> (start_voxel, end_voxel) in (x, y, z), end exclusive, or (None, None)"""
+    E.require_device(mask)
+    mask = mask.contiguous()
+    Z, Y, X = mask.shape
+    box = torch.tensor([2 ** 31 - 1] * 3 + [-1] * 3, dtype=torch.int32, device=mask.device)
+    labels = [] if selected_labels is None else [int(v) for v in selected_labels]
+    if selected_labels is not None and not labels:
+        return None, None
+    arr = (ctypes.c_int * max(1, len(labels)))(*labels) if labels else None
+    E.call('seg3d_mask_bounding_box', E.ptr(mask), X, Y, Z, arr, len(labels), E.ptr(box), E.stream_ptr())
+    b = box.cpu().tolist()
+    if b[3] < 0:
+        print('Fail to get the bounding box.')
+        return None, None
+    return [b[0], b[1], b[2]], [b[3] + 1, b[4] + 1, b[5] + 1]
+
+
+def get_bounding_box(mask, selected_labels):
+    """bounding box of the selected labels (None: every non-zero voxel), end exclusive (image_tools.py:481-510)"""
+    return get_bounding_box_device(_mask_to_device(mask), selected_labels)

@@ -151,3 +151,105 @@ def cal_dsc(gt, seg, label, threshold):
 def label_overlap_counts(gt, seg, labels):
     g, s = np.asarray(gt), np.asarray(seg)
     return [(int((g == l).sum()), int((s == l).sum()), int(((g == l) & (s == l)).sum())) for l in labels]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# geometry around the patch path -- ITK semantics restated, no SimpleITK here: parity unpinned
+# ---------------------------------------------------------------------------------------------------------------------
+def index_affine(src_frame, dst_frame):
+    """3 x 4 map destination index -> continuous source index (identity transform between the physical spaces)"""
+    s_sp, s_or, s_dir = (np.asarray(v, dtype=np.float64) for v in src_frame)
+    d_sp, d_or, d_dir = (np.asarray(v, dtype=np.float64) for v in dst_frame)
+    to_src = np.diag(1.0 / s_sp) @ np.linalg.inv(s_dir.reshape(3, 3))
+    M = np.zeros((3, 4))
+    M[:, :3] = to_src @ d_dir.reshape(3, 3) @ np.diag(d_sp)
+    M[:, 3] = to_src @ (d_or - s_or)
+    return M
+
+
+def resample_affine(src, M, out_size, linear=True, pad=0.0):
+    """src [Z, Y, X] sampled on the (Xo, Yo, Zo) grid; restates sitk.Resample(identity, LINEAR / NN, pad)
+    (utils/image_tools.py:329-377): inside iff -0.5 <= c < size - 0.5, clamped neighbourhood, double arithmetic"""
+    src = np.asarray(src, dtype=np.float64)
+    Zi, Yi, Xi = src.shape
+    Xo, Yo, Zo = out_size
+    z, y, x = np.meshgrid(np.arange(Zo), np.arange(Yo), np.arange(Xo), indexing='ij')
+    c = [M[r, 0] * x + M[r, 1] * y + M[r, 2] * z + M[r, 3] for r in range(3)]
+    size = (Xi, Yi, Zi)
+    inside = np.ones(x.shape, dtype=bool)
+    for r in range(3):
+        inside &= (c[r] >= -0.5) & (c[r] < size[r] - 0.5)
+    if linear:
+        f = [np.clip(c[r], 0.0, size[r] - 1) for r in range(3)]
+        i0 = [np.floor(v).astype(np.int64) for v in f]
+        i1 = [np.minimum(i0[r] + 1, size[r] - 1) for r in range(3)]
+        d = [f[r] - i0[r] for r in range(3)]
+        g = lambda zz, yy, xx: src[zz, yy, xx]
+        a00 = g(i0[2], i0[1], i0[0]) + (g(i0[2], i0[1], i1[0]) - g(i0[2], i0[1], i0[0])) * d[0]
+        a01 = g(i0[2], i1[1], i0[0]) + (g(i0[2], i1[1], i1[0]) - g(i0[2], i1[1], i0[0])) * d[0]
+        a10 = g(i1[2], i0[1], i0[0]) + (g(i1[2], i0[1], i1[0]) - g(i1[2], i0[1], i0[0])) * d[0]
+        a11 = g(i1[2], i1[1], i0[0]) + (g(i1[2], i1[1], i1[0]) - g(i1[2], i1[1], i0[0])) * d[0]
+        b0 = a00 + (a01 - a00) * d[1]
+        b1 = a10 + (a11 - a10) * d[1]
+        val = b0 + (b1 - b0) * d[2]
+    else:
+        n = [np.clip(np.floor(c[r] + 0.5).astype(np.int64), 0, size[r] - 1) for r in range(3)]
+        val = src[n[2], n[1], n[0]]
+    return np.where(inside, val, pad).astype(np.float32)
+
+
+def resampled_size(in_size, in_spacing, out_spacing, max_stride):
+    out = [int(in_size[d] * in_spacing[d] / out_spacing[d] + 0.5) for d in range(3)]
+    return [max_stride * (v // max_stride + 1) if v % max_stride else v for v in out]
+
+
+def connected_component_filter(mask, labels, mode, threshold=0):
+    """restates pick_largest_connected_component / remove_small_connected_component (utils/image_tools.py:380-432):
+    26-connectivity; largest = most voxels, ties to the component met first in raster order; composition: first label
+    -> 1, the others keep their value"""
+    from scipy import ndimage
+    mask = np.asarray(mask)
+    out = np.zeros(mask.shape, dtype=np.int64)
+    for k, label in enumerate(labels):
+        cc, n = ndimage.label(mask == label, structure=np.ones((3, 3, 3), dtype=bool))   # labels in raster order
+        keep = np.zeros(mask.shape, dtype=bool)
+        if n > 0:
+            sizes = np.bincount(cc.ravel(), minlength=n + 1)[1:]
+            if mode == 'largest':
+                keep = cc == (int(np.argmax(sizes)) + 1)          # argmax returns the first maximum
+            else:
+                keep = np.isin(cc, np.nonzero(sizes >= threshold)[0] + 1)
+        out += (1 if k == 0 else int(label)) * keep
+    return out.astype(mask.dtype)
+
+
+def get_bounding_box(mask, selected_labels):
+    """utils/image_tools.py:481-510: (start, end) in (x, y, z), end exclusive; (None, None) when nothing is selected"""
+    mask = np.asarray(mask)
+    sel = (mask > 0) if selected_labels is None else np.isin(mask, list(selected_labels))
+    if not sel.any():
+        return None, None
+    zz, yy, xx = np.nonzero(sel)
+    return [int(xx.min()), int(yy.min()), int(zz.min())], [int(xx.max()) + 1, int(yy.max()) + 1, int(zz.max()) + 1]
+
+
+def segmentation_volume(image, frame, net_fn, num_classes, model_spacing, partition_size, partition_stride, max_stride,
+                        normalizer, interpolation='LINEAR', pick_largest_cc=False, remove_small_cc=0):
+    """the whole of core/seg_infer.py:249-350 on the host: resample to the model spacing -> patch loop -> resample the
+    class probabilities back (padding 1.0 for class 0, 0.0 otherwise) -> arg-max -> component post-processing.
+    image [Z, Y, X], frame = (spacing, origin, direction) of the image; returns (probs [C, Z, Y, X], mask int8)"""
+    Z, Y, X = image.shape
+    iso_frame = (list(model_spacing), frame[1], frame[2])
+    size = resampled_size((X, Y, Z), frame[0], model_spacing, max_stride)
+    iso = resample_affine(image, index_affine(frame, iso_frame), size, interpolation == 'LINEAR', 0.0)
+    probs, _, _ = sliding_window_inference(iso, net_fn, num_classes, model_spacing, partition_size, partition_stride,
+                                           max_stride, normalizer, double_forward=False)
+    back = index_affine(iso_frame, frame)
+    out = np.stack([resample_affine(probs[c], back, (X, Y, Z), True, 1.0 if c == 0 else 0.0) for c in range(num_classes)])
+    mask = np.argmax(out, axis=0).astype(np.int8)
+    labels = list(range(1, num_classes))
+    if pick_largest_cc and labels:
+        mask = connected_component_filter(mask, labels, 'largest')
+    if remove_small_cc > 0 and labels:
+        mask = connected_component_filter(mask, labels, 'min_size', remove_small_cc)
+    return out, mask

@@ -359,3 +359,85 @@ def test_patch_batcher_against_numpy_oracle(hip_device):
         assert np.array_equal(batcher.count.cpu().numpy(), cnt)
         assert max_err(probs_d, rp) == 0.0          # same summation order as the sequential reference loop
         assert np.array_equal(mask_d.cpu().numpy(), rm)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# geometry around the patch path
+# ---------------------------------------------------------------------------------------------------------------------
+RESAMPLE_CASES = [
+    # src size (x, y, z), src frame, dst size, dst frame
+    ((14, 12, 10), ((0.8, 1.1, 2.0), (1.0, 2.0, 3.0), np.eye(3).ravel()), (16, 16, 16), ((1.0, 1.0, 1.0), (1.0, 2.0, 3.0), np.eye(3).ravel())),
+    ((20, 16, 12), ((1.0, 1.0, 1.0), (0.0, 0.0, 0.0), np.eye(3).ravel()), (32, 32, 16), ((0.5, 0.5, 1.5), (0.0, 0.0, 0.0), np.eye(3).ravel())),
+    ((16, 16, 16), ((1.0, 1.0, 1.0), (0.0, 0.0, 0.0), np.eye(3).ravel()), (16, 16, 16), ((1.0, 1.0, 1.0), (0.0, 0.0, 0.0), np.eye(3).ravel())),
+    ((12, 18, 9), ((0.7, 0.9, 1.3), (-3.0, 4.0, 1.0), np.diag([-1.0, 1.0, 1.0]).ravel()), (11, 13, 17),
+     ((0.9, 0.6, 0.8), (-9.0, 3.5, 0.5), np.diag([-1.0, 1.0, 1.0]).ravel())),
+]
+
+
+@pytest.mark.parametrize('interp', ['LINEAR', 'NN'])
+@pytest.mark.parametrize('case', RESAMPLE_CASES)
+def test_resample_against_oracle(hip_device, case, interp):
+    """seg3d_resample_affine (trilinear / nearest with ITK's inside test and padding) against oracle/numpy_ref"""
+    from oracle import numpy_ref
+    from segmentation3d.utils import image_tools
+    src_size, src_frame, dst_size, dst_frame = case
+    src = detgen.normal(401, 'rs/{}'.format(src_size), (src_size[2], src_size[1], src_size[0]))
+    M = numpy_ref.index_affine(src_frame, dst_frame)
+    ref = numpy_ref.resample_affine(src, M, dst_size, interp == 'LINEAR', pad=-2.5)
+    out = image_tools.resample_device(torch.from_numpy(src).to(hip_device), src_frame, dst_size, dst_frame, interp, -2.5)
+    e = max_err(out, ref)
+    report('resample_{}_{}'.format(interp, 'x'.join(map(str, src_size))), err=e, padded=float((ref == -2.5).mean()))
+    assert e < (1e-5 if interp == 'LINEAR' else 1e-7), e
+    assert tuple(out.shape) == (dst_size[2], dst_size[1], dst_size[0])
+
+
+def test_resample_spacing_and_back_host_api(hip_device):
+    """resample_spacing (size rounded up to the stride multiple, zero beyond the input) and resample onto a reference
+    image, through the Image3d API; identity resampling returns the input bit for bit"""
+    from oracle import numpy_ref
+    from segmentation3d.utils import image_tools
+    from segmentation3d.utils.image3d import Image3d
+    arr = detgen.normal(402, 'rs/img', (20, 30, 26))
+    img = Image3d(arr, (0.8, 0.8, 1.6), (5.0, -3.0, 2.0), np.eye(3).ravel())
+    iso = image_tools.resample_spacing(img, [1.0, 1.0, 1.0], 16, 'LINEAR')
+    want = numpy_ref.resampled_size(img.GetSize(), img.GetSpacing(), [1.0, 1.0, 1.0], 16)
+    assert list(iso.GetSize()) == want and all(v % 16 == 0 for v in want)
+    M = numpy_ref.index_affine((img.GetSpacing(), img.GetOrigin(), img.GetDirection()), ([1.0] * 3, img.GetOrigin(), img.GetDirection()))
+    assert max_err(iso.array, numpy_ref.resample_affine(arr, M, want, True, 0.0)) < 1e-5
+    back = image_tools.resample(iso, img, 'LINEAR', 1.0)
+    assert back.array.shape == arr.shape
+    same = image_tools.resample(img, img, 'LINEAR', 0.0)
+    assert np.array_equal(same.array, arr)
+
+
+def test_connected_components_and_bounding_box(hip_device):
+    """26-connected component selection (largest with the raster-order tie rule, size threshold, multi-label
+    composition) and the bounding box, bit-exact against the scipy-based oracle"""
+    from oracle import numpy_ref
+    from segmentation3d.utils import image_tools
+    shape = (28, 36, 44)
+    u = detgen.uniform(403, 'cc/u', tuple((s + 3) // 4 for s in shape))
+    blobs = np.zeros(u.shape, dtype=np.int8)
+    blobs[u > 0.80] = 1
+    blobs[u < 0.12] = 2
+    blobs[(u > 0.45) & (u < 0.50)] = 3
+    mask = np.repeat(np.repeat(np.repeat(blobs, 4, 0), 4, 1), 4, 2)[:shape[0], :shape[1], :shape[2]].copy()
+    mask[0, 0, 0:3] = 1                       # small stray components
+    mask[27, 35, 41:44] = 2
+    mask[5, 5, 5] = 3                         # diagonal neighbours join under 26-connectivity only
+    mask[6, 6, 6] = 3
+    md = torch.from_numpy(mask).to(hip_device)
+    for labels in ([1, 2, 3], [2], [3, 1], [4]):
+        got = image_tools.connected_component_filter_device(md, labels, 'largest').cpu().numpy()
+        assert np.array_equal(got, numpy_ref.connected_component_filter(mask, labels, 'largest')), labels
+        for thr in (2, 30, 100000):
+            got = image_tools.connected_component_filter_device(md, labels, 'min_size', thr).cpu().numpy()
+            assert np.array_equal(got, numpy_ref.connected_component_filter(mask, labels, 'min_size', thr)), (labels, thr)
+    # tie: two components of equal size -> the one met first in raster order
+    tie = np.zeros((6, 6, 6), dtype=np.int8)
+    tie[4, 4, 0:3] = 1
+    tie[1, 1, 2:5] = 1
+    got = image_tools.connected_component_filter_device(torch.from_numpy(tie).to(hip_device), [1], 'largest').cpu().numpy()
+    assert np.array_equal(got, numpy_ref.connected_component_filter(tie, [1], 'largest')) and got[1, 1, 3] == 1 and got[4, 4, 1] == 0
+    for sel in (None, [2], [1, 3], [9]):
+        assert image_tools.get_bounding_box_device(md, sel) == numpy_ref.get_bounding_box(mask, sel), sel

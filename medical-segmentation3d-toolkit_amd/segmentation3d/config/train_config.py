@@ -19,8 +19,8 @@ __C.dataset.num_classes = 2
 __C.dataset.spacing = [1.0, 1.0, 1.0]                  # mm, (x, y, z)
 __C.dataset.crop_size = [96, 96, 96]                   # voxels, multiples of max_stride (16)
 __C.dataset.sampling_method = 'HYBRID'                 # GLOBAL | MASK | HYBRID | CENTER
-__C.dataset.random_translation = [5, 5, 5]
-__C.dataset.random_scale = [0.05, 0.05, 0.05]
+__C.dataset.random_translation = [15, 15, 15]             # mm, uniform in [-t, t] per axis
+__C.dataset.random_scale = [0.9, 1.1]                     # crop spacing = spacing * uniform(lo, hi)
 __C.dataset.interpolation = 'LINEAR'                   # NN | LINEAR
 __C.dataset.crop_normalizers = [AdaptiveNormalizer()]
 

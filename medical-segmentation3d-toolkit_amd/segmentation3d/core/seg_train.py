@@ -75,10 +75,11 @@ class TrainStep(object):
 def train(train_config_file, data_iter_factory=None):
     """training engine with the reference's config schema (config/train_config.py) and checkpoint layout.
 
-    The reference's `SegmentationDataset` (SimpleITK resampling crops, dataloader/dataset.py) is outside this round's
-    scope; pass `data_iter_factory(cfg) -> iterator of (crops, masks)` device or host float tensors.  Everything
-    else -- model folder, config copies, seeding, loss selection, logging format, checkpoint cadence -- follows
-    core/seg_train.py:22-152.
+    Data: by default the GPU-resident `SegmentationDataset` (dataloader/dataset.py: cases read once, crops resampled
+    and normalised on the device) driven by `EpochConcateSampler` -- or its distributed variant, one shard per rank --
+    exactly as core/seg_train.py:56-70 wires the reference's dataset; alternatively pass
+    `data_iter_factory(cfg) -> iterator of (crops, masks[, frames, names])`.  Model folder, config copies, seeding,
+    loss selection, logging format and checkpoint cadence follow core/seg_train.py:22-152.
     """
     from segmentation3d.utils.file_io import load_config, setup_logger
     from segmentation3d.utils.model_io import load_checkpoint, save_checkpoint
@@ -106,9 +107,24 @@ def train(train_config_file, data_iter_factory=None):
     if cfg.general.resume_epoch >= 0:
         last_save_epoch, batch_idx = load_checkpoint(cfg.general.resume_epoch, step.net, step.opt, model_folder)
     if data_iter_factory is None:
-        raise NotImplementedError('the SimpleITK crop dataset is not part of this round; pass data_iter_factory')
-    num_samples = int(getattr(cfg.dataset, 'num_samples', cfg.train.batchsize))
-    for crops, masks in data_iter_factory(cfg):
+        from segmentation3d.dataloader.dataset import SegmentationDataset, DeviceCropLoader
+        from segmentation3d.dataloader.sampler import EpochConcateSampler, EpochConcateDistributedSampler
+        dataset = SegmentationDataset(
+            imlist_file=cfg.general.imseg_list, num_classes=cfg.dataset.num_classes, spacing=cfg.dataset.spacing,
+            crop_size=cfg.dataset.crop_size, sampling_method=cfg.dataset.sampling_method,
+            random_translation=cfg.dataset.random_translation, random_scale=cfg.dataset.random_scale,
+            interpolation=cfg.dataset.interpolation, crop_normalizers=cfg.dataset.crop_normalizers, device=step.device)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            sampler = EpochConcateDistributedSampler(dataset, cfg.train.epochs, max(0, cfg.general.resume_epoch))
+        else:
+            sampler = EpochConcateSampler(dataset, cfg.train.epochs)
+        batches = DeviceCropLoader(dataset, sampler, cfg.train.batchsize)
+        num_samples = len(dataset)
+    else:
+        batches = data_iter_factory(cfg)
+        num_samples = int(getattr(cfg.dataset, 'num_samples', cfg.train.batchsize))
+    for batch in batches:
+        crops, masks = batch[0], batch[1]
         begin_t = time.time()
         crops, masks = crops.to(step.device, non_blocking=True), masks.to(step.device, non_blocking=True)
         loss = step(crops, masks)

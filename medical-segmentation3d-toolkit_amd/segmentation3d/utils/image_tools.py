@@ -208,3 +208,79 @@ def get_bounding_box_device(mask, selected_labels):
 def get_bounding_box(mask, selected_labels):
     """bounding box of the selected labels (None: every non-zero voxel), end exclusive (image_tools.py:481-510)"""
     return get_bounding_box_device(_mask_to_device(mask), selected_labels)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training crops on the device (SURVEY.md 8f row f2): crop_image (image_tools.py:103-141) + the crop normalisers
+# ---------------------------------------------------------------------------------------------------------------------
+def crop_origin(cropping_center, cropping_size, cropping_spacing):
+    """world position of the crop's first voxel (image_tools.py:121-126): centre - size/2, moved in by half a voxel;
+    like the reference this ignores the image direction"""
+    out = []
+    for idx in range(3):
+        physical = int(cropping_size[idx]) * float(cropping_spacing[idx])
+        out.append(float(cropping_center[idx]) - physical / 2.0 + float(cropping_spacing[idx]) / 2.0)
+    return out
+
+
+def crop_image_device(volume, frame, cropping_center, cropping_size, cropping_spacing, interp_method):
+    """volume: float32 device tensor [Z, Y, X] with frame (spacing, origin, direction) -> crop [z, y, x] of
+    `cropping_size` voxels at `cropping_spacing`, centred at the world point `cropping_center`, zero outside"""
+    size = [int(cropping_size[idx]) for idx in range(3)]
+    spacing = [float(cropping_spacing[idx]) for idx in range(3)]
+    dst_frame = (spacing, crop_origin(cropping_center, size, spacing), frame[2])
+    return resample_device(volume, frame, size, dst_frame, interp_method, 0.0)
+
+
+def crop_image(image, cropping_center, cropping_size, cropping_spacing, interp_method):
+    """Image3d in, Image3d out (reference: image_tools.py:103-141)"""
+    assert isinstance(image, Image3d)
+    src = torch.from_numpy(np.array(image.array, dtype=np.float32, order='C')).to(_device())
+    out = crop_image_device(src, _frame(image), cropping_center, cropping_size, cropping_spacing, interp_method)
+    spacing = [float(cropping_spacing[idx]) for idx in range(3)]
+    return Image3d(out.cpu().numpy(), spacing, crop_origin(cropping_center, cropping_size, spacing), image.GetDirection())
+
+
+def normalize_crop_device(crop, normalizer):
+    """apply a FixedNormalizer / AdaptiveNormalizer (utils/normalizer.py) to a float32 device crop [z, y, x] with the
+    patch kernel of the inference path (csrc/patch.hip: fp64 statistics, population std floored at 1e-6)"""
+    d = normalizer.to_dict() if hasattr(normalizer, 'to_dict') else dict(normalizer)
+    crop = crop.contiguous()
+    bz, by, bx = crop.shape
+    if d['type'] == 0:
+        ntype, mean, std, clip, sigma = 0, float(d['mean']), float(d['stddev']), int(bool(d['clip'])), 1.0
+    elif d['type'] == 1:
+        ntype, mean, std, clip, sigma = 1, 0.0, 1.0, 1, float(d['clip_sigma'])
+    else:
+        raise ValueError('Unsupported normalization type.')
+    dev = crop.device
+    out = torch.empty((1, 1, bz, by, bx), dtype=torch.float32, device=dev)
+    starts = torch.zeros((1, 3), dtype=torch.int32, device=dev)
+    ws = torch.empty((E.query('seg3d_patch_stats_blocks', bx, by, bz) * 2,), dtype=torch.float64, device=dev)
+    mean_std = torch.empty((1, 2), dtype=torch.float32, device=dev)
+    E.call('seg3d_patch_gather_normalize', E.ptr(crop), E.ptr(starts), E.ptr(out), E.ptr(ws), E.ptr(mean_std), bz, by, bx,
+           bx, by, bz, 1, ntype, mean, std, clip, sigma, E.stream_ptr())
+    return out[0, 0]
+
+
+def get_image_frame(image):
+    """spacing, origin, direction packed into 15 float32 (image_tools.py:26-41)"""
+    return np.array(list(image.GetSpacing()) + list(image.GetOrigin()) + list(image.GetDirection()), dtype=np.float32)
+
+
+def set_image_frame(image, frame):
+    """inverse of get_image_frame (image_tools.py:44-61)"""
+    frame = np.asarray(frame)
+    image.spacing = tuple(float(v) for v in frame[:3])
+    image.origin = tuple(float(v) for v in frame[3:6])
+    image.direction = tuple(float(v) for v in frame[6:15])
+
+
+def select_random_voxels_in_multi_class_mask(mask, num_selected, selected_label):
+    """`num_selected` random voxels (x, y, z) carrying `selected_label` (image_tools.py:246-271; numpy global RNG)"""
+    mask_npy = mask.array if isinstance(mask, Image3d) else np.asarray(mask)
+    valid_voxels = np.argwhere(mask_npy == selected_label)
+    selected_voxels = []
+    while len(valid_voxels) > 0 and len(selected_voxels) < num_selected:
+        selected_voxels.append(valid_voxels[np.random.randint(0, len(valid_voxels))][::-1])
+    return selected_voxels

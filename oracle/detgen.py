@@ -87,3 +87,15 @@ def metric_label_cases():
     cases.append(('float_labels', g.astype(np.float32), mix.astype(np.float32), [0, 2], 10))
     cases.append(('int16_odd_size', g[:37, :41, :53].astype(np.int16), mix[:37, :41, :53].astype(np.int16), [0, 1, 2, 3], 10))
     return cases
+
+
+def sampling_cases():
+    """(name, size xyz, spacing, origin, direction, crop_size, crop_spacing, seed)"""
+    eye = [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0]
+    flip = [-1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0]
+    return [
+        ('big_iso', (200, 180, 160), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), eye, (96, 96, 96), (1.0, 1.0, 1.0), 11),
+        ('aniso_offset', (120, 90, 60), (0.7, 0.9, 2.5), (-31.5, 12.0, 100.0), eye, (64, 48, 32), (1.2, 1.2, 1.2), 12),
+        ('smaller_than_crop', (60, 200, 40), (1.0, 1.0, 1.0), (5.0, 5.0, 5.0), eye, (96, 96, 96), (1.0, 1.0, 1.0), 13),
+        ('flipped_x', (100, 100, 100), (0.8, 0.8, 0.8), (40.0, -40.0, 0.0), flip, (48, 48, 48), (1.0, 1.0, 1.0), 14),
+    ]

@@ -233,6 +233,68 @@ def gen_metrics():
         json.dump(out, f)
 
 
+def gen_sampling():
+    """crop-centre helpers of the reference executed through `ast` (their modules import SimpleITK): the two methods
+    SegmentationDataset.global_sample / center_sample on a duck-typed image, and
+    select_random_voxels_in_multi_class_mask on a numpy mask -- with numpy's seeded global RNG"""
+    import types
+    src = open(os.path.join(REF, 'segmentation3d', 'dataloader', 'dataset.py')).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == 'SegmentationDataset'][0]
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ('global_sample', 'center_sample')]
+
+    class _Duck(object):
+        def __init__(self, size, spacing, origin, direction):
+            self._s, self._sp, self._o, self._d = size, spacing, origin, np.asarray(direction, dtype=np.float64).reshape(3, 3)
+
+        def GetSize(self):
+            return self._s
+
+        def GetSpacing(self):
+            return self._sp
+
+        def GetOrigin(self):
+            return self._o
+
+        def TransformIndexToPhysicalPoint(self, index):
+            return tuple(np.asarray(self._o) + self._d @ (np.asarray(self._sp) * np.asarray(index, dtype=np.float64)))
+
+    class _Sitk(object):
+        Image = _Duck
+
+        @staticmethod
+        def GetArrayFromImage(image):
+            return image
+    ns = {'np': np, 'sitk': _Sitk}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), 'dataset.py', 'exec'), ns)
+    src2 = open(os.path.join(REF, 'segmentation3d', 'utils', 'image_tools.py')).read()
+    fn2 = [n for n in ast.parse(src2).body if isinstance(n, ast.FunctionDef) and n.name == 'select_random_voxels_in_multi_class_mask'][0]
+
+    class _Arr(np.ndarray):
+        pass
+    _Sitk.Image = (_Duck, np.ndarray)          # isinstance(mask, sitk.Image) must accept the numpy mask
+    ns2 = {'np': np, 'sitk': _Sitk}
+    exec(compile(ast.Module(body=[fn2], type_ignores=[]), 'image_tools.py', 'exec'), ns2)
+    out = {}
+    for name, size, spacing, origin, direction, crop_size, crop_spacing, seed in detgen.sampling_cases():
+        me = types.SimpleNamespace(crop_size=np.array(crop_size, dtype=np.int32), spacing=np.array(crop_spacing, dtype=np.double))
+        img = _Duck(size, spacing, origin, direction)
+        np.random.seed(seed)
+        g = [[float(v) for v in ns['global_sample'](me, img)] for _ in range(3)]
+        c = [float(v) for v in ns['center_sample'](me, img)]
+        out[name] = {'global': g, 'center': c}
+        print('sampling', name, g[0], c)
+    mask = detgen.labels(601, 'sampling/mask', (20, 24, 28), 4).astype(np.int8)
+    np.random.seed(21)
+    picks = []
+    for label in (1, 2, 3, 1, 9):
+        sel = ns2['select_random_voxels_in_multi_class_mask'](mask, 1, label)
+        picks.append([int(label), [int(v) for v in sel[0]] if len(sel) else None])
+    out['select_voxels'] = {'seed': 21, 'picks': picks, 'after': float(np.random.uniform())}
+    print('select', picks)
+    with open(os.path.join(OUT, 'sampling.json'), 'w') as f:
+        json.dump(out, f)
+
+
 def gen_shapes():
     from segmentation3d.network import vnet, vbnet
     out = {}
@@ -249,7 +311,7 @@ def gen_shapes():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['blocks', 'nets', 'losses', 'partitions', 'shapes', 'metrics']
+    which = sys.argv[1:] or ['blocks', 'nets', 'losses', 'partitions', 'shapes', 'metrics', 'sampling']
     if 'blocks' in which:
         gen_blocks()
     if 'nets' in which:
@@ -262,3 +324,5 @@ if __name__ == '__main__':
         gen_shapes()
     if 'metrics' in which:
         gen_metrics()
+    if 'sampling' in which:
+        gen_sampling()

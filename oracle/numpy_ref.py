@@ -253,3 +253,42 @@ def segmentation_volume(image, frame, net_fn, num_classes, model_spacing, partit
     if remove_small_cc > 0 and labels:
         mask = connected_component_filter(mask, labels, 'min_size', remove_small_cc)
     return out, mask
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training crops: dataloader/dataset.py:110-200, utils/image_tools.py:103-141, 246-271
+# ---------------------------------------------------------------------------------------------------------------------
+def crop_origin(center, size, spacing):
+    return [float(center[d]) - int(size[d]) * float(spacing[d]) / 2.0 + float(spacing[d]) / 2.0 for d in range(3)]
+
+
+def crop_image(volume, frame, center, size, spacing, linear):
+    """restates crop_image: sitk.Resample(image, size, identity, interp, origin, spacing, image direction), pad 0"""
+    dst_frame = ([float(v) for v in spacing], crop_origin(center, size, spacing), frame[2])
+    return resample_affine(volume, index_affine(frame, dst_frame), [int(v) for v in size], linear, 0.0)
+
+
+def global_sample(size, spacing, origin, crop_size, crop_spacing, rng):
+    """dataset.py:110-127; rng: np.random-like (uniform)"""
+    im_mm = [size[d] * spacing[d] for d in range(3)]
+    crop_mm = np.asarray(crop_size, dtype=np.double) * np.asarray(crop_spacing, dtype=np.double)
+    sp = np.array(origin, dtype=np.double)
+    for d in range(3):
+        if im_mm[d] > crop_mm[d]:
+            sp[d] = origin[d] + rng.uniform(0, im_mm[d] - crop_mm[d])
+    return sp + crop_mm / 2
+
+
+def center_sample(size, spacing, origin, direction):
+    """dataset.py:129-142"""
+    end_world = np.asarray(origin, dtype=np.double) + np.asarray(direction, dtype=np.double).reshape(3, 3) @ (
+        np.asarray(spacing, dtype=np.double) * (np.asarray(size, dtype=np.double) - 1))
+    return (np.asarray(origin, dtype=np.double) + end_world) / 2.0
+
+
+def select_random_voxel(mask, label, rng):
+    """image_tools.py:246-271 with num_selected = 1: (x, y, z) or None; consumes one randint only when the label exists"""
+    valid = np.argwhere(np.asarray(mask) == label)
+    if len(valid) == 0:
+        return None
+    return [int(v) for v in valid[rng.randint(0, len(valid))][::-1]]

@@ -149,7 +149,8 @@ extern "C" int seg3d_pack_weights_mfma(const float* w, float* wp, int A, int B, 
 
 // Many weight tensors in ONE launch (after an optimizer step every conv weight has to be re-packed, for the forward
 // and for the data-gradient orientation: 52 tiny launches per V-Net step otherwise).  `jobs` is a device array;
-// job k owns the workgroups [first_block[k], first_block[k+1]) and each workgroup packs 1024 consecutive elements.
+// job k owns the workgroups [first_block[k], first_block[k+1]) and each workgroup packs 1024 consecutive elements (one
+// float4 per thread: four independent strided gathers, one 16-byte store).
 __global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob* __restrict__ jobs, int njobs) {
   __shared__ int sjob;
   if (threadIdx.x == 0) {
@@ -162,26 +163,33 @@ __global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob
   }
   __syncthreads();
   const Seg3dPackJob jb = jobs[sjob];
-  const int AB = (jb.A + 7) / 8, BB = (jb.B + 31) / 32, T = jb.T;
-  const i64 total = (i64)BB * AB * T * 256;
-  const i64 base = ((i64)blockIdx.x - jb.first_block) * 1024;
+  const int AB = (jb.A + 7) / 8, T = jb.T;
+  const i64 total4 = (i64)((jb.B + 31) / 32) * AB * T * 64;          // float4 elements of the packed image
+  const i64 q4 = ((i64)blockIdx.x - jb.first_block) * 256 + threadIdx.x;  // one float4 (r = 0..3) per thread
+  if (q4 >= total4) return;
+  // packed index = (((bb * AB + ab) * T + t) * 2 + h) * 32 + j, times 4 + r
+  const int j = (int)(q4 & 31);
+  const int h = (int)((q4 >> 5) & 1);
+  i64 rest = q4 >> 6;
+  const int t = (int)(rest % T);
+  rest /= T;
+  const int ab = (int)(rest % AB);
+  const int bb = (int)(rest / AB);
+  const int a0 = ab * 8 + h * 4, b = bb * 32 + j;
+  const i64 base = b * jb.sb + (jb.flip ? T - 1 - t : t);
+  // four independent gathers issued back to back (clamped address, select afterwards)
+  float v[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const i64 idx = base + k * 256 + threadIdx.x;
-    if (idx >= total) break;
-    const int r = (int)(idx & 3);
-    const int j = (int)((idx >> 2) & 31);
-    const int h = (int)((idx >> 7) & 1);
-    i64 rest = idx >> 8;
-    const int t = (int)(rest % T);
-    rest /= T;
-    const int ab = (int)(rest % AB);
-    const int bb = (int)(rest / AB);
-    const int a = ab * 8 + h * 4 + r, b = bb * 32 + j;
-    float v = 0.f;
-    if (a < jb.A && b < jb.B) v = jb.w[a * jb.sa + b * jb.sb + (jb.flip ? T - 1 - t : t)];
-    jb.wp[idx] = v;
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = a0 + r < jb.A && b < jb.B;
+    v[r] = jb.w[ok ? (a0 + r) * jb.sa + base : 0];
   }
+  float4 o;
+  o.x = (a0 + 0 < jb.A && b < jb.B) ? v[0] : 0.f;
+  o.y = (a0 + 1 < jb.A && b < jb.B) ? v[1] : 0.f;
+  o.z = (a0 + 2 < jb.A && b < jb.B) ? v[2] : 0.f;
+  o.w = (a0 + 3 < jb.A && b < jb.B) ? v[3] : 0.f;
+  reinterpret_cast<float4*>(jb.wp)[q4] = o;
 }
 
 extern "C" long long seg3d_pack_job_blocks(int A, int B, int T) {

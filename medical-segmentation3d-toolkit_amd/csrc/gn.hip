@@ -51,19 +51,37 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(const float* __re
 }
 
 // mean_rstd[n] = (mean, rstd) from `count` partial (sum, sumsq) pairs per sample; fp64, fixed order.
-__global__ __launch_bounds__(64) void gn_stats_finalize_kernel(const float* __restrict__ part,
-                                                                 float* __restrict__ mean_rstd, int count, double M,
-                                                                 double eps) {
+__global__ __launch_bounds__(256) void gn_stats_finalize_kernel(const float* __restrict__ part,
+                                                                  float* __restrict__ mean_rstd, int count, double M,
+                                                                  double eps) {
+  // 256 threads per sample, 4 independent float2 loads in flight per thread (the kernel is pure latency: up to ~7000
+  // partial pairs per sample behind one dependent chain per thread), fixed combination order -> reproducible
+  __shared__ double red[8];
   const int n = blockIdx.x;
-  const float* p = part + (i64)n * count * 2;
+  const float2* p = reinterpret_cast<const float2*>(part + (i64)n * count * 2);
   double s = 0.0, ss = 0.0;
-  for (int k = threadIdx.x; k < count; k += 64) {
-    s += (double)p[2 * k];
-    ss += (double)p[2 * k + 1];
+  int k = threadIdx.x;
+  for (; k + 768 < count; k += 1024) {
+    const float2 a = p[k], b = p[k + 256], c = p[k + 512], d = p[k + 768];
+    s += ((double)a.x + (double)b.x) + ((double)c.x + (double)d.x);
+    ss += ((double)a.y + (double)b.y) + ((double)c.y + (double)d.y);
+  }
+  for (; k < count; k += 256) {
+    const float2 a = p[k];
+    s += (double)a.x;
+    ss += (double)a.y;
   }
   s = wave_sum_d(s);
   ss = wave_sum_d(ss);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[wave] = s;
+    red[4 + wave] = ss;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    ss = (red[4] + red[5]) + (red[6] + red[7]);
     const double mean = s / M;
     double var = ss / M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -86,7 +104,7 @@ extern "C" int seg3d_gn_stats_partial(const float* y, float* part, int N, long l
 extern "C" int seg3d_gn_stats_finalize(const float* part, float* mean_rstd, int N, int count, long long M, float eps,
                                        void* stream) {
   SEG3D_REQUIRE(part && mean_rstd && N > 0 && count > 0 && M > 0, "seg3d_gn_stats_finalize: bad arguments");
-  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, part, mean_rstd, count,
+  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, part, mean_rstd, count,
                      (double)M, (double)eps);
   SEG3D_LAUNCH_CHECK("seg3d_gn_stats_finalize");
   return SEG3D_OK;
@@ -333,7 +351,19 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_sample_kernel(const float
     double A = 0.0, B = 0.0, X = 0.0;
     if (pg < PARTS && c < C) {
       const float* p = part + ((i64)n * nblk * C + c) * 3;
-      for (int k = pg; k < nblk; k += PARTS) {
+      int k = pg;
+      for (; k + 3 * PARTS < nblk; k += 4 * PARTS) {   // 12 independent loads in flight (latency-bound kernel)
+        const float* q0 = p + (i64)k * C * 3;
+        const float* q1 = q0 + (i64)PARTS * C * 3;
+        const float* q2 = q1 + (i64)PARTS * C * 3;
+        const float* q3 = q2 + (i64)PARTS * C * 3;
+        const float a0 = q0[0], b0 = q0[1], x0 = q0[2], a1 = q1[0], b1 = q1[1], x1 = q1[2];
+        const float a2 = q2[0], b2 = q2[1], x2 = q2[2], a3 = q3[0], b3 = q3[1], x3 = q3[2];
+        A += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        B += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        X += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
+      }
+      for (; k < nblk; k += PARTS) {
         A += (double)p[(i64)k * C * 3 + 0];
         B += (double)p[(i64)k * C * 3 + 1];
         X += (double)p[(i64)k * C * 3 + 2];

@@ -120,17 +120,19 @@ long long seg3d_gn_stats_count(long long M);
 int seg3d_gn_stats_partial(const float* y, float* part, int N, long long M, void* stream);
 int seg3d_gn_stats_finalize(const float* part, float* mean_rstd, int N, int count, long long M, float eps, void* stream);
 int seg3d_gn_apply(const float* y, const float* mean_rstd, const float* gamma, const float* beta, const float* res,
-                   float* out, int N, long long S, int C, int relu, void* stream);
+                   float* out, int N, long long S, int C, int relu,
+                   int ld_out /* floats between consecutive voxels of `out`; 0 = C (a channel slice of a wider buffer) */,
+                   void* stream);
 long long seg3d_gn_bwd_blocks(long long S);
 int seg3d_gn_bwd_reduce(const float* dout, const float* out /* NULL: recompute the ReLU mask from y */, const float* y,
                         const float* mean_rstd, const float* gamma, const float* beta, float* part, int N, long long S,
-                        int C, int relu, void* stream);
+                        int C, int relu, int ld_dout /* row stride of dout in floats, 0 = C */, void* stream);
 int seg3d_gn_bwd_finalize(const float* part, const float* gamma, const float* mean_rstd, float* abx, float* s12,
                           float* dgamma, float* dbeta, float* dbias, int N, long long S, int C,
                           int acc_mask /* bit 0/1/2: accumulate into dgamma/dbeta/dbias */, void* stream);
 int seg3d_gn_bwd_apply(const float* dout, const float* out /* NULL: recompute */, const float* y, const float* mean_rstd,
                        const float* s12, const float* gamma, const float* beta, float* dy, float* dres, int N, long long S,
-                       int C, int relu, void* stream);
+                       int C, int relu, int ld_dout /* row stride of dout in floats, 0 = C */, void* stream);
 
 /* ---- head softmax (network/module/vnet_outblock.py:18,23) ---------------------------------------------------------- */
 int seg3d_softmax_fwd(const float* in_ndhwc, float* probs_ncdhw, int N, int C, long long S, void* stream);

@@ -115,7 +115,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean_rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ res, float* __restrict__ out, i64 S,
-                                                         int C, i64 total_vox, int relu) {
+                                                         int C, i64 total_vox, int relu, int ldo) {
   if (VEC) {
     const int CQ = C >> 2;
     const i64 total = total_vox * CQ;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       if (relu) {
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
       }
-      *reinterpret_cast<float4*>(out + idx * 4) = o;
+      *reinterpret_cast<float4*>(out + v * ldo + 4 * q) = o;
     }
   } else {
     const i64 total = total_vox * C;
@@ -151,22 +151,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       float o = (y[idx] - mean) * rstd * gamma[c] + beta[c];
       if (res) o += res[idx];
       if (relu) o = fmaxf(o, 0.f);
-      out[idx] = o;
+      out[v * ldo + c] = o;
     }
   }
 }
 
 extern "C" int seg3d_gn_apply(const float* y, const float* mean_rstd, const float* gamma, const float* beta,
-                              const float* res, float* out, int N, long long S, int C, int relu, void* stream) {
+                              const float* res, float* out, int N, long long S, int C, int relu, int ld_out,
+                              void* stream) {
   SEG3D_REQUIRE(y && mean_rstd && gamma && beta && out && N > 0 && S > 0 && C > 0, "seg3d_gn_apply: bad arguments");
+  SEG3D_REQUIRE(ld_out == 0 || (ld_out >= C && (ld_out & 3) == 0), "seg3d_gn_apply: ld_out must be 0 or a multiple of 4 >= C");
+  const int ldo = ld_out ? ld_out : C;
   const i64 total_vox = (i64)N * S;
   hipStream_t s = (hipStream_t)stream;
   if ((C & 3) == 0) {
     hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(seg3d_ew_grid(total_vox * (C / 4), 256)), dim3(256), 0, s, y, mean_rstd,
-                       gamma, beta, res, out, (i64)S, C, total_vox, relu);
+                       gamma, beta, res, out, (i64)S, C, total_vox, relu, ldo);
   } else {
     hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(seg3d_ew_grid(total_vox * C, 256)), dim3(256), 0, s, y, mean_rstd,
-                       gamma, beta, res, out, (i64)S, C, total_vox, relu);
+                       gamma, beta, res, out, (i64)S, C, total_vox, relu, ldo);
   }
   SEG3D_LAUNCH_CHECK("seg3d_gn_apply");
   return SEG3D_OK;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __r
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta,
                                                                   float* __restrict__ part, i64 S, int C, int nblk,
-                                                                  int relu, int vpb) {
+                                                                  int relu, int vpb, int ldd) {
   __shared__ float red[256 * 12];
   const int n = blockIdx.y;
   const int CQ = C >> 2, VL = 256 / CQ;
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __r
       const i64 svu = sv + u * VL;
       ok[u] = svu < s1;
       const i64 off = ((i64)n * S + (ok[u] ? svu : s0)) * C + 4 * q;
-      g[u] = *reinterpret_cast<const float4*>(dout + off);
+      g[u] = *reinterpret_cast<const float4*>(dout + ((i64)n * S + (ok[u] ? svu : s0)) * ldd + 4 * q);
       yv[u] = *reinterpret_cast<const float4*>(y + off);
       if (relu && out) o[u] = *reinterpret_cast<const float4*>(out + off);
     }
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_small_kernel(const float* _
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta,
                                                                     float* __restrict__ part, i64 S, int C, int nblk,
-                                                                    int relu, int vpb) {
+                                                                    int relu, int vpb, int ldd) {
   __shared__ float red[4 * 3];
   const int n = blockIdx.y;
   const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_small_kernel(const float* _
 #pragma unroll
     for (int c = 0; c < GN_SMALLC; ++c) {
       if (c < C) {
-        float g = dout[off + c];
+        float g = dout[((i64)n * S + sv) * ldd + c];
         const float ov = out ? out[off + c] : (y[off + c] - mean) * rstd * gamma[c] + beta[c];
         if (relu && !(ov > 0.f)) g = 0.f;
         const float xh = (y[off + c] - mean) * rstd;
@@ -315,17 +318,20 @@ static bool gn_vec_ok(int C) { return (C & 3) == 0 && (C >> 2) <= 256 && (256 % 
 // mask is recomputed from y, gamma, beta.
 extern "C" int seg3d_gn_bwd_reduce(const float* dout, const float* out, const float* y, const float* mean_rstd,
                                    const float* gamma, const float* beta, float* part, int N, long long S, int C,
-                                   int relu, void* stream) {
+                                   int relu, int ld_dout, void* stream) {
   SEG3D_REQUIRE(dout && y && mean_rstd && part && N > 0 && S > 0 && C > 0, "seg3d_gn_bwd_reduce: bad arguments");
+  SEG3D_REQUIRE(ld_dout == 0 || (ld_dout >= C && (ld_dout & 3) == 0),
+                "seg3d_gn_bwd_reduce: ld_dout must be 0 or a multiple of 4 >= C");
+  const int ldd = ld_dout ? ld_dout : C;
   SEG3D_REQUIRE(!relu || out || (gamma && beta), "seg3d_gn_bwd_reduce: relu mask needs the forward output or gamma/beta");
   const int nblk = (int)seg3d_gn_bwd_blocks(S);
   hipStream_t s = (hipStream_t)stream;
   if (gn_vec_ok(C)) {
     hipLaunchKernelGGL(gn_bwd_reduce_vec_kernel, dim3(nblk, N), dim3(256), 0, s, dout, out, y, mean_rstd, gamma, beta, part,
-                       (i64)S, C, nblk, relu, gn_bwd_vpb(S));
+                       (i64)S, C, nblk, relu, gn_bwd_vpb(S), ldd);
   } else if (C <= GN_SMALLC) {
     hipLaunchKernelGGL(gn_bwd_reduce_small_kernel, dim3(nblk, N), dim3(256), 0, s, dout, out, y, mean_rstd, gamma, beta,
-                       part, (i64)S, C, nblk, relu, gn_bwd_vpb(S));
+                       part, (i64)S, C, nblk, relu, gn_bwd_vpb(S), ldd);
   } else {
     SEG3D_UNSUPPORTED("seg3d_gn_bwd_reduce: unsupported channel count %d (need C<=16 or C%%4==0 with C/4 | 256)", C);
   }
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ dy,
                                                              float* __restrict__ dres, i64 S, int C, i64 total_vox,
-                                                             int relu) {
+                                                             int relu, int ldd) {
   if (VEC) {
     const int CQ = C >> 2;
     const i64 total = total_vox * CQ;
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       const int n = (int)(v / S);
       const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
       const float s1 = s12[2 * n], s2 = s12[2 * n + 1];
-      float4 g = *reinterpret_cast<const float4*>(dout + idx * 4);
+      float4 g = *reinterpret_cast<const float4*>(dout + v * ldd + 4 * q);
       const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
       const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * q);
       if (relu) {
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       const int c = (int)(idx - v * C);
       const int n = (int)(v / S);
       const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
-      float g = dout[idx];
+      float g = dout[v * ldd + c];
       const float ov = out ? out[idx] : (y[idx] - mean) * rstd * gamma[c] + beta[c];
       if (relu && !(ov > 0.f)) g = 0.f;
       dy[idx] = rstd * (gamma[c] * g - s12[2 * n] - (y[idx] - mean) * rstd * s12[2 * n + 1]);
@@ -492,17 +498,20 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 
 extern "C" int seg3d_gn_bwd_apply(const float* dout, const float* out, const float* y, const float* mean_rstd,
                                   const float* s12, const float* gamma, const float* beta, float* dy, float* dres, int N,
-                                  long long S, int C, int relu, void* stream) {
+                                  long long S, int C, int relu, int ld_dout, void* stream) {
   SEG3D_REQUIRE(dout && y && mean_rstd && s12 && gamma && dy && N > 0 && S > 0 && C > 0, "seg3d_gn_bwd_apply: bad arguments");
+  SEG3D_REQUIRE(ld_dout == 0 || (ld_dout >= C && (ld_dout & 3) == 0),
+                "seg3d_gn_bwd_apply: ld_dout must be 0 or a multiple of 4 >= C");
+  const int ldd = ld_dout ? ld_dout : C;
   SEG3D_REQUIRE(!relu || out || beta, "seg3d_gn_bwd_apply: relu mask needs the forward output or beta");
   const i64 total_vox = (i64)N * S;
   hipStream_t s = (hipStream_t)stream;
   if ((C & 3) == 0) {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), dim3(seg3d_ew_grid(total_vox * (C / 4), 256)), dim3(256), 0, s, dout, out,
-                       y, mean_rstd, s12, gamma, beta, dy, dres, (i64)S, C, total_vox, relu);
+                       y, mean_rstd, s12, gamma, beta, dy, dres, (i64)S, C, total_vox, relu, ldd);
   } else {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<false>), dim3(seg3d_ew_grid(total_vox * C, 256)), dim3(256), 0, s, dout, out, y,
-                       mean_rstd, s12, gamma, beta, dy, dres, (i64)S, C, total_vox, relu);
+                       mean_rstd, s12, gamma, beta, dy, dres, (i64)S, C, total_vox, relu, ldd);
   }
   SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_apply");
   return SEG3D_OK;

@@ -63,11 +63,11 @@ _SIGNATURES = {
     'seg3d_gn_stats_count': (_c_ll, [_c_ll]),
     'seg3d_gn_stats_partial': (_c_int, [_c_p, _c_p, _c_int, _c_ll, _c_p]),
     'seg3d_gn_stats_finalize': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),
-    'seg3d_gn_apply': (_c_int, [_c_p] * 6 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
+    'seg3d_gn_apply': (_c_int, [_c_p] * 6 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_p]),
     'seg3d_gn_bwd_blocks': (_c_ll, [_c_ll]),
-    'seg3d_gn_bwd_reduce': (_c_int, [_c_p] * 7 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
+    'seg3d_gn_bwd_reduce': (_c_int, [_c_p] * 7 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_p]),
     'seg3d_gn_bwd_finalize': (_c_int, [_c_p] * 8 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
-    'seg3d_gn_bwd_apply': (_c_int, [_c_p] * 9 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
+    'seg3d_gn_bwd_apply': (_c_int, [_c_p] * 9 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_p]),
     'seg3d_softmax_fwd': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
     'seg3d_softmax_bwd': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
     'seg3d_dice_blocks': (_c_ll, [_c_ll]),

@@ -419,12 +419,33 @@ def gn_stats(yn, stats_partial=None, eps=GN_EPS):
     return mean_rstd
 
 
-def gn_apply(yn, mean_rstd, gamma, beta, resn, relu):
+def gn_apply(yn, mean_rstd, gamma, beta, resn, relu, out=None):
+    """out: optional destination -- a channel slice [..., c0:c0+C] of a wider contiguous NDHWC buffer (the up-branch
+    half of a skip concatenation is normalised straight into the concatenated tensor)"""
     N, D, H, W_, C = yn.shape
-    out = torch.empty_like(yn)
+    ld = 0
+    if out is None:
+        out = torch.empty_like(yn)
+    else:
+        if tuple(out.shape) != tuple(yn.shape) or out.stride(4) != 1 or out.stride(3) < C or out.stride(3) % 4 or \
+                out.stride(2) != W_ * out.stride(3) or out.stride(1) != H * out.stride(2) or out.stride(0) != D * out.stride(1):
+            raise ValueError('gn_apply destination must be a channel slice of a contiguous NDHWC buffer')
+        ld = out.stride(3)
     E.call('seg3d_gn_apply', E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta), E.ptr(resn), E.ptr(out), N,
-           D * H * W_, C, int(relu), E.stream_ptr())
+           D * H * W_, C, int(relu), ld, E.stream_ptr())
     return out
+
+
+def _row_stride(t, C):
+    """0 for a contiguous [N,D,H,W,C] tensor, else the voxel stride of a channel slice of a wider contiguous buffer"""
+    if t.is_contiguous():
+        return 0
+    N, D, H, W_, _ = t.shape
+    ld = t.stride(3)
+    if t.stride(4) != 1 or ld < C or ld % 4 or t.stride(2) != W_ * ld or t.stride(1) != H * t.stride(2) or \
+            t.stride(0) != D * t.stride(1) or (t.storage_offset() % 4):
+        raise ValueError('expected a contiguous NDHWC tensor or a channel slice of one')
+    return ld
 
 
 def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_dbias=True, sinks=(None, None, None)):
@@ -437,8 +458,9 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
     nblk = E.query('seg3d_gn_bwd_blocks', S)
     part = _empty((N, nblk, C, 3), yn)
     mask_src = outn if relu else None
+    ldd = _row_stride(doutn, C)   # dout may be a channel slice of the concatenated gradient (UpCatFunction)
     E.call('seg3d_gn_bwd_reduce', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta),
-           E.ptr(part), N, S, C, int(relu), E.stream_ptr())
+           E.ptr(part), N, S, C, int(relu), ldd, E.stream_ptr())
     abx = _empty((N, C, 3), yn)
     s12 = _empty((N, 2), yn)
     sg, sb_, sc = sinks
@@ -454,7 +476,7 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
     dy = torch.empty_like(yn)
     dres = torch.empty_like(yn) if want_dres else None
     E.call('seg3d_gn_bwd_apply', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(s12), E.ptr(gamma),
-           E.ptr(beta), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), E.stream_ptr())
+           E.ptr(beta), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), ldd, E.stream_ptr())
     return (dy, dres, dgamma if sg is None else None, dbeta if sb_ is None else None,
             dbias if (want_dbias and sc is None) else None)
 
@@ -592,6 +614,57 @@ class ConvGnActFunction(torch.autograd.Function):
 def conv_gn_act(x, weight, bias, gamma, beta, residual=None, kind='k3', relu=True, eps=GN_EPS, link_in=None,
                 link_out=None):
     return ConvGnActFunction.apply(x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in, link_out)
+
+
+class UpCatFunction(torch.autograd.Function):
+    """cat((act(GroupNorm_1(convT(x) + bias)), skip), 1) -- the head of an UpBlock (network/module/vnet_upblock.py:19-21)
+    without the two copies of a separate concatenation: the normalised up-branch is written straight into its channel
+    slice of the concatenated buffer (gn_apply with a row stride) and only `skip` is copied; in backward GroupNorm
+    reads its gradient in place from the slice of the incoming gradient (row stride), and the skip gradient goes back
+    to autograd as a strided view of it (no copy either)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, skip, relu, eps):
+        E.require_device(x, weight, bias, gamma, beta, skip)
+        xn = to_ndhwc(x)
+        sn = to_ndhwc(skip)
+        w = weight.detach()
+        yn, partial = conv_forward(xn, w, None if bias is None else bias.detach(), 'convT', want_stats=True)
+        if sn.shape[:4] != yn.shape[:4]:
+            raise ValueError('cat: spatial shapes differ: {} vs {}'.format(tuple(from_ndhwc(yn).shape), tuple(skip.shape)))
+        mean_rstd = gn_stats(yn, partial, eps)
+        N, D, H, W_, Ca = yn.shape
+        Cb = sn.shape[4]
+        if Ca % 4 or Cb % 4:
+            raise ValueError('fused up + cat needs channel counts that are multiples of 4')
+        cat = _empty((N, D, H, W_, Ca + Cb), yn)
+        gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), None, relu, out=cat[..., :Ca])
+        E.call('seg3d_copy_channels', E.ptr(sn), E.ptr(cat), N * D * H * W_, Cb, Cb, 0, Ca + Cb, Ca, E.stream_ptr())
+        ctx.relu, ctx.has_bias, ctx.w_shape, ctx.ca = bool(relu), bias is not None, tuple(weight.shape), Ca
+        ctx.sinks = (G.lookup(weight), G.lookup(bias), G.lookup(gamma), G.lookup(beta))
+        ctx.save_for_backward(xn, w, gamma.detach(), beta.detach(), yn, mean_rstd)
+        return from_ndhwc(cat)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xn, w, gamma, beta, yn, mean_rstd = ctx.saved_tensors
+        dn = to_ndhwc(dout)                                  # [N, D, H, W, Ca + Cb], contiguous
+        sw, sb_, sg, sbt = ctx.sinks
+        dy, _, dgamma, dbeta, dbias = gn_backward(dn[..., :ctx.ca], None, yn, mean_rstd, gamma, beta, ctx.relu,
+                                                  want_dres=False, want_dbias=ctx.has_bias, sinks=_views(sg, sbt, sb_))
+        dx = from_ndhwc(conv_dgrad(dy, w, 'convT')) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if sw is not None:
+                _wgrad_to_sink(xn, dy, ctx.w_shape, 'convT', sw.view)
+            else:
+                dw = conv_wgrad(xn, dy, ctx.w_shape, 'convT')
+        dskip = from_ndhwc(dn[..., ctx.ca:]) if ctx.needs_input_grad[5] else None     # strided view, no copy
+        return dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta, dskip, None, None
+
+
+def up_cat(x, weight, bias, gamma, beta, skip, relu=True, eps=GN_EPS):
+    return UpCatFunction.apply(x, weight, bias, gamma, beta, skip, relu, eps)
 
 
 class ConvFunction(torch.autograd.Function):

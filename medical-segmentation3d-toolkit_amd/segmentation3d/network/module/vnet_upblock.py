@@ -20,7 +20,13 @@ class UpBlock(nn.Module):
             self.rblock = ResidualBlock3(out_channels, 3, 1, 1, num_convs)
 
     def forward(self, input, skip):
-        out = _ops.conv_gn_act(input, self.up_conv.weight, self.up_conv.bias, self.up_gn.weight, self.up_gn.bias,
-                               kind='convT', relu=True, eps=self.up_gn.eps)
-        out = _ops.cat_channels(out, skip)  # up first, then skip (vnet_upblock.py:21)
+        half = self.up_conv.weight.shape[1]
+        if half % 4 == 0 and skip.shape[1] % 4 == 0:
+            # up first, then skip (vnet_upblock.py:21), the up-branch normalised straight into the concatenated buffer
+            out = _ops.up_cat(input, self.up_conv.weight, self.up_conv.bias, self.up_gn.weight, self.up_gn.bias, skip,
+                              relu=True, eps=self.up_gn.eps)
+        else:
+            out = _ops.conv_gn_act(input, self.up_conv.weight, self.up_conv.bias, self.up_gn.weight, self.up_gn.bias,
+                                   kind='convT', relu=True, eps=self.up_gn.eps)
+            out = _ops.cat_channels(out, skip)
         return self.rblock(out)

@@ -228,6 +228,7 @@ extern "C" int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp, const
   const int ntz = seg3d_cdiv(Do, t.tz), nty = seg3d_cdiv(Ho, t.ty), ntx = seg3d_cdiv(Wo, t.tx);
   const int mt = t.tz * t.ty * t.tx;
   const size_t lds = (size_t)(8 * 8 * mt + K2_W_CHUNK + ((mt + 3) & ~3)) * 4;
+  SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "2x2x2 stride-2 MFMA kernels: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
   hipLaunchKernelGGL(conv3d_k2s2_mfma_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, stats, N, Do, Ho,
                      Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
@@ -408,6 +409,7 @@ extern "C" int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp, cons
                 "seg3d_convT3d_k2s2_mfma_fwd: tensor exceeds 2^31 elements");
   K2Tile t = k2_pick_tile(Di, Hi, Wi);
   const int ntz = seg3d_cdiv(Di, t.tz), nty = seg3d_cdiv(Hi, t.ty), ntx = seg3d_cdiv(Wi, t.tx);
+  SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "2x2x2 stride-2 MFMA kernels: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
   hipLaunchKernelGGL(convT3d_k2s2_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, stats, N, Di, Hi,
                      Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
@@ -621,6 +623,7 @@ extern "C" int seg3d_k2_mfma_wgrad(const float* P, const float* Q, float* dw, fl
   const int npairs = AB32 * BB32;
   const int ntz = seg3d_cdiv(Dq, K2W_TZ), nty = seg3d_cdiv(Hq, K2W_TY), ntx = seg3d_cdiv(Wq, K2W_TX);
   const int ntiles = N * ntz * nty * ntx;
+  SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "seg3d_k2_mfma_wgrad: more than 2^22 tiles");
   const int slabs = k2_wgrad_slabs(N, Dq, Hq, Wq, npairs);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k2_wgrad_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s, P, Q, workspace, N, Dq, Hq, Wq, CA, CB, ntz,

@@ -1350,6 +1350,7 @@ static Seg3dWgradPlan seg3d_wgrad_plan(int N, int D, int H, int W, int Cin, int 
       p.tz = 2, p.ty = 6, p.tx = 6;
     }
     const int ntiles = N * seg3d_cdiv(D, p.tz) * seg3d_cdiv(H, p.ty) * seg3d_cdiv(W, p.tx);
+    if (ntiles >= SEG3D_FDIV_MAX) return p;   // tile decoding by float reciprocal is exact below 2^22 only
     p.version = 2;
     p.nb = (COB32 % 2 == 0) ? 2 : 1;
     {

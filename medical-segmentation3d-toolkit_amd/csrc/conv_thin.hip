@@ -404,6 +404,7 @@ extern "C" int seg3d_conv3d_k3_thin_out_fwd(const float* x, const float* wq, con
   SEG3D_REQUIRE((Cin % 4) == 0 && Cout <= CO, "seg3d_conv3d_k3_thin_out_fwd: need Cin %% 4 == 0 and Cout <= CO");
   SEG3D_REQUIRE((i64)N * D * H * W * Cin < (1ll << 31), "seg3d_conv3d_k3_thin_out_fwd: tensor exceeds 2^31 elements");
   const int ntz = seg3d_cdiv(D, TO_TZ), nty = seg3d_cdiv(H, TO_TY), ntx = seg3d_cdiv(W, TO_TX);
+  SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "seg3d_conv3d_k3_thin_out_fwd: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx));
   hipStream_t s = (hipStream_t)stream;
   if (CO == 2) {

@@ -64,9 +64,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// v / d for 0 <= v < 2^20, 1 <= d <= 2^10 without the ~35-instruction integer division: r = 1.0f / d, and
-// (v + 0.5) * r is at least 0.5 / d away from an integer boundary while its float error stays below that, so the
-// truncation is exact.  Index decoding in kernels whose prologue is not hidden by other waves uses this.
+// v / d for 0 <= v < 2^22 (any divisor 1 <= d) without the ~35-instruction integer division: r = 1.0f / d, and
+// (v + 0.5) * r is at least 0.5 / d away from an integer boundary while its float error (two roundings,
+// <= (v / d) * 2^-23) stays below that for v < 2^22, so the truncation is exact.  Index decoding in kernels whose
+// prologue is not hidden by other waves uses this; launchers check SEG3D_FDIV_MAX.
+#define SEG3D_FDIV_MAX (1 << 22)
 __device__ __forceinline__ int seg3d_fdiv(int v, float r) { return (int)(((float)v + 0.5f) * r); }
 
 // Sum NV values over a 256-thread workgroup. Result valid in thread 0. `red` must hold 4*NV floats.

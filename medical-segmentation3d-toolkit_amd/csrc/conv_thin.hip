@@ -222,7 +222,7 @@ extern "C" int seg3d_conv3d_k3_thin_in_fwd(const float* x, const float* wp, cons
 // ---------------------------------------------------------------------------------------------------------------
 // thin-out forward (VALU): tile 4 x 8 x 16 = 512 voxels, 2 voxels per thread, 8 input channels per LDS chunk
 // ---------------------------------------------------------------------------------------------------------------
-#define TO_TZ 4
+#define TO_TZ 8
 #define TO_TY 8
 #define TO_TX 16
 #define TO_HY (TO_TY + 2)
@@ -260,6 +260,16 @@ extern "C" int seg3d_pack_weights_thin_out(const float* w, float* wq, int A, int
   return SEG3D_OK;
 }
 
+// Tile 8 x 8 x 16 outputs; a thread owns FOUR consecutive x outputs of one (z, y) row: per (kz, ky) it reads the six
+// input voxels of that row once (12 ds_read_b128 for 8 channels) and uses them for the three kx taps of all four
+// outputs (1/16 LDS read per FMA).  The halo row stride is padded to 19 voxels so that the 64 lanes of a ds_read_b128
+// hit 64 distinct banks (row stride 76 dwords, x-group stride 16 dwords).  Weights are wave-uniform: scalar loads.
+// Measured (round 1): 369 us for the 96^3 32 -> 2 head, 4x its HBM time.  PMC shows 2.8 GB fetched for a 453 MB input:
+// the 8-channel chunks read every 128-byte voxel row in four 32-byte passes, and with ~230 KB of halo rows per
+// workgroup x 64 workgroups per XCD the rows are evicted from the 4 MB L2 between passes.  Halving the LDS reads
+// (this version) therefore changed little; staging whole rows once is the fix that is still open.
+#define TO_PX (TO_TX + 3)                        // padded halo row: 19 voxels
+#define TO_NVP ((TO_TZ + 2) * TO_HY * TO_PX)     // 1900 padded halo voxels
 template <int CO>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float* __restrict__ x,
                                                                       const float* __restrict__ wq,
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
                                                                       float* __restrict__ y, float* __restrict__ stats,
                                                                       int N, int D, int H, int W, int Cin, int Cout,
                                                                       int ntz, int nty, int ntx) {
-  __shared__ __attribute__((aligned(16))) float xs[8 * TO_NV];      // [2][NV][4]
+  __shared__ __attribute__((aligned(16))) float xs[8 * TO_NVP];      // [2][NVP][4]  (60.8 KB)
   const int tid = threadIdx.x;
   int b = blockIdx.x;
   int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
@@ -280,33 +290,34 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
   const int z0 = tiz * TO_TZ, y0 = tiy * TO_TY, x0 = tix * TO_TX;
   const int CIB = (Cin + 7) >> 3;
   const int hh = tid & 1;
-  int goff[TO_E];
+  // staged float4 e = tid + 256 k: voxel v = e >> 1 of the UNPADDED halo (TO_HX = 18 per row), half hh
+  int goff[TO_E], loff[TO_E];
 #pragma unroll
   for (int e = 0; e < TO_E; ++e) {
     const int eidx = tid + e * 256;
     goff[e] = -1;
+    loff[e] = -1;
     if (eidx < 2 * TO_NV) {
       const int v = eidx >> 1;
       const int t = seg3d_fdiv(v, 1.0f / (float)TO_HX);
       const int hx = v - t * TO_HX;
       const int hz = seg3d_fdiv(t, 1.0f / (float)TO_HY);
       const int hy = t - hz * TO_HY;
+      loff[e] = (hh * TO_NVP + (hz * TO_HY + hy) * TO_PX + hx) * 4;
       const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
       if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
         goff[e] = (((n * D + gz) * H + gy) * W + gx) * Cin + hh * 4;
     }
   }
-  // this thread's two output voxels: (tz, ty, tx) and (tz + 2, ty, tx)
-  const int tx = tid & 15, ty = (tid >> 4) & 7, tz = tid >> 7;
-  const int vb0 = ((tz * TO_HY + ty) * TO_HX + tx) * 4;
-  const int vb1 = (((tz + 2) * TO_HY + ty) * TO_HX + tx) * 4;
-  float acc0[CO], acc1[CO];
+  // this thread's outputs: (tz, ty, 4 xg .. 4 xg + 3)
+  const int xg = tid & 3, ty = (tid >> 2) & 7, tz = tid >> 5;
+  const int vb = ((tz * TO_HY + ty) * TO_PX + 4 * xg) * 4;
+  float acc[4][CO];
 #pragma unroll
-  for (int c = 0; c < CO; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[o][c] = 0.f;
 
-  // HBM-bound kernel: the 9 loads of the next chunk are issued back to back (branch-free, zero-select at the LDS
-  // store) BEFORE the FMAs of the current chunk, and the weights -- identical for every lane -- are read straight from
-  // global memory with wave-uniform addresses (scalar loads) instead of 16 LDS broadcasts per tap.
   f32x4 xst[TO_E];
   auto load_chunk = [&](int cib) {
     const bool half_ok = cib * 8 + hh * 4 < Cin;
@@ -323,11 +334,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
       const bool half_ok = cib * 8 + hh * 4 < Cin;
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < TO_E; ++e) {
-        const int eidx = tid + e * 256;
-        if (eidx < 2 * TO_NV)
-          *reinterpret_cast<f32x4*>(xs + (hh * TO_NV + (eidx >> 1)) * 4) = (goff[e] >= 0 && half_ok) ? xst[e] : zero;
-      }
+      for (int e = 0; e < TO_E; ++e)
+        if (loff[e] >= 0) *reinterpret_cast<f32x4*>(xs + loff[e]) = (goff[e] >= 0 && half_ok) ? xst[e] : zero;
     }
     __syncthreads();
     if (cib + 1 < CIB) load_chunk(cib + 1);
@@ -335,46 +343,47 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int ky = 0; ky < 3; ++ky) {
+        const int rowoff = vb + ((kz * TO_HY + ky) * TO_PX) * 4;
+        f32x4 lo[6], hi[6];   // channels 0-3 / 4-7 of the six input voxels of this row
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          lo[i] = *reinterpret_cast<const f32x4*>(xs + rowoff + 4 * i);
+          hi[i] = *reinterpret_cast<const f32x4*>(xs + TO_NVP * 4 + rowoff + 4 * i);
+        }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const int tap = (kz * 3 + ky) * 3 + kx;
-          const int tapoff = ((kz * TO_HY + ky) * TO_HX + kx) * 4;
-          const f32x4 a00 = *reinterpret_cast<const f32x4*>(xs + vb0 + tapoff);
-          const f32x4 a01 = *reinterpret_cast<const f32x4*>(xs + TO_NV * 4 + vb0 + tapoff);
-          const f32x4 a10 = *reinterpret_cast<const f32x4*>(xs + vb1 + tapoff);
-          const f32x4 a11 = *reinterpret_cast<const f32x4*>(xs + TO_NV * 4 + vb1 + tapoff);
-          const float* wt = wchunk + tap * 8 * CO;   // wave-uniform address: scalar loads
+          const float* wt = wchunk + ((kz * 3 + ky) * 3 + kx) * 8 * CO;   // wave-uniform address: scalar loads
 #pragma unroll
           for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int c = 0; c < CO; ++c) {
-              acc0[c] = fmaf(a00[a], wt[a * CO + c], acc0[c]);
-              acc1[c] = fmaf(a10[a], wt[a * CO + c], acc1[c]);
-            }
+              const float w0 = wt[a * CO + c], w1 = wt[(4 + a) * CO + c];
 #pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < CO; ++c) {
-              acc0[c] = fmaf(a01[a], wt[(4 + a) * CO + c], acc0[c]);
-              acc1[c] = fmaf(a11[a], wt[(4 + a) * CO + c], acc1[c]);
+              for (int o = 0; o < 4; ++o) {
+                acc[o][c] = fmaf(lo[o + kx][a], w0, acc[o][c]);
+                acc[o][c] = fmaf(hi[o + kx][a], w1, acc[o][c]);
+              }
             }
         }
+      }
   }
   float s[2] = {0.f, 0.f};
-  const int gy = y0 + ty, gx = x0 + tx;
+  const int gz = z0 + tz, gy = y0 + ty;
+  if (gz < D && gy < H) {
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int gz = z0 + tz + 2 * m;
-    if (gz < D && gy < H && gx < W) {
-      float* yp = y + ((((i64)n * D + gz) * H + gy) * W + gx) * Cout;
+    for (int o = 0; o < 4; ++o) {
+      const int gx = x0 + 4 * xg + o;
+      if (gx < W) {
+        float* yp = y + ((((i64)n * D + gz) * H + gy) * W + gx) * Cout;
 #pragma unroll
-      for (int c = 0; c < CO; ++c) {
-        if (c < Cout) {
-          const float val = (m ? acc1[c] : acc0[c]) + (bias ? bias[c] : 0.f);
-          yp[c] = val;
-          s[0] += val;
-          s[1] += val * val;
+        for (int c = 0; c < CO; ++c) {
+          if (c < Cout) {
+            const float val = acc[o][c] + (bias ? bias[c] : 0.f);
+            yp[c] = val;
+            s[0] += val;
+            s[1] += val * val;
+          }
         }
       }
     }

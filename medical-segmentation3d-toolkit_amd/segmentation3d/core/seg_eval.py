@@ -1,9 +1,10 @@
-"""Batch Dice evaluation with the reference's entry point and CSV layout (core/seg_eval.py:8-57 `cal_dsc_batch`):
-one row per case with `label<k>_score`, `label<k>_type` columns, then a `mean` and a `std` row.
+"""Batch Dice evaluation: `cal_dsc_batch` with the reference's signature, console output and CSV layout
+(core/seg_eval.py:8-57) -- one row per case holding `label<k>_score` / `label<k>_type` pairs, followed by a `mean` and
+a `std` row whose type cells read 'ignore_type'.
 
-Differences by construction: label volumes are read with the built-in MetaImage reader (no SimpleITK), all labels of
-a case are counted in ONE device pass (utils/metrics.py), and the statistics rows are appended with `pandas.concat`
-(`DataFrame.append`, used by the reference at :56, no longer exists)."""
+What differs underneath: label volumes come from the built-in MetaImage reader (no SimpleITK), every case is counted
+in ONE device pass for all labels (utils/metrics.cal_dsc_labels -> csrc/metrics.hip), and the table is assembled from
+records with `pandas.concat` (`DataFrame.append`, which the reference calls at :56, was removed from pandas)."""
 import os
 
 import pandas as pd
@@ -12,35 +13,43 @@ from segmentation3d.utils.metrics import cal_dsc_labels
 from segmentation3d.utils.mha_io import read_mha
 
 
+def _columns(labels):
+    cols = ['filename']
+    for label in labels:
+        cols += ['label{}_score'.format(label), 'label{}_type'.format(label)]
+    return cols
+
+
+def _score_case(gt_path, seg_path, labels, threshold):
+    """one table row: file name, then (score, type) per label; also echoes the reference's progress lines"""
+    name = os.path.basename(gt_path)
+    results = cal_dsc_labels(read_mha(gt_path, dtype=None), read_mha(seg_path, dtype=None), labels, threshold)
+    row = [name]
+    for label, (score, seg_type) in zip(labels, results):
+        print('case_name: {}, label: {}, score: {}, type: {}'.format(name, label, score, seg_type))
+        row += [score, seg_type]
+    return row
+
+
 def cal_dsc_batch(gt_files, seg_files, labels, threshold, save_csv_file_path):
     """
-    gt_files / seg_files: equally long lists of label-volume files (.mha / .mhd)
-    labels: labels to score;  threshold: minimal voxel count for a label to count as present
-    save_csv_file_path: result csv (None -> only return the DataFrame)
+    :param gt_files, seg_files: equally long lists of label-volume files (.mha / .mhd)
+    :param labels: the labels to score
+    :param threshold: minimal voxel count for a label to count as present (TN / FP / FN / TP typing)
+    :param save_csv_file_path: result csv; None only returns the DataFrame
     """
     assert isinstance(gt_files, list) and isinstance(seg_files, list)
     assert len(gt_files) == len(seg_files)
-    result_content = []
-    for gt_case_path, seg_case_path in zip(gt_files, seg_files):
-        gt = read_mha(gt_case_path, dtype=None)
-        seg = read_mha(seg_case_path, dtype=None)
-        case_name = os.path.basename(gt_case_path)
-        content = [case_name]
-        for label, (score, seg_type) in zip(labels, cal_dsc_labels(gt, seg, labels, threshold)):
-            content.extend([score, seg_type])
-            print('case_name: {}, label: {}, score: {}, type: {}'.format(case_name, label, score, seg_type))
-        result_content.append(content)
-    column = ['filename']
+    cols = _columns(labels)
+    cases = pd.DataFrame([_score_case(g, s, labels, threshold) for g, s in zip(gt_files, seg_files)], columns=cols)
+    summary = {'mean': ['mean'], 'std': ['std']}
     for label in labels:
-        column.extend(['label{}_score'.format(label), 'label{}_type'.format(label)])
-    df = pd.DataFrame(data=result_content, columns=column)
-    statistics_content = [['mean'], ['std']]
-    for label in labels:
-        mean, std = df['label{}_score'.format(label)].mean(), df['label{}_score'.format(label)].std()
+        scores = cases['label{}_score'.format(label)]
+        mean, std = scores.mean(), scores.std()
         print(mean, std)
-        statistics_content[0].extend([mean, 'ignore_type'])
-        statistics_content[1].extend([std, 'ignore_type'])
-    df = pd.concat([df, pd.DataFrame(data=statistics_content, columns=column)])
+        summary['mean'] += [mean, 'ignore_type']
+        summary['std'] += [std, 'ignore_type']
+    table = pd.concat([cases, pd.DataFrame([summary['mean'], summary['std']], columns=cols)])
     if save_csv_file_path:
-        df.to_csv(save_csv_file_path)
-    return df
+        table.to_csv(save_csv_file_path)
+    return table

@@ -124,3 +124,33 @@ class Softmax(nn.Module):
 
     def forward(self, input):
         return _ops.softmax_channels(input)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fused conv + GroupNorm (+ ReLU) units
+# ---------------------------------------------------------------------------------------------------------------------
+_GEOMETRY = {'k3': dict(kernel_size=3, stride=1, padding=1), 'k2s2': dict(kernel_size=2, stride=2, padding=0),
+             'k1': dict(kernel_size=1, stride=1, padding=0)}
+
+
+def attach_unit(owner, names, kind, cin, cout, act=True, bias=True):
+    """register the parameter holders of one conv -> GroupNorm(1, C) [-> ReLU] unit on `owner` under the attribute
+    names the reference uses (`names` = (conv, gn, act); act name None or act=False: no activation module), in that
+    order, so `state_dict()` keys and their order equal the reference's.  kind: 'k3' | 'k2s2' | 'k1' | 'convT'."""
+    conv_name, gn_name, act_name = names
+    if kind == 'convT':
+        conv = ConvTranspose3d(cin, cout, kernel_size=2, stride=2, groups=1, bias=bias)
+    else:
+        conv = Conv3d(cin, cout, groups=1, bias=bias, **_GEOMETRY[kind])
+    setattr(owner, conv_name, conv)
+    setattr(owner, gn_name, GroupNorm(1, cout))
+    if act and act_name:
+        setattr(owner, act_name, ReLU(inplace=True))
+
+
+def run_unit(owner, names, input, relu, **fusion):
+    """forward of a unit registered with attach_unit as ONE fused HIP op: conv (GroupNorm statistics in its epilogue)
+    -> normalise + affine [+ residual] [+ ReLU].  `fusion`: residual / link_in / link_out of _ops.conv_gn_act."""
+    conv, gn = getattr(owner, names[0]), getattr(owner, names[1])
+    return _ops.conv_gn_act(input, conv.weight, conv.bias, gn.weight, gn.bias, kind=conv.kind, relu=relu, eps=gn.eps,
+                            **fusion)

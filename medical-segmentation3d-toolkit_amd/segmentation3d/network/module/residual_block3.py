@@ -24,31 +24,35 @@ def _residual_forward(ops, input):
     return ops[n - 1](output, residual=input, force_act=True, link_out=link)
 
 
-class ResidualBlock3(nn.Module):
-    """ residual block with variable number of convolutions """
+class _ResidualBase(nn.Module):
+    """`ops` (nn.Sequential of units, the last one without activation) + `act`, the reference's attribute names"""
+
+    def _build(self, make_unit, num_convs):
+        self.ops = nn.Sequential(*[make_unit(i != num_convs - 1) for i in range(num_convs)])
+        self.act = ReLU(inplace=True)
+
+    def forward(self, input):
+        return _residual_forward(self.ops, input)
+
+
+class ResidualBlock3(_ResidualBase):
+    """num_convs plain 3x3x3 units (residual_block3.py:5-26)"""
 
     def __init__(self, channels, ksize, stride, padding, num_convs):
         super(ResidualBlock3, self).__init__()
-        layers = []
-        for i in range(num_convs):
-            layers.append(ConvGnRelu3(channels, channels, ksize, stride, padding, do_act=(i != num_convs - 1)))
-        self.ops = nn.Sequential(*layers)
-        self.act = ReLU(inplace=True)
-
-    def forward(self, input):
-        return _residual_forward(self.ops, input)
+        self._build(lambda act: ConvGnRelu3(channels, channels, ksize, stride, padding, do_act=act), num_convs)
 
 
-class BottResidualBlock3(nn.Module):
-    """ block with bottle neck conv"""
+class BottResidualBlock3(_ResidualBase):
+    """num_convs bottleneck units (residual_block3.py:29-46)"""
 
     def __init__(self, channels, ksize, stride, padding, ratio, num_convs):
         super(BottResidualBlock3, self).__init__()
-        layers = []
-        for i in range(num_convs):
-            layers.append(BottConvGnRelu3(channels, channels, ksize, stride, padding, ratio, do_act=(i != num_convs - 1)))
-        self.ops = nn.Sequential(*layers)
-        self.act = ReLU(inplace=True)
+        self._build(lambda act: BottConvGnRelu3(channels, channels, ksize, stride, padding, ratio, do_act=act), num_convs)
 
-    def forward(self, input):
-        return _residual_forward(self.ops, input)
+
+def make_residual_block(channels, num_convs, compression=False, ratio=4):
+    """the residual stage of a Down / Up block: 3x3x3, stride 1, padding 1 (vnet_downblock.py:14-17, vnet_upblock.py:14-17)"""
+    if compression:
+        return BottResidualBlock3(channels, 3, 1, 1, ratio, num_convs)
+    return ResidualBlock3(channels, 3, 1, 1, num_convs)

@@ -1,19 +1,20 @@
-"""InputBlock -- mirrors network/module/vnet_inblock.py:4-15: conv k3 p1 -> GroupNorm(1, C) -> ReLU"""
+"""InputBlock: the V-Net stem (reference: network/module/vnet_inblock.py:4-15).
+
+One 3x3x3 convolution from the image modalities to `out_channels` features, GroupNorm(1, C) and ReLU, executed as a
+single fused op (thin-input MFMA kernel, csrc/conv_thin.hip).  Sub-modules keep the reference names `conv`, `gn`, `act`.
+"""
 import torch.nn as nn
 
-from segmentation3d import _ops
-from segmentation3d.network.module.layers import Conv3d, GroupNorm, ReLU
+from segmentation3d.network.module.layers import attach_unit, run_unit
+
+_STEM = ('conv', 'gn', 'act')
 
 
 class InputBlock(nn.Module):
-    """ input block of vb-net """
 
     def __init__(self, in_channels, out_channels):
         super(InputBlock, self).__init__()
-        self.conv = Conv3d(in_channels, out_channels, kernel_size=3, padding=1)
-        self.gn = GroupNorm(1, num_channels=out_channels)
-        self.act = ReLU(inplace=True)
+        attach_unit(self, _STEM, 'k3', in_channels, out_channels)
 
     def forward(self, input):
-        return _ops.conv_gn_act(input, self.conv.weight, self.conv.bias, self.gn.weight, self.gn.bias, kind='k3',
-                                relu=True, eps=self.gn.eps)
+        return run_unit(self, _STEM, input, relu=True)

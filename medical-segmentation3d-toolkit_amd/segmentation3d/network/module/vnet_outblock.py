@@ -1,26 +1,24 @@
-"""OutputBlock -- mirrors network/module/vnet_outblock.py:4-24:
-conv k3 (C -> classes) -> GN -> ReLU -> conv k1 (classes -> classes) -> GN -> Softmax(dim=1)"""
+"""OutputBlock: the V-Net head (reference: network/module/vnet_outblock.py:4-24).
+
+features -> 3x3x3 conv to `out_channels` classes -> GroupNorm -> ReLU -> 1x1x1 conv -> GroupNorm -> Softmax over the
+class axis; returns contiguous [N, classes, D, H, W] probabilities.  Reference attribute names: `conv1`, `gn1`, `act1`,
+`conv2`, `gn2`, `softmax`.
+"""
 import torch.nn as nn
 
-from segmentation3d import _ops
-from segmentation3d.network.module.layers import Conv3d, GroupNorm, ReLU, Softmax
+from segmentation3d.network.module.layers import Softmax, attach_unit, run_unit
+
+_FIRST, _SECOND = ('conv1', 'gn1', 'act1'), ('conv2', 'gn2', None)
 
 
 class OutputBlock(nn.Module):
-    """ output block of v-net: per-voxel class probabilities, contiguous [N, classes, D, H, W] """
 
     def __init__(self, in_channels, out_channels):
         super(OutputBlock, self).__init__()
-        self.conv1 = Conv3d(in_channels, out_channels, kernel_size=3, padding=1)
-        self.gn1 = GroupNorm(1, out_channels)
-        self.act1 = ReLU(inplace=True)
-        self.conv2 = Conv3d(out_channels, out_channels, kernel_size=1)
-        self.gn2 = GroupNorm(1, out_channels)
+        attach_unit(self, _FIRST, 'k3', in_channels, out_channels)
+        attach_unit(self, _SECOND, 'k1', out_channels, out_channels, act=False)
         self.softmax = Softmax(dim=1)
 
     def forward(self, input):
-        out = _ops.conv_gn_act(input, self.conv1.weight, self.conv1.bias, self.gn1.weight, self.gn1.bias, kind='k3',
-                               relu=True, eps=self.gn1.eps)
-        out = _ops.conv_gn_act(out, self.conv2.weight, self.conv2.bias, self.gn2.weight, self.gn2.bias, kind='k1',
-                               relu=False, eps=self.gn2.eps)
-        return self.softmax(out)
+        hidden = run_unit(self, _FIRST, input, relu=True)
+        return self.softmax(run_unit(self, _SECOND, hidden, relu=False))

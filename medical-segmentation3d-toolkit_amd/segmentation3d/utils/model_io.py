@@ -27,37 +27,43 @@ def strip_module_prefix(state_dict):
     return OrderedDict((k[len('module.'):] if k.startswith('module.') else k, v) for k, v in state_dict.items())
 
 
+def _chk_dir(model_folder, epoch_idx):
+    return os.path.join(model_folder, 'checkpoints', 'chk_{}'.format(epoch_idx))
+
+
+def _read(path, what):
+    assert os.path.isfile(path), '{} file not found: {}'.format(what, path)
+    return torch.load(path, map_location='cpu', weights_only=True)   # plain tensors / containers only
+
+
 def load_checkpoint(epoch_idx, net, opt, save_dir):
     """restore network + optimizer from `<save_dir>/checkpoints/chk_<epoch_idx>`; returns (epoch, batch)"""
-    chk_dir = os.path.join(save_dir, 'checkpoints', 'chk_{}'.format(epoch_idx))
-    chk_file = os.path.join(chk_dir, 'params.pth')
-    assert os.path.isfile(chk_file), 'checkpoint file not found: {}'.format(chk_file)
-    state = torch.load(chk_file, map_location='cpu', weights_only=True)
-    target = net.module if hasattr(net, 'module') else net
-    target.load_state_dict(strip_module_prefix(state['state_dict']))
-    opt_file = os.path.join(chk_dir, 'optimizer.pth')
-    assert os.path.isfile(opt_file), 'optimizer file not found: {}'.format(opt_file)
-    opt.load_state_dict(torch.load(opt_file, map_location='cpu', weights_only=True))
+    folder = _chk_dir(save_dir, epoch_idx)
+    state = _read(os.path.join(folder, 'params.pth'), 'checkpoint')
+    getattr(net, 'module', net).load_state_dict(strip_module_prefix(state['state_dict']))
+    opt.load_state_dict(_read(os.path.join(folder, 'optimizer.pth'), 'optimizer'))
     return state['epoch'], state['batch']
+
+
+def checkpoint_state(net, epoch_idx, batch_idx, cfg, max_stride, num_modality):
+    """the `params.pth` dictionary (fields of utils/model_io.py:75-84; tensors moved to the host)"""
+    weights = OrderedDict((key, value.detach().cpu()) for key, value in net.state_dict().items())
+    geometry = {'spacing': cfg.dataset.spacing, 'interpolation': cfg.dataset.interpolation, 'max_stride': max_stride}
+    channels = {'in_channels': num_modality, 'out_channels': cfg.dataset.num_classes}
+    state = {'epoch': epoch_idx, 'batch': batch_idx, 'net': cfg.net.name, 'state_dict': weights,
+             'crop_normalizers': [n.to_dict() for n in cfg.dataset.crop_normalizers]}
+    state.update(geometry)
+    state.update(channels)
+    return state
 
 
 def save_checkpoint(net, opt, epoch_idx, batch_idx, cfg, max_stride, num_modality):
     """write params.pth / optimizer.pth (+ a copy of train_config.py) for `epoch_idx`"""
     model_folder = os.path.join(cfg.general.save_dir, cfg.general.model_scale)
-    chk_folder = os.path.join(model_folder, 'checkpoints', 'chk_{}'.format(epoch_idx))
-    os.makedirs(chk_folder, exist_ok=True)
-    state = {'epoch': epoch_idx,
-             'batch': batch_idx,
-             'net': cfg.net.name,
-             'max_stride': max_stride,
-             'state_dict': OrderedDict((k, v.detach().cpu()) for k, v in net.state_dict().items()),
-             'spacing': cfg.dataset.spacing,
-             'interpolation': cfg.dataset.interpolation,
-             'in_channels': num_modality,
-             'out_channels': cfg.dataset.num_classes,
-             'crop_normalizers': [normalizer.to_dict() for normalizer in cfg.dataset.crop_normalizers]}
-    torch.save(state, os.path.join(chk_folder, 'params.pth'))
-    torch.save(opt.state_dict(), os.path.join(chk_folder, 'optimizer.pth'))
-    cfg_copy = os.path.join(model_folder, 'train_config.py')
-    if os.path.isfile(cfg_copy):
-        shutil.copy(cfg_copy, os.path.join(chk_folder, 'train_config.py'))
+    folder = _chk_dir(model_folder, epoch_idx)
+    os.makedirs(folder, exist_ok=True)
+    torch.save(checkpoint_state(net, epoch_idx, batch_idx, cfg, max_stride, num_modality), os.path.join(folder, 'params.pth'))
+    torch.save(opt.state_dict(), os.path.join(folder, 'optimizer.pth'))
+    config_copy = os.path.join(model_folder, 'train_config.py')
+    if os.path.isfile(config_copy):
+        shutil.copy(config_copy, os.path.join(folder, 'train_config.py'))

@@ -149,9 +149,13 @@ extern "C" int seg3d_pack_weights_mfma(const float* w, float* wp, int A, int B, 
 
 // Many weight tensors in ONE launch (after an optimizer step every conv weight has to be re-packed, for the forward
 // and for the data-gradient orientation: 52 tiny launches per V-Net step otherwise).  `jobs` is a device array;
-// job k owns the workgroups [first_block[k], first_block[k+1]) and each workgroup packs 1024 consecutive elements (one
-// float4 per thread: four independent strided gathers, one 16-byte store).
+// job k owns the workgroups [first_block[k], first_block[k+1]), one per packed (32 x 8 x T) chunk.
 __global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob* __restrict__ jobs, int njobs) {
+  // One workgroup per packed chunk (8 reduction channels x 32 output channels x T taps = exactly one LDS image of the
+  // conv kernels).  In both reference layouts one of the two channel strides equals T, so the chunk's source elements
+  // form long contiguous runs: they are read in memory order (coalesced), transposed through LDS and written in packed
+  // order (coalesced).  The first version gathered single floats straight from global memory and moved 5x the bytes.
+  __shared__ float tile[8 * 32 * 27];
   __shared__ int sjob;
   if (threadIdx.x == 0) {
     int lo = 0, hi = njobs - 1;  // last job whose first_block <= blockIdx.x
@@ -164,42 +168,55 @@ __global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob
   __syncthreads();
   const Seg3dPackJob jb = jobs[sjob];
   const int AB = (jb.A + 7) / 8, T = jb.T;
-  const i64 total4 = (i64)((jb.B + 31) / 32) * AB * T * 64;          // float4 elements of the packed image
-  const i64 q4 = ((i64)blockIdx.x - jb.first_block) * 256 + threadIdx.x;  // one float4 (r = 0..3) per thread
-  if (q4 >= total4) return;
-  // packed index = (((bb * AB + ab) * T + t) * 2 + h) * 32 + j, times 4 + r
-  const int j = (int)(q4 & 31);
-  const int h = (int)((q4 >> 5) & 1);
-  i64 rest = q4 >> 6;
-  const int t = (int)(rest % T);
-  rest /= T;
-  const int ab = (int)(rest % AB);
-  const int bb = (int)(rest / AB);
-  const int a0 = ab * 8 + h * 4, b = bb * 32 + j;
-  const i64 base = b * jb.sb + (jb.flip ? T - 1 - t : t);
-  // four independent gathers issued back to back (clamped address, select afterwards)
-  float v[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const bool ok = a0 + r < jb.A && b < jb.B;
-    v[r] = jb.w[ok ? (a0 + r) * jb.sa + base : 0];
+  const int chunk = (int)((i64)blockIdx.x - jb.first_block);   // = bb * AB + ab
+  const int ab = chunk % AB, bb = chunk / AB;
+  const int a0 = ab * 8, b0 = bb * 32;
+  const int n = 8 * 32 * T;                                     // elements of this chunk, tile[(a * 32 + b) * T + t]
+  if (T <= 27 && jb.sa == T) {
+    // w[b][a][t]: for a fixed output channel b the 8 x T values of this chunk are contiguous
+    const int run = 8 * T;
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+      const int b = i / run, r = i - b * run;
+      const int a = r / T, t = r - a * T;
+      float v = 0.f;
+      if (a0 + a < jb.A && b0 + b < jb.B) v = jb.w[(i64)(b0 + b) * jb.sb + (i64)a0 * T + r];
+      tile[(a * 32 + b) * T + t] = v;
+    }
+  } else if (T <= 27 && jb.sb == T) {
+    // w[a][b][t]: for a fixed reduction channel a the 32 x T values are contiguous
+    const int run = 32 * T;
+    for (int i = threadIdx.x; i < 8 * run; i += 256) {
+      const int a = i / run, r = i - a * run;
+      float v = 0.f;
+      if (a0 + a < jb.A && b0 + r / T < jb.B) v = jb.w[(i64)(a0 + a) * jb.sa + (i64)b0 * T + r];
+      tile[a * run + r] = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < n && T <= 27; i += 256) {
+      const int t = i % T, ab_ = i / T;
+      const int b = ab_ % 32, a = ab_ / 32;
+      float v = 0.f;
+      if (a0 + a < jb.A && b0 + b < jb.B) v = jb.w[(a0 + a) * jb.sa + (b0 + b) * jb.sb + t];
+      tile[i] = v;
+    }
   }
-  float4 o;
-  o.x = (a0 + 0 < jb.A && b < jb.B) ? v[0] : 0.f;
-  o.y = (a0 + 1 < jb.A && b < jb.B) ? v[1] : 0.f;
-  o.z = (a0 + 2 < jb.A && b < jb.B) ? v[2] : 0.f;
-  o.w = (a0 + 3 < jb.A && b < jb.B) ? v[3] : 0.f;
-  reinterpret_cast<float4*>(jb.wp)[q4] = o;
+  __syncthreads();
+  // packed order inside the chunk: [t][h][j][r]  with a = 4 h + r, b = j
+  float* dst = jb.wp + (i64)chunk * n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int r = i & 3, j = (i >> 2) & 31, h = (i >> 7) & 1, t = i >> 8;
+    dst[i] = tile[((4 * h + r) * 32 + j) * T + (jb.flip ? T - 1 - t : t)];
+  }
 }
 
 extern "C" long long seg3d_pack_job_blocks(int A, int B, int T) {
-  return ((long long)((B + 31) / 32) * ((A + 7) / 8) * T * 256 + 1023) / 1024;
+  return (long long)((B + 31) / 32) * ((A + 7) / 8);   // one workgroup per (32 outputs x 8 inputs) chunk
 }
 
 extern "C" int seg3d_pack_weights_mfma_multi(const Seg3dPackJob* jobs_device, int njobs, long long total_blocks,
                                              void* stream) {
   SEG3D_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31),
-                "seg3d_pack_weights_mfma_multi: bad arguments");
+                "seg3d_pack_weights_mfma_multi: bad arguments");   // every job must have T <= 27 (the kernels' taps)
   hipLaunchKernelGGL(pack_mfma_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device,
                      njobs);
   SEG3D_LAUNCH_CHECK("seg3d_pack_weights_mfma_multi");

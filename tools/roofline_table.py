@@ -1,0 +1,43 @@
+"""per-kernel roofline table (markdown) from the committed round profiles:
+  kernel statistics (rocprofv3 --kernel-trace --stats), the FETCH_SIZE / WRITE_SIZE PMC passes, the MFMA shape report
+usage: python tools/roofline_table.py <kernel_stats.csv> <pmc_fetch_write.json> <mfma_shapes.json> <steps> > table.md"""
+import csv
+import json
+import sys
+
+HBM_PEAK_GBS, MFMA_PEAK_TF = 8000.0, 157.3
+stats = list(csv.DictReader(open(sys.argv[1])))
+pmc = json.load(open(sys.argv[2]))
+shapes = json.load(open(sys.argv[3]))['mfma_conv_launches']
+steps = int(sys.argv[4])
+
+# algorithmic FLOPs per second of the 3x3x3 forward/dgrad instantiations from the live shape report
+variant_flops = {}
+for r in shapes:
+    N, D, H, W, Ci, Co, v = r['N_D_H_W_Cin_Cout_variant']
+    name = 'conv3d_k3_mfma2_kernel<{}, {}>'.format((v - 100) // 10, v % 10) if v >= 100 else 'conv3d_k3_mfma_kernel<{}>'.format(v)
+    e = variant_flops.setdefault(name, [0.0, 0.0])
+    e[0] += 2.0 * N * D * H * W * 27 * Ci * Co * r['launches_per_step']
+    e[1] += r['avg_ms'] * r['launches_per_step']
+
+print('| kernel | launches/step | ms/step | avg us | traffic at the L2 boundary, GB/launch (2 x FETCH + WRITE) | GB/s | % of 8 TB/s | TFLOP/s | % of 157.3 |')
+print('|---|---|---|---|---|---|---|---|---|')
+for r in stats[:40]:
+    name = r['Name'].split('(')[0].strip()
+    key = name
+    short = name[5:] if name.startswith('void ') else name
+    calls = float(r['Calls']) / steps
+    ms = float(r['TotalDurationNs']) / 1e6 / steps
+    avg_us = float(r['AverageNs']) / 1e3
+    e = pmc.get(key) or pmc.get('void ' + short) or {}
+    gb = None
+    if 'FETCH_SIZE_KB_per_launch' in e and 'WRITE_SIZE_KB_per_launch' in e:
+        gb = (2.0 * e['FETCH_SIZE_KB_per_launch'] + e['WRITE_SIZE_KB_per_launch']) * 1024 / 1e9
+    gbs = gb / (avg_us * 1e-6) if gb else None
+    tf = None
+    if short in variant_flops and variant_flops[short][1] > 0:
+        tf = variant_flops[short][0] / (variant_flops[short][1] * 1e-3) / 1e12
+    print('| `{}` | {:.1f} | {:.3f} | {:.1f} | {} | {} | {} | {} | {} |'.format(
+        short[:60], calls, ms, avg_us, '-' if gb is None else '{:.3f}'.format(gb), '-' if gbs is None else '{:.0f}'.format(gbs),
+        '-' if gbs is None else '{:.0f}'.format(100 * gbs / HBM_PEAK_GBS), '-' if tf is None else '{:.1f}'.format(tf),
+        '-' if tf is None else '{:.0f}'.format(100 * tf / MFMA_PEAK_TF)))

@@ -1352,15 +1352,8 @@ static Seg3dWgradPlan seg3d_wgrad_plan(int N, int D, int H, int W, int Cin, int 
     const int ntiles = N * seg3d_cdiv(D, p.tz) * seg3d_cdiv(H, p.ty) * seg3d_cdiv(W, p.tx);
     if (ntiles >= SEG3D_FDIV_MAX) return p;   // tile decoding by float reciprocal is exact below 2^22 only
     p.version = 2;
-    p.nb = (COB32 % 2 == 0) ? 2 : 1;
-    {
-      static int forced = -1;  // experiment switch
-      if (forced < 0) {
-        const char* e = getenv("SEG3D_WGRAD_NB");
-        forced = e ? atoi(e) : 0;
-      }
-      if (forced != 2) p.nb = 1;  // NB = 2 spills in the fully unrolled loop: opt-in until that is fixed
-    }
+    p.nb = 1;   // NB = 2 (two dy blocks per workgroup) halves the x staging, but hipcc spills the unrolled loop's piece
+                // table and reloads it behind vmcnt(0) waits (negative results): not used until that is solved
     const int npg = CIB32 * (COB32 / p.nb);
     int slabs = 256 / npg;  // one resident workgroup per CU over the whole grid
     if (slabs > (ntiles + 1) / 2) slabs = (ntiles + 1) / 2;  // small levels: >= 2 tiles per workgroup
@@ -1417,7 +1410,6 @@ extern "C" int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float
     int rc;
     if (plan.tx == 4) rc = launch_wgrad2<1, 4, 4, 4>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
     else if (plan.tx == 6) rc = launch_wgrad2<1, 2, 6, 6>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
-    else if (plan.nb == 2) rc = launch_wgrad2<2, 4, 4, 8>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
     else rc = launch_wgrad2<1, 4, 4, 8>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
     if (rc != SEG3D_OK) return rc;
   } else {

@@ -10,7 +10,7 @@ import os
 import pandas as pd
 
 from segmentation3d.utils.metrics import cal_dsc_labels
-from segmentation3d.utils.mha_io import read_mha
+from segmentation3d.utils.image_io import read_image
 
 
 def _columns(labels):
@@ -23,7 +23,7 @@ def _columns(labels):
 def _score_case(gt_path, seg_path, labels, threshold):
     """one table row: file name, then (score, type) per label; also echoes the reference's progress lines"""
     name = os.path.basename(gt_path)
-    results = cal_dsc_labels(read_mha(gt_path, dtype=None), read_mha(seg_path, dtype=None), labels, threshold)
+    results = cal_dsc_labels(read_image(gt_path, dtype=None), read_image(seg_path, dtype=None), labels, threshold)
     row = [name]
     for label, (score, seg_type) in zip(labels, results):
         print('case_name: {}, label: {}, score: {}, type: {}'.format(name, label, score, seg_type))

@@ -380,14 +380,14 @@ def segmentation(input_path, model_folder, output_folder, seg_name, gpu_id, retu
                  save_prob):
     """volumetric image segmentation engine for MetaImage files (reference: seg_infer.py:353-493): single-scale
     ('coarse' / 'fine') or the coarse -> fine cascade ('DISABLE') through the coarse mask's bounding box."""
-    from segmentation3d.utils.mha_io import read_mha, write_mha
+    from segmentation3d.utils.image_io import read_image, write_image
     begin = time.time()
     models = load_models(model_folder, gpu_id)
     load_model_time = time.time() - begin
     if os.path.isfile(input_path) and input_path.endswith('.txt'):
         with open(input_path) as f:
             paths = [ln.strip() for ln in f.readlines()[1:] if ln.strip()]
-    elif os.path.isfile(input_path) and (input_path.endswith('.mha') or input_path.endswith('.mhd')):
+    elif os.path.isfile(input_path) and input_path.endswith(('.mha', '.mhd', '.nii', '.nii.gz')):
         paths = [input_path]
     else:
         raise ValueError('Unsupported input path.')
@@ -397,7 +397,7 @@ def segmentation(input_path, model_folder, output_folder, seg_name, gpu_id, retu
     masks, total = [], 0.0
     for i, path in enumerate(paths):
         print('{}: {}'.format(i, path))
-        image = read_mha(path)
+        image = read_image(path)
         begin = time.time()
         if scale == 'coarse':
             mean_probs, mask = segmentation_volume(models['coarse_model'], models['infer_cfg'].coarse, image, None, None, True)
@@ -425,11 +425,11 @@ def segmentation(input_path, model_folder, output_folder, seg_name, gpu_id, retu
         if save_mask or save_image or save_prob:
             os.makedirs(os.path.join(output_folder, case), exist_ok=True)
         if save_mask:
-            write_mha(mask, os.path.join(output_folder, case, seg_name))
+            write_image(mask, os.path.join(output_folder, case, seg_name))
         if save_image:
-            write_mha(image, os.path.join(output_folder, case, 'org.mha'))
+            write_image(image, os.path.join(output_folder, case, 'org.mha'))
         if save_prob:
             for c, p in enumerate(mean_probs):
-                write_mha(p, os.path.join(output_folder, case, 'mean_prob_{}.mha'.format(c)))
+                write_image(p, os.path.join(output_folder, case, 'mean_prob_{}.mha'.format(c)))
         print('load model time: {:.2f}, average inference time: {:.2f}'.format(load_model_time, total / (i + 1)))
     return masks

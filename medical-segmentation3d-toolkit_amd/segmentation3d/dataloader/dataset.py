@@ -20,7 +20,7 @@ from segmentation3d import _engine as E
 from segmentation3d.utils.file_io import readlines
 from segmentation3d.utils.image3d import Image3d
 from segmentation3d.utils import image_tools
-from segmentation3d.utils.mha_io import read_mha
+from segmentation3d.utils.image_io import read_image
 
 
 def read_train_txt(imlist_file):
@@ -120,7 +120,7 @@ class SegmentationDataset(Dataset):
     def case(self, index):
         c = self._cases.get(index)
         if c is None:
-            c = _Case(read_mha(self.im_list[index]), read_mha(self.seg_list[index], dtype=None), self.device)
+            c = _Case(read_image(self.im_list[index]), read_image(self.seg_list[index], dtype=None), self.device)
             self._cases[index] = c
         return c
 

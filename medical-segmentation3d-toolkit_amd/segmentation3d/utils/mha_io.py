@@ -1,7 +1,8 @@
 """Minimal MetaImage (.mha / .mhd) reader and writer -- enough to run `seg_infer` on synthetic volumes without
 SimpleITK (the reference reads/writes through `sitk.ReadImage` / `sitk.WriteImage`, core/seg_infer.py:414,467).
-Uncompressed, little-endian, 3-D, scalar element types only."""
+3-D scalar element types; raw or zlib-compressed data (read), raw (write)."""
 import os
+import zlib
 
 import numpy as np
 
@@ -24,18 +25,20 @@ def read_mha(path, dtype=np.float32):
             header[key] = value
             if key == 'ElementDataFile':
                 break
-        if header.get('CompressedData', 'False').lower() == 'true':
-            raise NotImplementedError('compressed MetaImage files are not supported')
+        compressed = header.get('CompressedData', 'False').lower() == 'true'   # zlib stream (sitk.WriteImage(..., True))
         if int(header.get('NDims', 3)) != 3:
             raise ValueError('only 3-D images are supported')
         size = [int(v) for v in header['DimSize'].split()]
         et = _MET[header['ElementType']]
         count = size[0] * size[1] * size[2]
         if header['ElementDataFile'] == 'LOCAL':
-            data = np.frombuffer(f.read(count * np.dtype(et).itemsize), dtype=et)
+            blob = f.read()
         else:
-            raw = os.path.join(os.path.dirname(path), header['ElementDataFile'])
-            data = np.fromfile(raw, dtype=et, count=count)
+            with open(os.path.join(os.path.dirname(path), header['ElementDataFile']), 'rb') as g:
+                blob = g.read()
+        if compressed:
+            blob = zlib.decompress(blob)
+        data = np.frombuffer(blob, dtype=et, count=count)
     if header.get('BinaryDataByteOrderMSB', 'False').lower() == 'true':
         data = data.byteswap()
     array = data.reshape(size[2], size[1], size[0])

@@ -95,3 +95,54 @@ def test_partition_matches_reference_tables():
         assert ends == case['ends'], name
     c = golden_json('partitions')['vol512x512x400_96_48']
     assert len(c['starts']) == 800
+
+
+def test_image_io_roundtrips_nifti_and_compressed_mha(tmp_path):
+    """utils/image_io: NIfTI-1 (.nii / .nii.gz) write -> read round trip keeps voxels and the ITK-convention frame
+    (RAS <-> LPS sign flips), header fields sit at the NIfTI-1 offsets, the qform path agrees with the sform path, and a
+    zlib-compressed MetaImage (what sitk.WriteImage(..., True) produces) is readable"""
+    import gzip
+    import struct
+    import zlib
+    from segmentation3d.utils.image3d import Image3d
+    from segmentation3d.utils.image_io import read_image, write_image
+    rng = np.random.RandomState(3)
+    arr = rng.randn(5, 7, 9).astype(np.float32)
+    direction = [0.0, -1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0]            # a 90 degree in-plane rotation
+    img = Image3d(arr, (0.8, 1.25, 2.5), (-12.5, 30.0, 4.0), direction)
+    for name in ('a.nii.gz', 'b.nii'):
+        path = str(tmp_path / name)
+        write_image(img, path)
+        back = read_image(path, dtype=None)
+        assert back.array.dtype == np.float32 and np.array_equal(back.array, arr)
+        assert np.allclose(back.GetSpacing(), img.GetSpacing(), atol=1e-6)
+        assert np.allclose(back.GetOrigin(), img.GetOrigin(), atol=1e-5)
+        assert np.allclose(back.GetDirection(), direction, atol=1e-6)
+    raw = gzip.open(str(tmp_path / 'a.nii.gz'), 'rb').read()
+    assert struct.unpack('<i', raw[:4])[0] == 348 and raw[344:348] == b'n+1\x00'
+    assert struct.unpack('<8h', raw[40:56])[:4] == (3, 9, 7, 5) and struct.unpack('<h', raw[70:72])[0] == 16
+    # RAS affine: x and y rows carry the opposite sign of the LPS frame
+    srow_x = struct.unpack('<4f', raw[280:296])
+    assert abs(srow_x[3] - 12.5) < 1e-5
+    # the same geometry written as a qform only
+    hdr = bytearray(raw[:352])
+    struct.pack_into('<2h', hdr, 252, 1, 0)
+    R = np.diag([-1.0, -1.0, 1.0]) @ np.array(direction).reshape(3, 3)
+    a = 0.5 * np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2]))
+    b, c, d = (R[2, 1] - R[1, 2]) / (4 * a), (R[0, 2] - R[2, 0]) / (4 * a), (R[1, 0] - R[0, 1]) / (4 * a)
+    struct.pack_into('<6f', hdr, 256, b, c, d, 12.5, -30.0, 4.0)
+    qpath = str(tmp_path / 'q.nii')
+    open(qpath, 'wb').write(bytes(hdr) + raw[352:])
+    q = read_image(qpath)
+    assert np.allclose(q.GetDirection(), direction, atol=1e-6) and np.allclose(q.GetOrigin(), img.GetOrigin(), atol=1e-5)
+    # compressed MetaImage
+    lab = rng.randint(0, 4, size=(4, 6, 8)).astype(np.int16)
+    header = ('ObjectType = Image\nNDims = 3\nBinaryData = True\nBinaryDataByteOrderMSB = False\nCompressedData = True\n'
+              'TransformMatrix = 1 0 0 0 1 0 0 0 1\nOffset = 1 2 3\nElementSpacing = 0.5 0.5 2\nDimSize = 8 6 4\n'
+              'ElementType = MET_SHORT\nElementDataFile = LOCAL\n')
+    cpath = str(tmp_path / 'c.mha')
+    open(cpath, 'wb').write(header.encode('ascii') + zlib.compress(lab.tobytes()))
+    c_img = read_image(cpath, dtype=None)
+    assert np.array_equal(c_img.array, lab) and c_img.GetSpacing() == (0.5, 0.5, 2.0) and c_img.GetOrigin() == (1.0, 2.0, 3.0)
+    with pytest.raises(ValueError):
+        read_image(str(tmp_path / 'x.dcm'))

@@ -292,11 +292,15 @@ __device__ __forceinline__ void seg3d_glds16(const float* src, float* lds_dst_wa
   __builtin_amdgcn_global_load_lds(src, lds_dst_wave_uniform, 16, 0, 0);
 }
 
-template <int MA, int NB>
-__global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
+template <int MA, int NB, bool SPLITK>
+__device__ __forceinline__ void conv3d_k3_mfma2_body(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ stats, int N, int D, int H, int W, int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
-    int ntx, int ncog, int nitems, const float* __restrict__ addend) {
+    int ntx, int ncog, int nitems, const float* __restrict__ addend, float* __restrict__ kpart, int ksplit, int cpk_arg) {
+  // SPLITK is a compile-time switch so that the whole-K instantiation keeps exactly the code it had without it
+  // split-K (kpart != nullptr): a work item is (tile, column group, K range of cpk chunks); its raw partial sums go to
+  // slab `ks` of kpart and conv3d_splitk_finish_kernel adds the slabs, the bias, the addend and takes the statistics.
+  // Used where whole-K items cannot fill 256 CUs evenly (12^3 and 6^3 levels): finer items remove the idle tail.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int HY = TY + 2, HX = TX + 2;
   const int NV = (TZ + 2) * HY * HX;
@@ -316,6 +320,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
   // per SIMD nothing hides such instructions, and a 32-bit division is ~35 of them.
   const float rHX = 1.0f / (float)HX, rHY = 1.0f / (float)HY, rTX = 1.0f / (float)TX, rTY = 1.0f / (float)TY;
   const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz, rNCOG = 1.0f / (float)ncog;
+  const float rKS = 1.0f / (float)ksplit;
+  const int cpk = SPLITK ? cpk_arg : CIB;
   auto fdiv = [](int v, float r) { return (int)(((float)v + 0.5f) * r); };
 
   // ---- per-lane constants that do not depend on the work item ----
@@ -359,11 +365,19 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
 
   // ---- work item state ----
   int it_n = 0, it_z0 = 0, it_y0 = 0, it_x0 = 0, it_cog = 0, it_tile = 0;  // item whose DMA sources are set up
+  int it_ks = 0, it_c0 = 0, it_c1 = CIB;                                    // its K slab and chunk range
   const float* xsrc[SEG3D_V2_MAXPX];
   int xadv = 0;  // bit j: piece j advances by 8 channels per chunk (0 for zero-padding sources)
   auto setup_item = [&](int item) {
-    const int tile_all = fdiv(item, rNCOG);
-    it_cog = item - tile_all * ncog;
+    int item_k = item;
+    if (SPLITK) {
+      item_k = fdiv(item, rKS);                      // K slab index varies fastest
+      it_ks = item - item_k * ksplit;
+      it_c0 = it_ks * cpk;
+      it_c1 = it_c0 + cpk < CIB ? it_c0 + cpk : CIB;
+    }
+    const int tile_all = fdiv(item_k, rNCOG);
+    it_cog = item_k - tile_all * ncog;
     int b = tile_all;
     int q = fdiv(b, rNTX);
     const int tix = b - q * ntx;
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
       const int hp = hpos[j];
       const int gz = it_z0 + ((hp >> 20) & 1023) - 1, gy = it_y0 + ((hp >> 10) & 1023) - 1, gx = it_x0 + (hp & 1023) - 1;
       if (hp >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        xsrc[j] = x + ((i64)(((it_n * D + gz) * H + gy) * W + gx) * Cin + ((hp >> 30) & 1) * 4);
+        xsrc[j] = x + ((i64)(((it_n * D + gz) * H + gy) * W + gx) * Cin + ((hp >> 30) & 1) * 4 + (SPLITK ? it_c0 * 8 : 0));
         xadv |= 1 << j;
       }
     }
@@ -407,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
   setup_item(item);
   SEG3D_STAMP(blockIdx.x, 0);
   {  // the only exposed DMA prologue of this workgroup: chunk 0 of its first item into buffer 0
-    const float* w0 = wp + (i64)(it_cog * NB) * CIB * SEG3D_W_CHUNK;
+    const float* w0 = wp + ((i64)(it_cog * NB) * CIB + (SPLITK ? it_c0 : 0)) * SEG3D_W_CHUNK;
 #pragma unroll
     for (int j = 0; j < SEG3D_V2_MAXPX; ++j)
       if (j < nx) dma_x(j, lds);
@@ -421,6 +435,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
   for (;;) {
     // the item being multiplied (its identity is needed again in the epilogue, after setup_item moved on)
     const int cur_n = it_n, cur_z0 = it_z0, cur_y0 = it_y0, cur_x0 = it_x0, cur_cog = it_cog, cur_tile = it_tile;
+    const int cur_ks = it_ks, cur_c0 = SPLITK ? it_c0 : 0, cur_c1 = SPLITK ? it_c1 : CIB;
     const int next_item = item + G;
     const bool more_items = next_item < nitems;
 
@@ -443,14 +458,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
       }
 
     f32x4 ad[MA][NB][4];  // fused addend values of this item (loaded at the start of its last chunk)
-    for (int cib = 0; cib < CIB; ++cib) {
+    for (int cib = cur_c0; cib < cur_c1; ++cib) {
       float* cur = lds + parity * BUF;
       float* nxt = lds + (parity ^ 1) * BUF;
-      const bool last = cib + 1 == CIB;
+      const bool last = cib + 1 == cur_c1;
       const bool do_dma = !last || more_items;
       const float* wnext;
       if (last) {
-        if (addend) {
+        if (!SPLITK && addend) {
           // fused addend (dgrad of a residual block's first conv): fetched NOW, before this chunk's DMAs are issued,
           // so the loads complete behind the MFMAs of the last chunk instead of stalling the epilogue
 #pragma unroll
@@ -469,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
           }
         }
         if (more_items) setup_item(next_item);  // DMA sources now belong to the next item
-        wnext = wp + (i64)(it_cog * NB) * CIB * SEG3D_W_CHUNK;
+        wnext = wp + ((i64)(it_cog * NB) * CIB + (SPLITK ? it_c0 : 0)) * SEG3D_W_CHUNK;
       } else {
         wnext = wp + ((i64)(cur_cog * NB) * CIB + cib + 1) * SEG3D_W_CHUNK;
       }
@@ -520,6 +535,33 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
       parity ^= 1;
     }
     SEG3D_STAMP(item, 2);
+
+    if (SPLITK) {
+      // split-K: raw partial sums of this K range -> slab cur_ks (bias, addend and statistics belong to the finish pass)
+      float* slab = kpart + (i64)cur_ks * N * D * H * W * Cout;
+#pragma unroll
+      for (int m = 0; m < MA; ++m) {
+        const int vp = vpos[m];
+        const int gz = cur_z0 + ((vp >> 20) & 1023), gy = cur_y0 + ((vp >> 10) & 1023), gx = cur_x0 + (vp & 1023);
+        const bool vok = vp >= 0 && gz < D && gy < H && gx < W;
+        const i64 vo = vok ? ((i64)(cur_n * D + gz) * H + gy) * W + gx : 0;
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = cur_cog * NB * 32 + 4 * lh + 32 * q + 8 * g4;
+            if (vok && co < Cout) {
+              f32x4 v;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] = acc[m][q][4 * g4 + c];
+              *reinterpret_cast<f32x4*>(slab + vo * Cout + co) = v;
+            }
+          }
+      }
+      if (!more_items) break;
+      item = next_item;
+      continue;
+    }
 
     // ---- epilogue: bias (+ addend), dwordx4 stores, per-wave GroupNorm partial sums ----
     // Loads first, stores last, nothing in between: on gfx9 stores count in vmcnt too, so a load placed after a store
@@ -604,6 +646,24 @@ struct Seg3dTile {
 };
 
 #define SPLITK_CHUNK 4096  // elements per workgroup of the finish pass
+
+template <int MA, int NB>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ stats, int N, int D, int H, int W, int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
+    int ntx, int ncog, int nitems, const float* __restrict__ addend) {
+  conv3d_k3_mfma2_body<MA, NB, false>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, TZ, TY, TX, ntz, nty, ntx, ncog, nitems,
+                                      addend, nullptr, 1, 0);
+}
+
+// same loop over (tile, column group, K range) items; writes raw partial slabs for conv3d_splitk_finish_kernel
+template <int MA, int NB>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_splitk_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ kpart, int N, int D, int H, int W,
+    int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty, int ntx, int ncog, int nitems, int ksplit, int cpk) {
+  conv3d_k3_mfma2_body<MA, NB, true>(x, wp, nullptr, nullptr, nullptr, N, D, H, W, Cin, Cout, TZ, TY, TX, ntz, nty, ntx,
+                                     ncog, nitems, nullptr, kpart, ksplit, cpk);
+}
 
 // y[e] = bias[c] + sum_ks part[ks][e]; emits GroupNorm (sum, sumsq) partials per workgroup.  HBM-bound, float4.
 __global__ __launch_bounds__(256) void conv3d_splitk_finish_kernel(const float* __restrict__ part,
@@ -711,9 +771,32 @@ struct Seg3dFwdPlan {
   int ma, nb, ks;
 };
 
+static int seg3d_fwd_v2_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEG3D_FWD_V2");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+static int seg3d_fwd_v2_ksplit_enabled() {  // SEG3D_FWD_V2_KSPLIT=0: whole-K items only (measurement switch)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEG3D_FWD_V2_KSPLIT");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 // time model (cycles): 256 workgroups run at once, every round costs one workgroup's duration =
 // K-chunks x 27 taps x 4 x MA x NB MFMAs of 64 cycles + DMA issue + a fixed prologue/epilogue
-static bool seg3d_pick_tile_v2(int N, int D, int H, int W, int Cin, int Cout, Seg3dTile* tile, int* ma_out, int* nb_out) {
+// With ks > 1 an item covers only ceil(cib / ks) chunks and a finish pass (read ks slabs, write y) is added; that pays
+// on the spatially small levels where whole-K items leave most of a round idle.
+static bool seg3d_pick_tile_v2(int N, int D, int H, int W, int Cin, int Cout, Seg3dTile* tile, int* ma_out, int* nb_out,
+                               int* ks_out) {
+  const int cand_ks[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  const double out_bytes = (double)N * D * H * W * Cout * 4.0;
   const int cand_z[] = {1, 2, 3, 4, 6, 8};
   const int cand_y[] = {2, 3, 4, 6, 8, 12, 16};
   const int cand_x[] = {4, 6, 8, 12, 16, 24, 32};
@@ -734,29 +817,29 @@ static bool seg3d_pick_tile_v2(int N, int D, int H, int W, int Cin, int Cout, Se
           if (seg3d_fwd2_lds_bytes(t, nb) > 160 * 1024) continue;
           const int ma = ((mt + 31) / 32 + 3) / 4;
           const double wgs = (double)N * seg3d_cdiv(D, tz) * seg3d_cdiv(H, ty) * seg3d_cdiv(W, tx) * (cobs / nb);
-          const double rounds = ceil(wgs / 256.0);
           const double pieces = (((8 * nv + 255) >> 8) + 27 * nb) / 4.0;
-          const double per_wg = cib * (6912.0 * ma * nb + 60.0 * pieces + 400.0) + 9000.0;
-          const double cost = rounds * per_wg;
-          if (cost < best_cost) {
-            best_cost = cost;
-            *tile = t;
-            *ma_out = ma;
-            *nb_out = nb;
-            found = true;
+          for (int ks : cand_ks) {
+            if (ks > 1 && (2 * ks > cib || !seg3d_fwd_v2_ksplit_enabled())) break;
+            const int cpk = (cib + ks - 1) / ks;
+            const int slabs = (cib + cpk - 1) / cpk;
+            if (slabs != ks) continue;  // this ks leaves an empty slab; a smaller one covers the same split
+            const double rounds = ceil(wgs * ks / 256.0);
+            const double per_wg = cpk * (6912.0 * ma * nb + 60.0 * pieces + 400.0) + 9000.0;
+            // finish pass: (ks + 2) x output bytes through ~4 TB/s (1700 B/cycle) + launch and pipeline latency
+            const double finish = ks > 1 ? (ks + 2) * out_bytes / 1700.0 + 16000.0 : 0.0;
+            const double cost = rounds * per_wg + finish;
+            if (cost < best_cost) {
+              best_cost = cost;
+              *tile = t;
+              *ma_out = ma;
+              *nb_out = nb;
+              *ks_out = ks;
+              found = true;
+            }
           }
         }
   }
   return found;
-}
-
-static int seg3d_fwd_v2_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SEG3D_FWD_V2");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
 }
 
 static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout) {
@@ -766,22 +849,24 @@ static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout
   p.nb = 1;
   p.t = seg3d_pick_tile(N, D, H, W, (Cout + 31) / 32);
   p.ma = ((p.t.tz * p.t.ty * p.t.tx + 31) / 32 + 3) / 4;
-  if (p.ks == 1 && (Cin & 7) == 0 && (Cout & 3) == 0 && seg3d_fwd_v2_enabled()) {
+  if ((Cin & 7) == 0 && (Cout & 3) == 0 && seg3d_fwd_v2_enabled()) {
     Seg3dTile t2;
-    int ma2, nb2;
-    if (seg3d_pick_tile_v2(N, D, H, W, Cin, Cout, &t2, &ma2, &nb2) &&
-        (i64)N * seg3d_cdiv(D, t2.tz) * seg3d_cdiv(H, t2.ty) * seg3d_cdiv(W, t2.tx) * ((Cout + 31) / 32 / nb2) < (1 << 20)) {
+    int ma2, nb2, ks2 = 1;
+    if (seg3d_pick_tile_v2(N, D, H, W, Cin, Cout, &t2, &ma2, &nb2, &ks2) &&
+        (i64)N * seg3d_cdiv(D, t2.tz) * seg3d_cdiv(H, t2.ty) * seg3d_cdiv(W, t2.tx) * ((Cout + 31) / 32 / nb2) * ks2 <
+            (1 << 20)) {
       p.version = 2;
       p.t = t2;
       p.ma = ma2;
       p.nb = nb2;
+      p.ks = ks2;
     }
   }
   return p;
 }
 
 extern "C" long long seg3d_conv3d_k3_mfma_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
-  const int ks = seg3d_fwd_ksplit(N, D, H, W, Cin, Cout);
+  const int ks = seg3d_fwd_plan(N, D, H, W, Cin, Cout).ks;
   return ks > 1 ? (long long)ks * N * D * H * W * Cout : 0;
 }
 
@@ -827,13 +912,17 @@ static int launch_fwd(const float* x, const float* wp, const float* bias, float*
 
 template <int MA, int NB>
 static int launch_fwd2(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
-                       int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, const float* addend) {
+                       int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, const float* addend, float* kpart,
+                       int ks) {
   const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
   const size_t lds = seg3d_fwd2_lds_bytes(t, NB);
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_kernel<MA, NB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_splitk_kernel<MA, NB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     if (e != hipSuccess) {
       seg3d_set_error("conv3d_k3_mfma2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return SEG3D_ERR_LAUNCH;
@@ -841,10 +930,15 @@ static int launch_fwd2(const float* x, const float* wp, const float* bias, float
     configured = true;
   }
   const int ncog = (Cout + 31) / 32 / NB;
-  const int nitems = N * ntz * nty * ntx * ncog;
+  const int nitems = N * ntz * nty * ntx * ncog * ks;
+  const int cib = Cin / 8, cpk = (cib + ks - 1) / ks;
   dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);  // persistent: one workgroup per CU walks the items
-  hipLaunchKernelGGL((conv3d_k3_mfma2_kernel<MA, NB>), grid, dim3(256), lds, s, x, wp, bias, y, stats, N, D, H, W, Cin,
-                     Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, addend);
+  if (ks > 1)
+    hipLaunchKernelGGL((conv3d_k3_mfma2_splitk_kernel<MA, NB>), grid, dim3(256), lds, s, x, wp, kpart, N, D, H, W, Cin,
+                       Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, ks, cpk);
+  else
+    hipLaunchKernelGGL((conv3d_k3_mfma2_kernel<MA, NB>), grid, dim3(256), lds, s, x, wp, bias, y, stats, N, D, H, W, Cin,
+                       Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, addend);
   return SEG3D_OK;
 }
 
@@ -865,24 +959,31 @@ extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const f
   const int ma = plan.ma;
   hipStream_t s = (hipStream_t)stream;
   const int ks = plan.ks;
+  SEG3D_REQUIRE(ks == 1 || workspace, "seg3d_conv3d_k3_mfma_fwd: this shape runs split-K and needs the workspace "
+                "(seg3d_conv3d_k3_mfma_fwd_workspace_floats)");
   if (plan.version == 2) {
     int rc2;
     switch (plan.ma * 10 + plan.nb) {
-      case 11: rc2 = launch_fwd2<1, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
-      case 21: rc2 = launch_fwd2<2, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
-      case 31: rc2 = launch_fwd2<3, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
-      case 41: rc2 = launch_fwd2<4, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
-      case 12: rc2 = launch_fwd2<1, 2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
-      case 22: rc2 = launch_fwd2<2, 2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend); break;
+      case 11: rc2 = launch_fwd2<1, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+      case 21: rc2 = launch_fwd2<2, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+      case 31: rc2 = launch_fwd2<3, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+      case 41: rc2 = launch_fwd2<4, 1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+      case 12: rc2 = launch_fwd2<1, 2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+      case 22: rc2 = launch_fwd2<2, 2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
       default:
         SEG3D_UNSUPPORTED("seg3d_conv3d_k3_mfma_fwd: internal plan error (ma=%d nb=%d)", plan.ma, plan.nb);
     }
     if (rc2 != SEG3D_OK) return rc2;
     SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_fwd(v2)");
+    if (ks > 1) {
+      const i64 M = (i64)D * H * W * Cout;
+      const int nblk = (int)((M + SPLITK_CHUNK - 1) / SPLITK_CHUNK);
+      hipLaunchKernelGGL(conv3d_splitk_finish_kernel, dim3(nblk, N), dim3(256), 0, s, workspace, bias, addend, y, stats,
+                         ks, M, (i64)N * M, Cout, nblk);
+      SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_fwd(v2 split-K finish)");
+    }
     return SEG3D_OK;
   }
-  SEG3D_REQUIRE(ks == 1 || workspace, "seg3d_conv3d_k3_mfma_fwd: this shape runs split-K and needs the workspace "
-                "(seg3d_conv3d_k3_mfma_fwd_workspace_floats)");
   int rc;
   switch (ma) {
     case 1: rc = launch_fwd<1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, workspace, ks, addend); break;

@@ -90,6 +90,30 @@ def test_conv_k3_mfma_addend_and_accumulate_flags(hip_device):
                variant=float(E.query('seg3d_conv3d_k3_mfma_variant', N, D, H, W, Cin, Cout)))
 
 
+@pytest.mark.parametrize('shape', [(4, 256, 256, 6, 6, 6), (1, 256, 256, 12, 12, 12), (2, 128, 64, 5, 6, 7),
+                                   (1, 64, 32, 3, 5, 6), (2, 256, 128, 8, 8, 8), (1, 72, 36, 4, 6, 6)])
+def test_conv3d_k3_mfma_split_k(hip_device, shape):
+    """spatially small levels cut K across work items (slabs summed by the finish pass): value, fused addend and
+    statistics parity on whole and ragged tiles, K ranges that do not divide evenly included"""
+    from segmentation3d import _ops, _engine as E
+    N, Cin, Cout, D, H, W = shape
+    x = _t(21, 'skx', (N, Cin, D, H, W)).to(hip_device)
+    w = _t(22, 'skw', (Cout, Cin, 3, 3, 3), std=0.05).to(hip_device)
+    b = _t(23, 'skb', (Cout,), std=0.5).to(hip_device)
+    a = _t(24, 'ska', (N, Cout, D, H, W)).to(hip_device)
+    an = _ops.to_ndhwc(a)
+    y, part = _ops._conv_k3_generic(_ops.to_ndhwc(x), w, b, Cin, Cout, 27, Cin * 27, 0, True, addend=an)
+    ref = F.conv3d(x.cpu().double(), w.cpu().double(), b.cpu().double(), padding=1) + a.cpu().double()
+    assert max_err(_ops.from_ndhwc(y).double(), ref) < 1e-4
+    s = part.double().sum(1).cpu()
+    rr = ref.reshape(N, -1)
+    assert float(((s[:, 0] - rr.sum(1)).abs() / rr.abs().sum(1)).max()) < 1e-5 and rel_err(s[:, 1], (rr * rr).sum(1)) < 1e-5
+    nws = E.query('seg3d_conv3d_k3_mfma_fwd_workspace_floats', N, D, H, W, Cin, Cout)
+    report('splitk_{}x{}x{}x{}_{}_{}'.format(N, D, H, W, Cin, Cout),
+           variant=float(E.query('seg3d_conv3d_k3_mfma_variant', N, D, H, W, Cin, Cout)),
+           ksplit=float(nws // (N * D * H * W * Cout)))
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 48, 6, 10, 20), (1, 128, 64, 4, 4, 4), (4, 256, 256, 6, 6, 6)])
 def test_conv3d_k3_mfma_stats_partials(hip_device, shape):
     """the conv epilogue's per-workgroup (sum, sumsq) equal the statistics of its own output (incl. the split-K path

@@ -87,6 +87,23 @@ long long seg3d_conv3d_k3_mfma_wgrad_workspace_floats(int N, int D, int H, int W
 int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H, int W,
                                int Cin, int Cout, int accumulate, void* stream);
 
+/* bf16 mode (BASELINE config 5: bf16 activations and weights, fp32 accumulation, fp32 GroupNorm statistics, fp32 master
+ * weights).  Conv INPUTS (x) and packed weights are bf16 (raw 16-bit patterns, `void*` at this boundary); bias, addend,
+ * conv OUTPUT, statistics and workspaces are fp32 as above.  Same nn.Conv3d(k3, p1) call sites (conv_gn_relu3.py:10).
+ * Needs Cin % 16 == 0 and Cout % 4 == 0. */
+long long seg3d_packed_mfma_bf16_elems(int A, int B, int T);
+int seg3d_pack_weights_mfma_bf16(const float* w, void* wp_bf16, int A, int B, int T, long long sa, long long sb, int flip,
+                                 void* stream);
+int seg3d_f32_to_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+int seg3d_bf16_to_f32(const void* src_bf16, float* dst, long long n, void* stream);
+long long seg3d_conv3d_k3_bf16_stats_count(int N, int D, int H, int W, int Cin, int Cout);
+long long seg3d_conv3d_k3_bf16_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+/* 200 + 10*MA + NB = conv3d_k3_mfma2_bf16_kernel<MA, NB>; 0 = shape not supported */
+int seg3d_conv3d_k3_bf16_variant(int N, int D, int H, int W, int Cin, int Cout);
+int seg3d_conv3d_k3_bf16_fwd(const void* x_bf16, const void* wp_bf16, const float* bias, const float* addend, float* y,
+                             float* stats_partial, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
+                             void* stream);
+
 /* fp32 MFMA path for the stride-2 2x2x2 layers (Cin % 4 == 0): gather = Conv3d k2s2 forward / ConvTranspose3d dgrad,
  * scatter = ConvTranspose3d k2s2 forward / Conv3d k2s2 dgrad, pair-reduce = weight gradient of both */
 long long seg3d_conv3d_k2s2_mfma_stats_count(int Do, int Ho, int Wo, int Cout);

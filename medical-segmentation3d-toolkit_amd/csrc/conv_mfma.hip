@@ -292,7 +292,13 @@ __device__ __forceinline__ void seg3d_glds16(const float* src, float* lds_dst_wa
   __builtin_amdgcn_global_load_lds(src, lds_dst_wave_uniform, 16, 0, 0);
 }
 
-template <int MA, int NB, bool SPLITK>
+// BF16 = true: x and wp hold bf16 (viewed here as 32-bit words, `Cin` = words per voxel = channels / 2).  The byte
+// geometry is the same as in fp32 -- a 16-byte piece per (voxel, half), 1-KiB weight pieces per tap -- only a chunk is
+// 16 channels instead of 8 and ONE v_mfma_f32_32x32x16_bf16 (a lane supplies the 8 channels of its half) replaces the
+// four 32x32x2 fp32 MFMAs per tap.  Accumulators, bias, addend, output and statistics stay fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int MA, int NB, bool SPLITK, bool BF16 = false>
 __device__ __forceinline__ void conv3d_k3_mfma2_body(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ stats, int N, int D, int H, int W, int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
@@ -519,13 +525,22 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
           }
         }
         // A = weights, B = voxels: D[co][voxel], a lane owns voxel (lane & 31) and channels 8 g + 4 (lane >> 5) + c
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
+        if constexpr (BF16) {
 #pragma unroll
           for (int m = 0; m < MA; ++m)
 #pragma unroll
             for (int q = 0; q < NB; ++q)
-              acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[q][r], av[m][r], acc[m][q], 0, 0, 0);
+              acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[q]),
+                                                                  __builtin_bit_cast(bf16x8, av[m]), acc[m][q], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < MA; ++m)
+#pragma unroll
+              for (int q = 0; q < NB; ++q)
+                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[q][r], av[m][r], acc[m][q], 0, 0, 0);
+        }
 #pragma unroll
         for (int q = 0; q < NB; ++q) bw[q] = bwn[q];
 #pragma unroll
@@ -665,6 +680,24 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_splitk_kernel(
                                      ncog, nitems, nullptr, kpart, ksplit, cpk);
 }
 
+// bf16-input variants (x, wp: bf16 viewed as words; Cw = Cin / 2 words per voxel)
+template <int MA, int NB>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_bf16_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ stats, int N, int D, int H, int W, int Cw, int Cout, int TZ, int TY, int TX, int ntz, int nty,
+    int ntx, int ncog, int nitems, const float* __restrict__ addend) {
+  conv3d_k3_mfma2_body<MA, NB, false, true>(x, wp, bias, y, stats, N, D, H, W, Cw, Cout, TZ, TY, TX, ntz, nty, ntx, ncog,
+                                            nitems, addend, nullptr, 1, 0);
+}
+
+template <int MA, int NB>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_bf16_splitk_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ kpart, int N, int D, int H, int W,
+    int Cw, int Cout, int TZ, int TY, int TX, int ntz, int nty, int ntx, int ncog, int nitems, int ksplit, int cpk) {
+  conv3d_k3_mfma2_body<MA, NB, true, true>(x, wp, nullptr, nullptr, nullptr, N, D, H, W, Cw, Cout, TZ, TY, TX, ntz, nty,
+                                           ntx, ncog, nitems, nullptr, kpart, ksplit, cpk);
+}
+
 // y[e] = bias[c] + sum_ks part[ks][e]; emits GroupNorm (sum, sumsq) partials per workgroup.  HBM-bound, float4.
 __global__ __launch_bounds__(256) void conv3d_splitk_finish_kernel(const float* __restrict__ part,
                                                                      const float* __restrict__ bias,
@@ -794,13 +827,15 @@ static int seg3d_fwd_v2_ksplit_enabled() {  // SEG3D_FWD_V2_KSPLIT=0: whole-K it
 // With ks > 1 an item covers only ceil(cib / ks) chunks and a finish pass (read ks slabs, write y) is added; that pays
 // on the spatially small levels where whole-K items leave most of a round idle.
 static bool seg3d_pick_tile_v2(int N, int D, int H, int W, int Cin, int Cout, Seg3dTile* tile, int* ma_out, int* nb_out,
-                               int* ks_out) {
+                               int* ks_out, bool bf16 = false) {
   const int cand_ks[] = {1, 2, 3, 4, 6, 8, 12, 16};
   const double out_bytes = (double)N * D * H * W * Cout * 4.0;
   const int cand_z[] = {1, 2, 3, 4, 6, 8};
   const int cand_y[] = {2, 3, 4, 6, 8, 12, 16};
   const int cand_x[] = {4, 6, 8, 12, 16, 24, 32};
-  const int cobs = (Cout + 31) / 32, cib = (Cin + 7) / 8;
+  const int cobs = (Cout + 31) / 32, cib = bf16 ? Cin / 16 : (Cin + 7) / 8;
+  // cycles of the 27 x 4 (fp32: K = 2 each) or 27 x 1 (bf16: K = 16) MFMAs of one accumulator per chunk
+  const double mfma_chunk = bf16 ? 27.0 * 32.0 : 6912.0;
   double best_cost = 1e30;
   bool found = false;
   for (int nb = 1; nb <= 2; ++nb) {
@@ -824,7 +859,10 @@ static bool seg3d_pick_tile_v2(int N, int D, int H, int W, int Cin, int Cout, Se
             const int slabs = (cib + cpk - 1) / cpk;
             if (slabs != ks) continue;  // this ks leaves an empty slab; a smaller one covers the same split
             const double rounds = ceil(wgs * ks / 256.0);
-            const double per_wg = cpk * (6912.0 * ma * nb + 60.0 * pieces + 400.0) + 9000.0;
+            // bf16: the chunk is as long as the slower of its MFMAs and its DMA traffic (4 x pieces KiB per workgroup
+            // at ~16 B/clk per CU out of L2)
+            const double body = bf16 ? fmax(mfma_chunk * ma * nb, 4.0 * pieces * 1024.0 / 16.0) : mfma_chunk * ma * nb;
+            const double per_wg = cpk * (body + 60.0 * pieces + 400.0) + 9000.0;
             // finish pass: (ks + 2) x output bytes through ~4 TB/s (1700 B/cycle) + launch and pipeline latency
             const double finish = ks > 1 ? (ks + 2) * out_bytes / 1700.0 + 16000.0 : 0.0;
             const double cost = rounds * per_wg + finish;
@@ -863,6 +901,46 @@ static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout
     }
   }
   return p;
+}
+
+// bf16-input plan: always the second-generation kernel (Cin % 16 == 0, Cout % 4 == 0 checked by the entry point)
+static Seg3dFwdPlan seg3d_fwd_plan_bf16(int N, int D, int H, int W, int Cin, int Cout) {
+  Seg3dFwdPlan p;
+  p.version = 0;
+  p.ks = 1;
+  p.ma = p.nb = 1;
+  p.t = {1, 1, 1};
+  Seg3dTile t2;
+  int ma2, nb2, ks2 = 1;
+  if ((Cin & 15) == 0 && (Cout & 3) == 0 && seg3d_pick_tile_v2(N, D, H, W, Cin, Cout, &t2, &ma2, &nb2, &ks2, true) &&
+      (i64)N * seg3d_cdiv(D, t2.tz) * seg3d_cdiv(H, t2.ty) * seg3d_cdiv(W, t2.tx) * ((Cout + 31) / 32 / nb2) * ks2 <
+          (1 << 20)) {
+    p.version = 2;
+    p.t = t2;
+    p.ma = ma2;
+    p.nb = nb2;
+    p.ks = ks2;
+  }
+  return p;
+}
+
+extern "C" long long seg3d_conv3d_k3_bf16_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
+  const int ks = seg3d_fwd_plan_bf16(N, D, H, W, Cin, Cout).ks;
+  return ks > 1 ? (long long)ks * N * D * H * W * Cout : 0;
+}
+
+extern "C" long long seg3d_conv3d_k3_bf16_stats_count(int N, int D, int H, int W, int Cin, int Cout) {
+  const Seg3dFwdPlan p = seg3d_fwd_plan_bf16(N, D, H, W, Cin, Cout);
+  if (p.version != 2) return 0;
+  if (p.ks > 1) return ((long long)D * H * W * Cout + SPLITK_CHUNK - 1) / SPLITK_CHUNK;
+  const long long tiles = (long long)seg3d_cdiv(D, p.t.tz) * seg3d_cdiv(H, p.t.ty) * seg3d_cdiv(W, p.t.tx);
+  return tiles * ((Cout + 31) / 32 / p.nb) * 4;
+}
+
+// 200 + 10 MA + NB of conv3d_k3_mfma2_bf16_kernel<MA, NB> (0: shape not supported)
+extern "C" int seg3d_conv3d_k3_bf16_variant(int N, int D, int H, int W, int Cin, int Cout) {
+  const Seg3dFwdPlan p = seg3d_fwd_plan_bf16(N, D, H, W, Cin, Cout);
+  return p.version == 2 ? 200 + 10 * p.ma + p.nb : 0;
 }
 
 extern "C" long long seg3d_conv3d_k3_mfma_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
@@ -910,10 +988,38 @@ static int launch_fwd(const float* x, const float* wp, const float* bias, float*
   return SEG3D_OK;
 }
 
-template <int MA, int NB>
+template <int MA, int NB, bool BF16 = false>
 static int launch_fwd2(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
                        int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, const float* addend, float* kpart,
                        int ks) {
+  if constexpr (BF16) {  // Cin counts bf16 channels; the kernel sees Cin / 2 words per voxel and 16-channel chunks
+    const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
+    const size_t lds = seg3d_fwd2_lds_bytes(t, NB);
+    static bool configured16 = false;
+    if (!configured16) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_bf16_kernel<MA, NB>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_bf16_splitk_kernel<MA, NB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+      if (e != hipSuccess) {
+        seg3d_set_error("conv3d_k3_mfma2_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return SEG3D_ERR_LAUNCH;
+      }
+      configured16 = true;
+    }
+    const int ncog = (Cout + 31) / 32 / NB;
+    const int nitems = N * ntz * nty * ntx * ncog * ks;
+    const int cib = Cin / 16, cpk = (cib + ks - 1) / ks;
+    dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
+    if (ks > 1)
+      hipLaunchKernelGGL((conv3d_k3_mfma2_bf16_splitk_kernel<MA, NB>), grid, dim3(256), lds, s, x, wp, kpart, N, D, H, W,
+                         Cin / 2, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, ks, cpk);
+    else
+      hipLaunchKernelGGL((conv3d_k3_mfma2_bf16_kernel<MA, NB>), grid, dim3(256), lds, s, x, wp, bias, y, stats, N, D, H,
+                         W, Cin / 2, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, addend);
+    return SEG3D_OK;
+  }
   const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
   const size_t lds = seg3d_fwd2_lds_bytes(t, NB);
   static bool configured = false;
@@ -1002,6 +1108,49 @@ extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const f
     hipLaunchKernelGGL(conv3d_splitk_finish_kernel, dim3(nblk, N), dim3(256), 0, s, workspace, bias, addend, y, stats,
                        (cib + cpk - 1) / cpk, M, (i64)N * M, Cout, nblk);
     SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_fwd(split-K finish)");
+  }
+  return SEG3D_OK;
+}
+
+// bf16 inputs: x [N][D][H][W][Cin] bf16, wp = seg3d_pack_weights_mfma_bf16(A = Cin, B = Cout, T = 27); bias, addend,
+// y, stats, workspace fp32 exactly as in seg3d_conv3d_k3_mfma_fwd.  Needs Cin % 16 == 0 and Cout % 4 == 0.
+extern "C" int seg3d_conv3d_k3_bf16_fwd(const void* x, const void* wp, const float* bias, const float* addend, float* y,
+                                        float* stats, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
+                                        void* stream) {
+  SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_bf16_fwd: null pointer");
+  SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k3_bf16_fwd: bad dims");
+  SEG3D_REQUIRE((Cin % 16) == 0 && (Cout % 4) == 0,
+                "seg3d_conv3d_k3_bf16_fwd: needs Cin %% 16 == 0 and Cout %% 4 == 0 (got %d, %d)", Cin, Cout);
+  SEG3D_REQUIRE((i64)N * D * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31),
+                "seg3d_conv3d_k3_bf16_fwd: tensor exceeds 2^31 elements");
+  const Seg3dFwdPlan plan = seg3d_fwd_plan_bf16(N, D, H, W, Cin, Cout);
+  if (plan.version != 2) SEG3D_UNSUPPORTED("seg3d_conv3d_k3_bf16_fwd: no tile fits this shape");
+  const int ks = plan.ks;
+  SEG3D_REQUIRE(ks == 1 || workspace, "seg3d_conv3d_k3_bf16_fwd: this shape runs split-K and needs the workspace "
+                "(seg3d_conv3d_k3_bf16_fwd_workspace_floats)");
+  const float* xw = reinterpret_cast<const float*>(x);
+  const float* ww = reinterpret_cast<const float*>(wp);
+  const Seg3dTile t = plan.t;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  switch (plan.ma * 10 + plan.nb) {
+    case 11: rc = launch_fwd2<1, 1, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+    case 21: rc = launch_fwd2<2, 1, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+    case 31: rc = launch_fwd2<3, 1, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+    case 41: rc = launch_fwd2<4, 1, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+    case 12: rc = launch_fwd2<1, 2, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+    case 22: rc = launch_fwd2<2, 2, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+    default:
+      SEG3D_UNSUPPORTED("seg3d_conv3d_k3_bf16_fwd: internal plan error (ma=%d nb=%d)", plan.ma, plan.nb);
+  }
+  if (rc != SEG3D_OK) return rc;
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_bf16_fwd");
+  if (ks > 1) {
+    const i64 M = (i64)D * H * W * Cout;
+    const int nblk = (int)((M + SPLITK_CHUNK - 1) / SPLITK_CHUNK);
+    hipLaunchKernelGGL(conv3d_splitk_finish_kernel, dim3(nblk, N), dim3(256), 0, s, workspace, bias, addend, y, stats, ks,
+                       M, (i64)N * M, Cout, nblk);
+    SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_bf16_fwd(split-K finish)");
   }
   return SEG3D_OK;
 }

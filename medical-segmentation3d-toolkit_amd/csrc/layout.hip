@@ -147,6 +147,79 @@ extern "C" int seg3d_pack_weights_mfma(const float* w, float* wp, int A, int B, 
   return SEG3D_OK;
 }
 
+// bf16 MFMA pack (bf16 conv path): wp[bb][ab][t][h][j][r] = bf16(W(a = ab*16 + h*8 + r, b = bb*32 + j, t)), zero padded:
+// the same 1-KiB-per-tap LDS image as the fp32 pack with 8 bf16 channels where that has 4 floats.
+__global__ __launch_bounds__(256) void pack_mfma_bf16_kernel(const float* __restrict__ w, seg3d_bf16* __restrict__ wp,
+                                                               int A, int B, int AB, int BB, int T, i64 sa, i64 sb,
+                                                               int flip) {
+  i64 total = (i64)BB * AB * T * 512;
+  for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
+    int r = (int)(idx & 7);
+    int j = (int)((idx >> 3) & 31);
+    int h = (int)((idx >> 8) & 1);
+    i64 rest = idx >> 9;
+    int t = (int)(rest % T);
+    rest /= T;
+    int ab = (int)(rest % AB);
+    int bb = (int)(rest / AB);
+    int a = ab * 16 + h * 8 + r, b = bb * 32 + j;
+    float v = 0.f;
+    if (a < A && b < B) v = w[a * sa + b * sb + (flip ? T - 1 - t : t)];
+    wp[idx] = seg3d_f2bf(v);
+  }
+}
+
+extern "C" long long seg3d_packed_mfma_bf16_elems(int A, int B, int T) {
+  return (long long)((B + 31) / 32) * ((A + 15) / 16) * T * 512;
+}
+
+extern "C" int seg3d_pack_weights_mfma_bf16(const float* w, void* wp, int A, int B, int T, long long sa, long long sb,
+                                            int flip, void* stream) {
+  SEG3D_REQUIRE(w && wp && A > 0 && B > 0 && T > 0, "seg3d_pack_weights_mfma_bf16: bad arguments");
+  int AB = (A + 15) / 16, BB = (B + 31) / 32;
+  i64 total = (i64)BB * AB * T * 512;
+  hipLaunchKernelGGL(pack_mfma_bf16_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (seg3d_bf16*)wp, A, B, AB, BB, T, (i64)sa, (i64)sb, flip);
+  SEG3D_LAUNCH_CHECK("seg3d_pack_weights_mfma_bf16");
+  return SEG3D_OK;
+}
+
+// fp32 <-> bf16 (round to nearest even) over n elements, n % 4 == 0 handled 4 per thread, tail by the last threads
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, seg3d_bf16* __restrict__ dst,
+                                                            i64 n) {
+  const i64 n4 = n >> 2;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n4; i += (i64)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    uint2 o;
+    o.x = seg3d_pack2bf(v.x, v.y);
+    o.y = seg3d_pack2bf(v.z, v.w);
+    reinterpret_cast<uint2*>(dst)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = seg3d_f2bf(src[(n4 << 2) + threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const seg3d_bf16* __restrict__ src, float* __restrict__ dst,
+                                                            i64 n) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) dst[i] = seg3d_bf2f(src[i]);
+}
+
+extern "C" int seg3d_f32_to_bf16(const float* src, void* dst, long long n, void* stream) {
+  SEG3D_REQUIRE(src && dst && n > 0, "seg3d_f32_to_bf16: bad arguments");
+  SEG3D_REQUIRE((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 7) == 0, "seg3d_f32_to_bf16: unaligned buffers");
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(seg3d_ew_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (seg3d_bf16*)dst, (i64)n);
+  SEG3D_LAUNCH_CHECK("seg3d_f32_to_bf16");
+  return SEG3D_OK;
+}
+
+extern "C" int seg3d_bf16_to_f32(const void* src, float* dst, long long n, void* stream) {
+  SEG3D_REQUIRE(src && dst && n > 0, "seg3d_bf16_to_f32: bad arguments");
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(seg3d_ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const seg3d_bf16*)src, dst, (i64)n);
+  SEG3D_LAUNCH_CHECK("seg3d_bf16_to_f32");
+  return SEG3D_OK;
+}
+
 // Many weight tensors in ONE launch (after an optimizer step every conv weight has to be re-packed, for the forward
 // and for the data-gradient orientation: 52 tiny launches per V-Net step otherwise).  `jobs` is a device array;
 // job k owns the workgroups [first_block[k], first_block[k+1]), one per packed (32 x 8 x T) chunk.

@@ -71,6 +71,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #define SEG3D_FDIV_MAX (1 << 22)
 __device__ __forceinline__ int seg3d_fdiv(int v, float r) { return (int)(((float)v + 0.5f) * r); }
 
+// bf16 storage helpers (bf16 mode: conv INPUTS and packed weights are bf16, accumulation and conv outputs fp32).
+// A plain cast compiles to v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN).
+typedef unsigned short seg3d_bf16;  // raw bits at the C ABI
+__device__ __forceinline__ seg3d_bf16 seg3d_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ float seg3d_bf2f(seg3d_bf16 b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned seg3d_pack2bf(float lo, float hi) {
+  return (unsigned)seg3d_f2bf(lo) | ((unsigned)seg3d_f2bf(hi) << 16);
+}
+
 // Sum NV values over a 256-thread workgroup. Result valid in thread 0. `red` must hold 4*NV floats.
 template <int NV>
 __device__ __forceinline__ void block_sum_256(float (&v)[NV], float* red) {

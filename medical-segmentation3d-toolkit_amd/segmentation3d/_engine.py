@@ -43,6 +43,14 @@ _SIGNATURES = {
     'seg3d_conv3d_k3_mfma_fwd_workspace_floats': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_variant': (_c_int, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_fwd': (_c_int, [_c_p] * 7 + [_c_int] * 6 + [_c_p]),
+    'seg3d_packed_mfma_bf16_elems': (_c_ll, [_c_int, _c_int, _c_int]),
+    'seg3d_pack_weights_mfma_bf16': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p]),
+    'seg3d_f32_to_bf16': (_c_int, [_c_p, _c_p, _c_ll, _c_p]),
+    'seg3d_bf16_to_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_p]),
+    'seg3d_conv3d_k3_bf16_stats_count': (_c_ll, [_c_int] * 6),
+    'seg3d_conv3d_k3_bf16_fwd_workspace_floats': (_c_ll, [_c_int] * 6),
+    'seg3d_conv3d_k3_bf16_variant': (_c_int, [_c_int] * 6),
+    'seg3d_conv3d_k3_bf16_fwd': (_c_int, [_c_p] * 7 + [_c_int] * 6 + [_c_p]),
     'seg3d_conv3d_k3_mfma_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 7 + [_c_p]),
     'seg3d_conv3d_k2s2_mfma_stats_count': (_c_ll, [_c_int] * 4),
@@ -140,7 +148,8 @@ def require_device(*tensors):
             raise Seg3dEngineError(
                 'segmentation3d HIP engine needs tensors on a ROCm device (got device={}); '
                 'there is no CPU path in this package'.format(t.device))
-        if t.dtype not in (torch.float32, torch.int32, torch.int8, torch.float64, torch.uint8, torch.int16, torch.int64):
+        if t.dtype not in (torch.float32, torch.int32, torch.int8, torch.float64, torch.uint8, torch.int16, torch.int64,
+                           torch.bfloat16):
             raise TypeError('unsupported dtype {}'.format(t.dtype))
 
 

@@ -114,6 +114,65 @@ def test_conv3d_k3_mfma_split_k(hip_device, shape):
            ksplit=float(nws // (N * D * H * W * Cout)))
 
 
+def test_bf16_conversion_bit_exact(hip_device):
+    """seg3d_f32_to_bf16 rounds to nearest even exactly like torch's .bfloat16() (incl. ties, denormals, inf)"""
+    from segmentation3d import _engine as E
+    vals = _t(31, 'cv', (4099,)).float()
+    special = torch.tensor([0.0, -0.0, 1.0, 1.00390625, 1.01171875, 3.3895314e38, float('inf'), -float('inf'), 1e-40, 65504.0])
+    src = torch.cat([vals, special]).to(hip_device)
+    pad = (-src.numel()) % 4
+    dst = torch.empty(src.numel() + pad, dtype=torch.bfloat16, device=hip_device)
+    E.call('seg3d_f32_to_bf16', E.ptr(src), E.ptr(dst), src.numel(), E.stream_ptr())
+    got = dst[:src.numel()].view(torch.int16).cpu()
+    want = src.cpu().bfloat16().view(torch.int16)
+    assert torch.equal(got, want)
+    back = torch.empty(src.numel(), device=hip_device)
+    E.call('seg3d_bf16_to_f32', E.ptr(dst), E.ptr(back), src.numel(), E.stream_ptr())
+    assert torch.equal(back.cpu(), src.cpu().bfloat16().float())
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 32, 16, 16, 16), (2, 16, 16, 6, 10, 12), (1, 64, 96, 4, 6, 6), (4, 256, 256, 6, 6, 6),
+                                   (1, 128, 64, 5, 6, 7), (2, 48, 20, 4, 12, 20), (1, 32, 32, 24, 24, 48)])
+@pytest.mark.parametrize('with_addend', [False, True])
+def test_conv3d_k3_bf16_fwd(hip_device, shape, with_addend):
+    """bf16-input conv (bf16 activations and weights, fp32 accumulate / bias / addend / output): equals the exact conv of
+    the bf16-rounded operands to fp32 accumulation error (tolerance 2e-5 relative to the output scale), and its GN partial
+    sums equal the statistics of its own output"""
+    from segmentation3d import _ops, _engine as E
+    N, Cin, Cout, D, H, W = shape
+    x = _t(41, 'bx', (N, Cin, D, H, W))
+    w = _t(42, 'bw', (Cout, Cin, 3, 3, 3), std=0.05)
+    b = _t(43, 'bb', (Cout,), std=0.5)
+    a = _t(44, 'ba', (N, Cout, D, H, W))
+    xb = _ops.to_ndhwc(x.to(hip_device)).bfloat16()
+    wd = w.to(hip_device)
+    wp = torch.empty(E.query('seg3d_packed_mfma_bf16_elems', Cin, Cout, 27), dtype=torch.bfloat16, device=hip_device)
+    E.call('seg3d_pack_weights_mfma_bf16', E.ptr(wd), E.ptr(wp), Cin, Cout, 27, 27, Cin * 27, 0, E.stream_ptr())
+    y = torch.empty(N, D, H, W, Cout, device=hip_device)
+    cnt = E.query('seg3d_conv3d_k3_bf16_stats_count', N, D, H, W, Cin, Cout)
+    assert cnt > 0
+    st = torch.zeros(N, cnt, 2, device=hip_device)
+    nws = E.query('seg3d_conv3d_k3_bf16_fwd_workspace_floats', N, D, H, W, Cin, Cout)
+    ws = torch.empty(max(nws, 1), device=hip_device)
+    an = _ops.to_ndhwc(a.to(hip_device)) if with_addend else None
+    bd = b.to(hip_device)
+    E.call('seg3d_conv3d_k3_bf16_fwd', E.ptr(xb), E.ptr(wp), E.ptr(bd), E.ptr(an), E.ptr(y), E.ptr(st), E.ptr(ws),
+           N, D, H, W, Cin, Cout, E.stream_ptr())
+    ref = F.conv3d(x.bfloat16().double(), w.bfloat16().double(), b.double(), padding=1)
+    if with_addend:
+        ref = ref + a.double()
+    got = _ops.from_ndhwc(y).double().cpu()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 2e-5 * scale
+    s = st.double().sum(1).cpu()
+    rr = got.reshape(N, -1)
+    assert float(((s[:, 0] - rr.sum(1)).abs() / rr.abs().sum(1)).max()) < 1e-5 and rel_err(s[:, 1], (rr * rr).sum(1)) < 1e-5
+    report('bf16conv_{}x{}x{}x{}_{}_{}{}'.format(N, D, H, W, Cin, Cout, '_addend' if with_addend else ''),
+           variant=float(E.query('seg3d_conv3d_k3_bf16_variant', N, D, H, W, Cin, Cout)),
+           max_abs_err=float((got - ref).abs().max()), out_scale=scale,
+           err_vs_fp32_conv=float((got - (F.conv3d(x.double(), w.double(), b.double(), padding=1) + (a.double() if with_addend else 0))).abs().max()))
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 48, 6, 10, 20), (1, 128, 64, 4, 4, 4), (4, 256, 256, 6, 6, 6)])
 def test_conv3d_k3_mfma_stats_partials(hip_device, shape):
     """the conv epilogue's per-workgroup (sum, sumsq) equal the statistics of its own output (incl. the split-K path

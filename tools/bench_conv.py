@@ -1,5 +1,5 @@
 """micro-benchmark of single conv launches (events on the launch stream); used for kernel A/B work and PMC runs.
-usage: python tools/bench_conv.py [fwd|wgrad|all] [N D H W Cin Cout] [--iters K]"""
+usage: python tools/bench_conv.py [fwd|fwd16|wgrad|all] [N D H W Cin Cout] [--iters K]   (fwd16 = bf16-input kernel)"""
 import os, sys, time
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +22,17 @@ def run(kind, N, D, H, W, Cin, Cout, iters=10):
         ad = torch.randn(N, D, H, W, Cout, device=dev) if '--addend' in sys.argv else None
         nostats = '--nostats' in sys.argv
         fn = lambda: E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(x), E.ptr(wp), None if nostats else E.ptr(b), E.ptr(ad), E.ptr(y), None if nostats else E.ptr(st), E.ptr(wsp), N, D, H, W, Cin, Cout, E.stream_ptr())
+    elif kind == 'fwd16':
+        xb = x.bfloat16()
+        wp = torch.empty(E.query('seg3d_packed_mfma_bf16_elems', Cin, Cout, 27), dtype=torch.bfloat16, device=dev)
+        E.call('seg3d_pack_weights_mfma_bf16', E.ptr(w), E.ptr(wp), Cin, Cout, 27, 27, Cin * 27, 0, E.stream_ptr())
+        y = torch.empty(N, D, H, W, Cout, device=dev)
+        cnt = E.query('seg3d_conv3d_k3_bf16_stats_count', N, D, H, W, Cin, Cout)
+        nws = E.query('seg3d_conv3d_k3_bf16_fwd_workspace_floats', N, D, H, W, Cin, Cout)
+        wsp = torch.empty(max(nws, 1), device=dev)
+        st = torch.empty(N, cnt, 2, device=dev)
+        print('variant', E.query('seg3d_conv3d_k3_bf16_variant', N, D, H, W, Cin, Cout), 'ks', nws // (N * D * H * W * Cout))
+        fn = lambda: E.call('seg3d_conv3d_k3_bf16_fwd', E.ptr(xb), E.ptr(wp), E.ptr(b), None, E.ptr(y), E.ptr(st), E.ptr(wsp), N, D, H, W, Cin, Cout, E.stream_ptr())
     else:
         ws = torch.empty(E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W, Cin, Cout), device=dev)
         dw = torch.empty(Cout, Cin, 3, 3, 3, device=dev)

@@ -30,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (v_mfma_f32_32x32x16_bf16)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -50,6 +51,10 @@ def parse():
     ap.add_argument('--infer-volume', default='512,512,400', help='X,Y,Z of the synthetic inference volume')
     ap.add_argument('--infer-batch', type=int, default=16)
     ap.add_argument('--kernel-report', default='', help='write the per-shape kernel timing table to this json file')
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                    help="fp32 = the headline metric (BASELINE configs 2-4); bf16 = BASELINE config 5's mode (bf16 "
+                         "activations / packed weights, fp32 accumulate, statistics and master weights) -- reported "
+                         "under its own dtype, never as the fp32 headline")
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='enqueue weight-gradient kernels on the main stream (no second HIP stream): use this under '
                          'rocprofv3 --kernel-trace, which serialises concurrent dispatches and distorts their durations')
@@ -83,14 +88,15 @@ class KernelTimer(object):
         timer = self
 
         def call(name, *args):
-            if name != 'seg3d_conv3d_k3_mfma_fwd':
+            if name not in ('seg3d_conv3d_k3_mfma_fwd', 'seg3d_conv3d_k3_bf16_fwd'):
                 return timer._orig(name, *args)
             N, D, H, W, Cin, Cout = args[7:13]
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             rc = timer._orig(name, *args)
             b.record()
-            ma = E.query('seg3d_conv3d_k3_mfma_variant', N, D, H, W, Cin, Cout)
+            ma = E.query('seg3d_conv3d_k3_bf16_variant' if 'bf16' in name else 'seg3d_conv3d_k3_mfma_variant',
+                         N, D, H, W, Cin, Cout)
             timer.records.append(((N, D, H, W, Cin, Cout, ma), a, b))
             return rc
         E.call = call
@@ -115,6 +121,8 @@ class KernelTimer(object):
 
 def variant_kernel_name(v):
     """seg3d_conv3d_k3_mfma_variant code -> kernel symbol as rocprofv3 prints it"""
+    if v >= 200:
+        return 'conv3d_k3_mfma2_bf16_kernel<{}, {}>'.format((v - 200) // 10, v % 10)
     if v >= 100:
         return 'conv3d_k3_mfma2_kernel<{}, {}>'.format((v - 100) // 10, v % 10)
     return 'conv3d_k3_mfma_kernel<{}>'.format(v)
@@ -222,6 +230,8 @@ def main():
         sys.stderr.write('note: --gpus {} but WORLD_SIZE {}\n'.format(args.gpus, world))
 
     from segmentation3d.core.seg_train import TrainStep
+    from segmentation3d import _ops as _ops_mode
+    _ops_mode.set_activation_dtype(args.dtype)
     weights = [1.0 / args.classes] * args.classes
     if args.no_wgrad_overlap:
         from segmentation3d import _ops as _ops_cfg
@@ -280,8 +290,9 @@ def main():
         traffic = pmc_traffic_gb('void ' + kname)
         d = by_variant[dom]
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
         roofline = {'kernel': kname, 'bound': 'mfma', 'achieved': round(achieved, 2),
-                    'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                     'traffic': traffic, 'traffic_unit': 'GB per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, see profiles/)',
                     'launches_per_step': d['launches'] // 2,
                     'avg_launch_ms': round(d['ms'] / d['launches'], 4),
@@ -310,10 +321,12 @@ def main():
         out = {
             'metric': 'patches/sec (96^3, 1-mod V-Net) train-step', 'value': round(value, 3), 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.dtype == 'fp32' else 'bf16 (activations + packed k3 weights; f32 accumulate, GN statistics, master weights)',
+            'data': 'synthetic',
             'config': {'workload': '{}({},{}) train step (fwd + {} loss + bwd + fused Adam), {} patches of {}^3 per GPU, '
-                                   'fp32, random-init weights'.format(args.net, args.in_channels, args.classes, args.loss,
-                                                                      args.batch, args.patch),
+                                   '{}, random-init weights'.format(args.net, args.in_channels, args.classes, args.loss,
+                                                                    args.batch, args.patch, args.dtype),
                        'global_batch': world * args.batch, 'patch': args.patch,
                        'parallelism': 'dp{} (bucketed RCCL all-reduce overlapped with backward)'.format(world) if world > 1 else 'single GPU',
                        'wgrad_overlap': not args.no_wgrad_overlap},

@@ -94,6 +94,10 @@ int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float* dw, float
 long long seg3d_packed_mfma_bf16_elems(int A, int B, int T);
 int seg3d_pack_weights_mfma_bf16(const float* w, void* wp_bf16, int A, int B, int T, long long sa, long long sb, int flip,
                                  void* stream);
+/* bf16 images of many weights in one launch; Seg3dPackJob.wp then points at bf16 storage and first_block advances by
+ * seg3d_pack_job_blocks_bf16 */
+long long seg3d_pack_job_blocks_bf16(int A, int B, int T);
+int seg3d_pack_weights_mfma_bf16_multi(const Seg3dPackJob* jobs_device, int njobs, long long total_blocks, void* stream);
 int seg3d_f32_to_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 int seg3d_bf16_to_f32(const void* src_bf16, float* dst, long long n, void* stream);
 long long seg3d_conv3d_k3_bf16_stats_count(int N, int D, int H, int W, int Cin, int Cout);
@@ -103,6 +107,22 @@ int seg3d_conv3d_k3_bf16_variant(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_bf16_fwd(const void* x_bf16, const void* wp_bf16, const float* bias, const float* addend, float* y,
                              float* stats_partial, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
                              void* stream);
+
+/* bf16 mode, remaining conv entry points: the INPUT activations (and, for weight gradients, the output gradient) are
+ * bf16 and are widened to fp32 while a tile is staged; weights (fp32 pack), accumulation and outputs are fp32.  Each one
+ * mirrors the fp32 entry point of the same name without `bf16` (same call sites in the reference). */
+long long seg3d_conv3d_k3_bf16_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+int seg3d_conv3d_k3_bf16_wgrad(const void* x_bf16, const void* dy_bf16, float* dw, float* workspace, int N, int D, int H,
+                               int W, int Cin, int Cout, int accumulate, void* stream);
+int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp_mfma, const float* bias, float* y, float* stats_partial,
+                               int N, int Do, int Ho, int Wo, int Cin, int Cout, void* stream);
+int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp_mfma, const float* bias, float* y,
+                                float* stats_partial, int N, int Di, int Hi, int Wi, int Cin, int Cout, void* stream);
+int seg3d_k2_bf16_wgrad(const void* P_bf16, const void* Q_bf16, float* dw, float* workspace, int N, int Dq, int Hq, int Wq,
+                        int CA, int CB, long long sa, long long sb, int accumulate, void* stream);
+int seg3d_conv3d_k3_thin_out_bf16_fwd(const void* x_bf16, const float* wq, const float* bias, float* y,
+                                      float* stats_partial, int N, int D, int H, int W, int Cin, int Cout, int CO,
+                                      void* stream);
 
 /* fp32 MFMA path for the stride-2 2x2x2 layers (Cin % 4 == 0): gather = Conv3d k2s2 forward / ConvTranspose3d dgrad,
  * scatter = ConvTranspose3d k2s2 forward / Conv3d k2s2 dgrad, pair-reduce = weight gradient of both */
@@ -150,6 +170,18 @@ int seg3d_gn_bwd_finalize(const float* part, const float* gamma, const float* me
 int seg3d_gn_bwd_apply(const float* dout, const float* out /* NULL: recompute */, const float* y, const float* mean_rstd,
                        const float* s12, const float* gamma, const float* beta, float* dy, float* dres, int N, long long S,
                        int C, int relu, int ld_dout /* row stride of dout in floats, 0 = C */, void* stream);
+
+/* bf16 mode GroupNorm: the conv output y, the statistics and all arithmetic stay fp32; the activation-side tensors
+ * (residual, unit output, incoming gradient) are bf16 where flagged.  ld_out / ld_dout count elements of that tensor. */
+int seg3d_gn_apply_mixed(const float* y, const float* mean_rstd, const float* gamma, const float* beta, const void* res,
+                         void* out, int N, long long S, int C, int relu, int ld_out, int res_bf16, int out_bf16,
+                         void* stream);
+int seg3d_gn_bwd_reduce_bf16(const void* dout_bf16, const void* out_bf16, const float* y, const float* mean_rstd,
+                             const float* gamma, const float* beta, float* part, int N, long long S, int C, int relu,
+                             int ld_dout, void* stream);
+int seg3d_gn_bwd_apply_bf16(const void* dout_bf16, const void* out_bf16, const float* y, const float* mean_rstd,
+                            const float* s12, const float* gamma, const float* beta, void* dy, float* dres, int N,
+                            long long S, int C, int relu, int ld_dout, int dy_bf16, void* stream);
 
 /* ---- head softmax (network/module/vnet_outblock.py:18,23) ---------------------------------------------------------- */
 int seg3d_softmax_fwd(const float* in_ndhwc, float* probs_ncdhw, int N, int C, long long S, void* stream);

@@ -53,7 +53,10 @@ static K2Tile k2_pick_tile(int D, int H, int W) {
 // ---------------------------------------------------------------------------------------------------------------
 // gather: output tile TZ x TY x TX (<= 128 voxels), input tile 2TZ x 2TY x 2TX staged 8 channels at a time
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const float* __restrict__ x,
+// XBF: the input tensor is bf16 (bf16 mode); it is widened to fp32 when the staged chunk is written to LDS, the
+// weights, the fp32 MFMAs and the fp32 output are the same.
+template <bool XBF>
+__global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __restrict__ x,
                                                                     const float* __restrict__ wp,
                                                                     const float* __restrict__ bias, float* __restrict__ y,
                                                                     float* __restrict__ stats, int N, int Do, int Ho,
@@ -130,13 +133,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const float* _
   // Register-prefetch pipeline: all loads of chunk c+1 are issued back to back (branch-free, clamped addresses; the
   // zero-select happens at the LDS store) before the MFMAs of chunk c, so a workgroup keeps 32 KB in flight -- at the
   // top level this kernel is HBM-bound and a load consumed right where it is issued serialises on memory latency.
-  f32x4 xst[K2_MAXE], wst[2];
+  typename Seg3dQuad<XBF>::raw xst[K2_MAXE];
+  f32x4 wst[2];
   auto load_chunk = [&](int cib) {
     const bool half_ok = cib * 8 + hh * 4 < Cin;
 #pragma unroll
     for (int e = 0; e < K2_MAXE; ++e) {
       const bool ok = goff[e] >= 0 && half_ok;
-      xst[e] = *reinterpret_cast<const f32x4*>(x + (ok ? (i64)goff[e] + cib * 8 : (i64)0));
+      xst[e] = Seg3dQuad<XBF>::load(x, ok ? (i64)goff[e] + cib * 8 : (i64)0);
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * K2_W_CHUNK);
 #pragma unroll
@@ -149,7 +153,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const float* _
     for (int e = 0; e < K2_MAXE; ++e) {
       const int eidx = tid + e * 256;
       if (eidx < 2 * NV)
-        *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) = (goff[e] >= 0 && half_ok) ? xst[e] : zero;
+        *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) =
+            (goff[e] >= 0 && half_ok) ? Seg3dQuad<XBF>::cvt(xst[e]) : zero;
     }
     f32x4* wdst = reinterpret_cast<f32x4*>(ws);
 #pragma unroll
@@ -216,8 +221,8 @@ extern "C" long long seg3d_conv3d_k2s2_mfma_stats_count(int Do, int Ho, int Wo, 
 }
 
 // x [N][2Do][2Ho][2Wo][Cin] -> y [N][Do][Ho][Wo][Cout];  wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 8)
-extern "C" int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N,
-                                          int Do, int Ho, int Wo, int Cin, int Cout, void* stream) {
+static int k2_gather_launch(const void* x, int x_bf16, const float* wp, const float* bias, float* y, float* stats, int N,
+                            int Do, int Ho, int Wo, int Cin, int Cout, void* stream) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k2s2_mfma_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && Do > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k2s2_mfma_fwd: bad dims");
   SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
@@ -230,16 +235,32 @@ extern "C" int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp, const
   const size_t lds = (size_t)(8 * 8 * mt + K2_W_CHUNK + ((mt + 3) & ~3)) * 4;
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "2x2x2 stride-2 MFMA kernels: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
-  hipLaunchKernelGGL(conv3d_k2s2_mfma_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, stats, N, Do, Ho,
-                     Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
+  if (x_bf16)
+    hipLaunchKernelGGL(conv3d_k2s2_mfma_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, stats, N,
+                       Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
+  else
+    hipLaunchKernelGGL(conv3d_k2s2_mfma_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, stats, N,
+                       Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k2s2_mfma_fwd");
   return SEG3D_OK;
+}
+
+extern "C" int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N,
+                                          int Do, int Ho, int Wo, int Cin, int Cout, void* stream) {
+  return k2_gather_launch(x, 0, wp, bias, y, stats, N, Do, Ho, Wo, Cin, Cout, stream);
+}
+
+// bf16 mode: x is bf16 ([N][2Do][2Ho][2Wo][Cin]); weights (fp32 pack), bias, y and statistics as above
+extern "C" int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp, const float* bias, float* y, float* stats,
+                                          int N, int Do, int Ho, int Wo, int Cin, int Cout, void* stream) {
+  return k2_gather_launch(x_bf16, 1, wp, bias, y, stats, N, Do, Ho, Wo, Cin, Cout, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // scatter: input tile TZ x TY x TX (<= 128 voxels), one accumulator per tap, output cell 2^3 per input voxel
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const float* __restrict__ x,
+template <bool XBF>
+__global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* __restrict__ x,
                                                                      const float* __restrict__ wp,
                                                                      const float* __restrict__ bias,
                                                                      float* __restrict__ y, float* __restrict__ stats,
@@ -290,10 +311,11 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const float* 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   // register prefetch of the next chunk (one float4 of x + two of weights per thread) behind the 32 MFMAs of this one
-  f32x4 xst, wst[2];
+  typename Seg3dQuad<XBF>::raw xst;
+  f32x4 wst[2];
   auto load_chunk = [&](int cib) {
     const bool ok = goff >= 0 && cib * 8 + hh * 4 < Cin;
-    xst = *reinterpret_cast<const f32x4*>(x + (ok ? (i64)goff + cib * 8 : (i64)0));
+    xst = Seg3dQuad<XBF>::load(x, ok ? (i64)goff + cib * 8 : (i64)0);
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * K2_W_CHUNK);
 #pragma unroll
     for (int k = 0; k < 2; ++k) wst[k] = wsrc[tid + k * 256];
@@ -303,7 +325,8 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const float* 
     __syncthreads();
     if (sv < MT) {
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(xs + (hh * MT + sv) * 4) = (goff >= 0 && cib * 8 + hh * 4 < Cin) ? xst : zero;
+      *reinterpret_cast<f32x4*>(xs + (hh * MT + sv) * 4) =
+          (goff >= 0 && cib * 8 + hh * 4 < Cin) ? Seg3dQuad<XBF>::cvt(xst) : zero;
     }
     {
       f32x4* wdst = reinterpret_cast<f32x4*>(ws);
@@ -399,8 +422,8 @@ extern "C" long long seg3d_convT3d_k2s2_mfma_stats_count(int Di, int Hi, int Wi,
 }
 
 // x [N][Di][Hi][Wi][Cin] -> y [N][2Di][2Hi][2Wi][Cout];  wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 8)
-extern "C" int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
-                                           int N, int Di, int Hi, int Wi, int Cin, int Cout, void* stream) {
+static int k2_scatter_launch(const void* x, int x_bf16, const float* wp, const float* bias, float* y, float* stats, int N,
+                             int Di, int Hi, int Wi, int Cin, int Cout, void* stream) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_convT3d_k2s2_mfma_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && Di > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "seg3d_convT3d_k2s2_mfma_fwd: bad dims");
   SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
@@ -411,10 +434,24 @@ extern "C" int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp, cons
   const int ntz = seg3d_cdiv(Di, t.tz), nty = seg3d_cdiv(Hi, t.ty), ntx = seg3d_cdiv(Wi, t.tx);
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "2x2x2 stride-2 MFMA kernels: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
-  hipLaunchKernelGGL(convT3d_k2s2_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, stats, N, Di, Hi,
-                     Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
+  if (x_bf16)
+    hipLaunchKernelGGL(convT3d_k2s2_mfma_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, stats, N,
+                       Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
+  else
+    hipLaunchKernelGGL(convT3d_k2s2_mfma_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, stats, N,
+                       Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
   SEG3D_LAUNCH_CHECK("seg3d_convT3d_k2s2_mfma_fwd");
   return SEG3D_OK;
+}
+
+extern "C" int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
+                                           int N, int Di, int Hi, int Wi, int Cin, int Cout, void* stream) {
+  return k2_scatter_launch(x, 0, wp, bias, y, stats, N, Di, Hi, Wi, Cin, Cout, stream);
+}
+
+extern "C" int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp, const float* bias, float* y, float* stats,
+                                           int N, int Di, int Hi, int Wi, int Cin, int Cout, void* stream) {
+  return k2_scatter_launch(x_bf16, 1, wp, bias, y, stats, N, Di, Hi, Wi, Cin, Cout, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -428,7 +465,9 @@ extern "C" int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp, cons
 #define K2W_HX (2 * K2W_TX)
 #define K2W_NV (8 * K2W_MT)                 // 512 P voxels per tile
 
-__global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+// BF: P and Q are bf16 (bf16 mode: activations and their gradients), widened to fp32 when the tile is written to LDS
+template <bool BF>
+__global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const void* __restrict__ P, const void* __restrict__ Q,
                                                                  float* __restrict__ part, int N, int Dq, int Hq, int Wq,
                                                                  int CA, int CB, int ntz, int nty, int ntx, int ntiles,
                                                                  int BB32) {
@@ -461,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
   // top level, so keeping the next tile's 18 x 16-byte loads per thread in flight behind the MFMA block is what
   // keeps the memory system busy
   constexpr int PE = (K2W_NV * 8) / 256, QE = (K2W_MT * 8) / 256;
-  f32x4 pst[PE], qst[QE];
+  typename Seg3dQuad<BF>::raw pst[PE], qst[QE];
   unsigned okmask = 0;  // zero-select deferred to store_tile: a select right at the load would serialise the loads
   // tile-invariant part of every entry's address (tile dims are compile-time constants: shifts and masks only); a
   // tile inside the volume adds its origin to these -- two instructions per load instead of ~70 of index arithmetic,
@@ -491,13 +530,13 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
     const int n = qd;
     const int z0 = tiz * K2W_TZ, y0 = tiy * K2W_TY, x0 = tix * K2W_TX;
     if (z0 + K2W_TZ <= Dq && y0 + K2W_TY <= Hq && x0 + K2W_TX <= Wq) {  // whole tile inside the volume
-      const float* pbase = P + ((((i64)n * Dp + 2 * z0) * Hp + 2 * y0) * Wp + 2 * x0) * CA;
-      const float* qbase = Q + ((((i64)n * Dq + z0) * Hq + y0) * Wq + x0) * CB;
+      const i64 pbase = ((((i64)n * Dp + 2 * z0) * Hp + 2 * y0) * Wp + 2 * x0) * CA;
+      const i64 qbase = ((((i64)n * Dq + z0) * Hq + y0) * Wq + x0) * CB;
       const unsigned pm = pq_ok ? (1u << PE) - 1u : 0u, qm = qq_ok ? ((1u << QE) - 1u) << PE : 0u;
 #pragma unroll
-      for (int e = 0; e < PE; ++e) pst[e] = *reinterpret_cast<const f32x4*>(pq_ok ? pbase + prel[e] : P);
+      for (int e = 0; e < PE; ++e) pst[e] = Seg3dQuad<BF>::load(P, pq_ok ? pbase + prel[e] : (i64)0);
 #pragma unroll
-      for (int e = 0; e < QE; ++e) qst[e] = *reinterpret_cast<const f32x4*>(qq_ok ? qbase + qrel[e] : Q);
+      for (int e = 0; e < QE; ++e) qst[e] = Seg3dQuad<BF>::load(Q, qq_ok ? qbase + qrel[e] : (i64)0);
       okmask = pm | qm;
       return;
     }
@@ -511,8 +550,7 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
       const int hz = t / K2W_HY;
       const int gz = 2 * z0 + hz, gy = 2 * y0 + hy, gx = 2 * x0 + hx;
       const bool ok = pq_ok && gz < Dp && gy < Hp && gx < Wp;
-      pst[e] = *reinterpret_cast<const f32x4*>(
-          P + (ok ? ((((i64)n * Dp + gz) * Hp + gy) * Wp + gx) * CA + a0 + 4 * q : (i64)0));
+      pst[e] = Seg3dQuad<BF>::load(P, ok ? ((((i64)n * Dp + gz) * Hp + gy) * Wp + gx) * CA + a0 + 4 * q : (i64)0);
       okmask |= (ok ? 1u : 0u) << e;
     }
 #pragma unroll
@@ -524,8 +562,7 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
       const int tz = t / K2W_TY;
       const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
       const bool ok = qq_ok && gz < Dq && gy < Hq && gx < Wq;
-      qst[e] = *reinterpret_cast<const f32x4*>(
-          Q + (ok ? ((((i64)n * Dq + gz) * Hq + gy) * Wq + gx) * CB + b0 + 4 * q : (i64)0));
+      qst[e] = Seg3dQuad<BF>::load(Q, ok ? ((((i64)n * Dq + gz) * Hq + gy) * Wq + gx) * CB + b0 + 4 * q : (i64)0);
       okmask |= (ok ? 1u : 0u) << (PE + e);
     }
   };
@@ -533,10 +570,12 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const float* __re
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < PE; ++e)
-      *reinterpret_cast<f32x4*>(ps + ((tid + e * 256) >> 3) * 32 + 4 * q) = ((okmask >> e) & 1u) ? pst[e] : zero;
+      *reinterpret_cast<f32x4*>(ps + ((tid + e * 256) >> 3) * 32 + 4 * q) =
+          ((okmask >> e) & 1u) ? Seg3dQuad<BF>::cvt(pst[e]) : zero;
 #pragma unroll
     for (int e = 0; e < QE; ++e)
-      *reinterpret_cast<f32x4*>(qs + ((tid + e * 256) >> 3) * 32 + 4 * q) = ((okmask >> (PE + e)) & 1u) ? qst[e] : zero;
+      *reinterpret_cast<f32x4*>(qs + ((tid + e * 256) >> 3) * 32 + 4 * q) =
+          ((okmask >> (PE + e)) & 1u) ? Seg3dQuad<BF>::cvt(qst[e]) : zero;
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -613,8 +652,8 @@ extern "C" long long seg3d_k2_mfma_wgrad_workspace_floats(int N, int Dq, int Hq,
 }
 
 // P [N][2Dq][2Hq][2Wq][CA], Q [N][Dq][Hq][Wq][CB];  dw[a*sa + b*sb + t] (t < 8) receives the gradient
-extern "C" int seg3d_k2_mfma_wgrad(const float* P, const float* Q, float* dw, float* workspace, int N, int Dq, int Hq,
-                                   int Wq, int CA, int CB, long long sa, long long sb, int accumulate, void* stream) {
+static int k2_wgrad_launch(const void* P, const void* Q, int bf16, float* dw, float* workspace, int N, int Dq, int Hq,
+                           int Wq, int CA, int CB, long long sa, long long sb, int accumulate, void* stream) {
   SEG3D_REQUIRE(P && Q && dw && workspace, "seg3d_k2_mfma_wgrad: null pointer");
   SEG3D_REQUIRE(N > 0 && Dq > 0 && Hq > 0 && Wq > 0 && CA > 0 && CB > 0, "seg3d_k2_mfma_wgrad: bad dims");
   SEG3D_REQUIRE((CA % 4) == 0 && (CB % 4) == 0, "seg3d_k2_mfma_wgrad: channel counts must be multiples of 4 (got %d, %d)",
@@ -626,12 +665,28 @@ extern "C" int seg3d_k2_mfma_wgrad(const float* P, const float* Q, float* dw, fl
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "seg3d_k2_mfma_wgrad: more than 2^22 tiles");
   const int slabs = k2_wgrad_slabs(N, Dq, Hq, Wq, npairs);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k2_wgrad_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s, P, Q, workspace, N, Dq, Hq, Wq, CA, CB, ntz,
-                     nty, ntx, ntiles, BB32);
+  if (bf16)
+    hipLaunchKernelGGL(k2_wgrad_mfma_kernel<true>, dim3(slabs, npairs), dim3(256), 0, s, P, Q, workspace, N, Dq, Hq, Wq, CA,
+                       CB, ntz, nty, ntx, ntiles, BB32);
+  else
+    hipLaunchKernelGGL(k2_wgrad_mfma_kernel<false>, dim3(slabs, npairs), dim3(256), 0, s, P, Q, workspace, N, Dq, Hq, Wq, CA,
+                       CB, ntz, nty, ntx, ntiles, BB32);
   SEG3D_LAUNCH_CHECK("seg3d_k2_mfma_wgrad");
   const i64 total = (i64)npairs * 8 * 1024;
   hipLaunchKernelGGL(k2_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dw, slabs, CA, CB,
                      BB32, npairs, (i64)sa, (i64)sb, accumulate);
   SEG3D_LAUNCH_CHECK("seg3d_k2_mfma_wgrad(reduce)");
   return SEG3D_OK;
+}
+
+extern "C" int seg3d_k2_mfma_wgrad(const float* P, const float* Q, float* dw, float* workspace, int N, int Dq, int Hq,
+                                   int Wq, int CA, int CB, long long sa, long long sb, int accumulate, void* stream) {
+  return k2_wgrad_launch(P, Q, 0, dw, workspace, N, Dq, Hq, Wq, CA, CB, sa, sb, accumulate, stream);
+}
+
+// bf16 mode: P and Q bf16, dw and workspace fp32 (same sizes as seg3d_k2_mfma_wgrad_workspace_floats)
+extern "C" int seg3d_k2_bf16_wgrad(const void* P_bf16, const void* Q_bf16, float* dw, float* workspace, int N, int Dq,
+                                   int Hq, int Wq, int CA, int CB, long long sa, long long sb, int accumulate,
+                                   void* stream) {
+  return k2_wgrad_launch(P_bf16, Q_bf16, 1, dw, workspace, N, Dq, Hq, Wq, CA, CB, sa, sb, accumulate, stream);
 }

@@ -1168,11 +1168,11 @@ extern "C" int seg3d_conv3d_k3_bf16_fwd(const void* x, const void* wp, const flo
 #define SEG3D_WG_XE ((SEG3D_WG_NV * 8 + 255) / 256)                                     // float4 per thread: 12
 #define SEG3D_WG_YE ((SEG3D_WG_MT * 8) / 256)                                           // 4
 
-__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const float* __restrict__ x,
-                                                                        const float* __restrict__ dy,
-                                                                        float* __restrict__ part, int N, int D, int H,
-                                                                        int W, int Cin, int Cout, int ntz, int nty,
-                                                                        int ntx, int ntiles, int COB32) {
+// BF (bf16 mode): x and dy are bf16, widened to fp32 when the staged tile is written to LDS (fp32 MFMA, fp32 partials)
+template <bool BF>
+__device__ __forceinline__ void conv3d_k3_wgrad_mfma_body(const void* __restrict__ x, const void* __restrict__ dy,
+                                                          float* __restrict__ part, int N, int D, int H, int W, int Cin,
+                                                          int Cout, int ntz, int nty, int ntx, int ntiles, int COB32) {
   __shared__ __attribute__((aligned(16))) float xs[SEG3D_WG_NV * 32];
   __shared__ __attribute__((aligned(16))) float dys[SEG3D_WG_MT * 32];
   const int tid = threadIdx.x;
@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
   // tile t (branch-free, clamped addresses) and written to LDS after it, so HBM/L2 latency hides behind the matrix work.
   // (the zero-select of out-of-range entries happens in store_tile from a bit mask: consuming a loaded value right
   // here would make the compiler wait for each load before issuing the next)
-  f32x4 xst[SEG3D_WG_XE], yst[SEG3D_WG_YE];
+  typename Seg3dQuad<BF>::raw xst[SEG3D_WG_XE], yst[SEG3D_WG_YE];
   unsigned okmask = 0;
   auto load_tile = [&](int tile) {
     int b = tile;
@@ -1224,8 +1224,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
       const int hz = t / SEG3D_WG_HY;
       const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
       const bool ok = eidx < SEG3D_WG_NV * 8 && xq_ok && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      xst[e] = *reinterpret_cast<const f32x4*>(
-          x + (ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * Cin + ci0 + 4 * q : (i64)0));
+      xst[e] = Seg3dQuad<BF>::load(x, ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * Cin + ci0 + 4 * q : (i64)0);
       okmask |= (ok ? 1u : 0u) << e;
     }
 #pragma unroll
@@ -1238,8 +1237,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
       const int tz = t / SEG3D_WG_TY;
       const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
       const bool ok = yq_ok && gz < D && gy < H && gx < W;
-      yst[e] = *reinterpret_cast<const f32x4*>(
-          dy + (ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * Cout + co0 + 4 * q : (i64)0));
+      yst[e] = Seg3dQuad<BF>::load(dy, ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * Cout + co0 + 4 * q : (i64)0);
       okmask |= (ok ? 1u : 0u) << (16 + e);
     }
   };
@@ -1249,12 +1247,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
     for (int e = 0; e < SEG3D_WG_XE; ++e) {
       const int eidx = tid + e * 256;
       if (eidx < SEG3D_WG_NV * 8)
-        *reinterpret_cast<f32x4*>(xs + (eidx >> 3) * 32 + 4 * q) = ((okmask >> e) & 1u) ? xst[e] : zero;
+        *reinterpret_cast<f32x4*>(xs + (eidx >> 3) * 32 + 4 * q) = ((okmask >> e) & 1u) ? Seg3dQuad<BF>::cvt(xst[e]) : zero;
     }
 #pragma unroll
     for (int e = 0; e < SEG3D_WG_YE; ++e) {
       const int eidx = tid + e * 256;
-      *reinterpret_cast<f32x4*>(dys + (eidx >> 3) * 32 + 4 * q) = ((okmask >> (16 + e)) & 1u) ? yst[e] : zero;
+      *reinterpret_cast<f32x4*>(dys + (eidx >> 3) * 32 + 4 * q) =
+          ((okmask >> (16 + e)) & 1u) ? Seg3dQuad<BF>::cvt(yst[e]) : zero;
     }
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
@@ -1291,6 +1290,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const floa
       for (int r = 0; r < 16; ++r) dst[tap * 1024 + mfma_row(r, lh) * 32 + li] = acc[j][r];
     }
   }
+}
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const float* __restrict__ x,
+                                                                        const float* __restrict__ dy,
+                                                                        float* __restrict__ part, int N, int D, int H,
+                                                                        int W, int Cin, int Cout, int ntz, int nty,
+                                                                        int ntx, int ntiles, int COB32) {
+  conv3d_k3_wgrad_mfma_body<false>(x, dy, part, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, COB32);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_bf16_kernel(const void* __restrict__ x,
+                                                                             const void* __restrict__ dy,
+                                                                             float* __restrict__ part, int N, int D, int H,
+                                                                             int W, int Cin, int Cout, int ntz, int nty,
+                                                                             int ntx, int ntiles, int COB32) {
+  conv3d_k3_wgrad_mfma_body<true>(x, dy, part, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, COB32);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1671,5 +1686,35 @@ extern "C" int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float
   hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dw, slabs,
                      Cin, Cout, COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_wgrad(reduce)");
+  return SEG3D_OK;
+}
+
+// bf16 mode: x and dy bf16 (first-generation kernel, converted while staging; fp32 MFMA, fp32 dw)
+extern "C" long long seg3d_conv3d_k3_bf16_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
+  const int npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
+  return (long long)seg3d_wgrad_slabs(N, D, H, W, npairs) * npairs * 27 * 1024;
+}
+
+extern "C" int seg3d_conv3d_k3_bf16_wgrad(const void* x, const void* dy, float* dw, float* workspace, int N, int D, int H,
+                                          int W, int Cin, int Cout, int accumulate, void* stream) {
+  SEG3D_REQUIRE(x && dy && dw && workspace, "seg3d_conv3d_k3_bf16_wgrad: null pointer");
+  SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k3_bf16_wgrad: bad dims");
+  SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
+                "seg3d_conv3d_k3_bf16_wgrad: Cin and Cout must be multiples of 4 (got %d, %d)", Cin, Cout);
+  SEG3D_REQUIRE((i64)N * D * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31),
+                "seg3d_conv3d_k3_bf16_wgrad: tensor exceeds 2^31 elements");
+  const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
+  const int npairs = CIB32 * COB32;
+  const int ntz = seg3d_cdiv(D, SEG3D_WG_TZ), nty = seg3d_cdiv(H, SEG3D_WG_TY), ntx = seg3d_cdiv(W, SEG3D_WG_TX);
+  const int ntiles = N * ntz * nty * ntx;
+  const int slabs = seg3d_wgrad_slabs(N, D, H, W, npairs);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv3d_k3_wgrad_mfma_bf16_kernel, dim3(slabs, npairs), dim3(256), 0, s, x, dy, workspace, N, D, H, W,
+                     Cin, Cout, ntz, nty, ntx, ntiles, COB32);
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_bf16_wgrad");
+  const i64 total = (i64)npairs * 27 * 1024;
+  hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dw, slabs,
+                     Cin, Cout, COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_bf16_wgrad(reduce)");
   return SEG3D_OK;
 }

@@ -270,13 +270,12 @@ extern "C" int seg3d_pack_weights_thin_out(const float* w, float* wq, int A, int
 // (this version) therefore changed little; staging whole rows once is the fix that is still open.
 #define TO_PX (TO_TX + 3)                        // padded halo row: 19 voxels
 #define TO_NVP ((TO_TZ + 2) * TO_HY * TO_PX)     // 1900 padded halo voxels
-template <int CO>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float* __restrict__ x,
-                                                                      const float* __restrict__ wq,
-                                                                      const float* __restrict__ bias,
-                                                                      float* __restrict__ y, float* __restrict__ stats,
-                                                                      int N, int D, int H, int W, int Cin, int Cout,
-                                                                      int ntz, int nty, int ntx) {
+// XBF (bf16 mode): x is bf16, widened when the staged chunk is written to LDS
+template <int CO, bool XBF>
+__device__ __forceinline__ void conv3d_k3_thin_out_body(const void* __restrict__ x, const float* __restrict__ wq,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        float* __restrict__ stats, int N, int D, int H, int W, int Cin,
+                                                        int Cout, int ntz, int nty, int ntx) {
   __shared__ __attribute__((aligned(16))) float xs[8 * TO_NVP];      // [2][NVP][4]  (60.8 KB)
   const int tid = threadIdx.x;
   int b = blockIdx.x;
@@ -318,13 +317,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[o][c] = 0.f;
 
-  f32x4 xst[TO_E];
+  typename Seg3dQuad<XBF>::raw xst[TO_E];
   auto load_chunk = [&](int cib) {
     const bool half_ok = cib * 8 + hh * 4 < Cin;
 #pragma unroll
     for (int e = 0; e < TO_E; ++e) {
       const bool ok = goff[e] >= 0 && half_ok;
-      xst[e] = *reinterpret_cast<const f32x4*>(x + (ok ? (i64)goff[e] + cib * 8 : (i64)0));
+      xst[e] = Seg3dQuad<XBF>::load(x, ok ? (i64)goff[e] + cib * 8 : (i64)0);
     }
   };
   load_chunk(0);
@@ -335,7 +334,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < TO_E; ++e)
-        if (loff[e] >= 0) *reinterpret_cast<f32x4*>(xs + loff[e]) = (goff[e] >= 0 && half_ok) ? xst[e] : zero;
+        if (loff[e] >= 0)
+          *reinterpret_cast<f32x4*>(xs + loff[e]) = (goff[e] >= 0 && half_ok) ? Seg3dQuad<XBF>::cvt(xst[e]) : zero;
     }
     __syncthreads();
     if (cib + 1 < CIB) load_chunk(cib + 1);
@@ -401,13 +401,49 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float*
   }
 }
 
+template <int CO>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_kernel(const float* __restrict__ x,
+                                                                      const float* __restrict__ wq,
+                                                                      const float* __restrict__ bias,
+                                                                      float* __restrict__ y, float* __restrict__ stats,
+                                                                      int N, int D, int H, int W, int Cin, int Cout,
+                                                                      int ntz, int nty, int ntx) {
+  conv3d_k3_thin_out_body<CO, false>(x, wq, bias, y, stats, N, D, H, W, Cin, Cout, ntz, nty, ntx);
+}
+
+template <int CO>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_out_bf16_kernel(const void* __restrict__ x,
+                                                                           const float* __restrict__ wq,
+                                                                           const float* __restrict__ bias,
+                                                                           float* __restrict__ y, float* __restrict__ stats,
+                                                                           int N, int D, int H, int W, int Cin, int Cout,
+                                                                           int ntz, int nty, int ntx) {
+  conv3d_k3_thin_out_body<CO, true>(x, wq, bias, y, stats, N, D, H, W, Cin, Cout, ntz, nty, ntx);
+}
+
 extern "C" long long seg3d_conv3d_k3_thin_out_stats_count(int D, int H, int W) {
   return (long long)seg3d_cdiv(D, TO_TZ) * seg3d_cdiv(H, TO_TY) * seg3d_cdiv(W, TO_TX);
 }
 
 // x [N][D][H][W][Cin] (Cin % 4 == 0), wq = seg3d_pack_weights_thin_out(CO), y [N][D][H][W][Cout], Cout <= CO <= 8
+static int thin_out_launch(const void* xv, int x_bf16, const float* wq, const float* bias, float* y, float* stats, int N,
+                           int D, int H, int W, int Cin, int Cout, int CO, void* stream);
+
 extern "C" int seg3d_conv3d_k3_thin_out_fwd(const float* x, const float* wq, const float* bias, float* y, float* stats,
                                             int N, int D, int H, int W, int Cin, int Cout, int CO, void* stream) {
+  return thin_out_launch(x, 0, wq, bias, y, stats, N, D, H, W, Cin, Cout, CO, stream);
+}
+
+// bf16 mode: x bf16, everything else as seg3d_conv3d_k3_thin_out_fwd
+extern "C" int seg3d_conv3d_k3_thin_out_bf16_fwd(const void* x_bf16, const float* wq, const float* bias, float* y,
+                                                 float* stats, int N, int D, int H, int W, int Cin, int Cout, int CO,
+                                                 void* stream) {
+  return thin_out_launch(x_bf16, 1, wq, bias, y, stats, N, D, H, W, Cin, Cout, CO, stream);
+}
+
+static int thin_out_launch(const void* xv, int x_bf16, const float* wq, const float* bias, float* y, float* stats, int N,
+                           int D, int H, int W, int Cin, int Cout, int CO, void* stream) {
+  const float* x = reinterpret_cast<const float*>(xv);
   SEG3D_REQUIRE(x && wq && y, "seg3d_conv3d_k3_thin_out_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k3_thin_out_fwd: bad dims");
   SEG3D_REQUIRE((Cin % 4) == 0 && Cout <= CO, "seg3d_conv3d_k3_thin_out_fwd: need Cin %% 4 == 0 and Cout <= CO");
@@ -416,7 +452,19 @@ extern "C" int seg3d_conv3d_k3_thin_out_fwd(const float* x, const float* wq, con
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "seg3d_conv3d_k3_thin_out_fwd: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx));
   hipStream_t s = (hipStream_t)stream;
-  if (CO == 2) {
+  if (x_bf16) {
+    if (CO == 2)
+      hipLaunchKernelGGL((conv3d_k3_thin_out_bf16_kernel<2>), grid, dim3(256), 0, s, xv, wq, bias, y, stats, N, D, H, W, Cin,
+                         Cout, ntz, nty, ntx);
+    else if (CO == 4)
+      hipLaunchKernelGGL((conv3d_k3_thin_out_bf16_kernel<4>), grid, dim3(256), 0, s, xv, wq, bias, y, stats, N, D, H, W, Cin,
+                         Cout, ntz, nty, ntx);
+    else if (CO == 8)
+      hipLaunchKernelGGL((conv3d_k3_thin_out_bf16_kernel<8>), grid, dim3(256), 0, s, xv, wq, bias, y, stats, N, D, H, W, Cin,
+                         Cout, ntz, nty, ntx);
+    else
+      SEG3D_UNSUPPORTED("seg3d_conv3d_k3_thin_out_fwd: CO must be 2, 4 or 8 (got %d)", CO);
+  } else if (CO == 2) {
     hipLaunchKernelGGL((conv3d_k3_thin_out_kernel<2>), grid, dim3(256), 0, s, x, wq, bias, y, stats, N, D, H, W, Cin, Cout, ntz,
                        nty, ntx);
   } else if (CO == 4) {

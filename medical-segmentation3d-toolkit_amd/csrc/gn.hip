@@ -111,11 +111,14 @@ extern "C" int seg3d_gn_stats_finalize(const float* part, float* mean_rstd, int 
 }
 
 // ---- apply: out = act(gamma*(y-mean)*rstd + beta (+ res)) -------------------------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean_rstd,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const float* __restrict__ res, float* __restrict__ out, i64 S,
-                                                         int C, i64 total_vox, int relu, int ldo) {
+// RES_BF / OUT_BF (bf16 mode): the residual / the output are bf16 activations; y, statistics and the arithmetic fp32
+template <bool VEC, bool RES_BF, bool OUT_BF>
+__device__ __forceinline__ void gn_apply_body(const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              const void* __restrict__ res_v, void* __restrict__ out_v, i64 S, int C,
+                                              i64 total_vox, int relu, int ldo) {
+  const float* res = reinterpret_cast<const float*>(res_v);   // only dereferenced as float when !RES_BF
+  float* out = reinterpret_cast<float*>(out_v);
   if (VEC) {
     const int CQ = C >> 2;
     const i64 total = total_vox * CQ;
@@ -133,13 +136,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       o.z = (yv.z - mean) * rstd * g.z + b.z;
       o.w = (yv.w - mean) * rstd * g.w + b.w;
       if (res) {
-        const float4 rv = *reinterpret_cast<const float4*>(res + idx * 4);
-        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        const seg3d_f32x4 rv = Seg3dQuad<RES_BF>::cvt(Seg3dQuad<RES_BF>::load(res_v, idx * 4));
+        o.x += rv[0]; o.y += rv[1]; o.z += rv[2]; o.w += rv[3];
       }
       if (relu) {
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
       }
-      *reinterpret_cast<float4*>(out + v * ldo + 4 * q) = o;
+      const seg3d_f32x4 ov = {o.x, o.y, o.z, o.w};
+      Seg3dQuad<OUT_BF>::store(out_v, v * ldo + 4 * q, ov);
     }
   } else {
     const i64 total = total_vox * C;
@@ -154,6 +158,49 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       out[v * ldo + c] = o;
     }
   }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ res, float* __restrict__ out, i64 S,
+                                                         int C, i64 total_vox, int relu, int ldo) {
+  gn_apply_body<VEC, false, false>(y, mean_rstd, gamma, beta, res, out, S, C, total_vox, relu, ldo);
+}
+
+template <bool RES_BF, bool OUT_BF>
+__global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restrict__ y,
+                                                              const float* __restrict__ mean_rstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const void* __restrict__ res,
+                                                              void* __restrict__ out, i64 S, int C, i64 total_vox,
+                                                              int relu, int ldo) {
+  gn_apply_body<true, RES_BF, OUT_BF>(y, mean_rstd, gamma, beta, res, out, S, C, total_vox, relu, ldo);
+}
+
+// bf16 mode: `res` (optional) is bf16 when res_bf16, `out` is bf16 when out_bf16 (ld_out then counts bf16 elements);
+// y fp32.  C % 4 == 0.
+extern "C" int seg3d_gn_apply_mixed(const float* y, const float* mean_rstd, const float* gamma, const float* beta,
+                                    const void* res, void* out, int N, long long S, int C, int relu, int ld_out,
+                                    int res_bf16, int out_bf16, void* stream) {
+  SEG3D_REQUIRE(y && mean_rstd && gamma && beta && out && N > 0 && S > 0 && C > 0, "seg3d_gn_apply_mixed: bad arguments");
+  SEG3D_REQUIRE((C & 3) == 0, "seg3d_gn_apply_mixed: C must be a multiple of 4 (got %d)", C);
+  SEG3D_REQUIRE(ld_out == 0 || (ld_out >= C && (ld_out & 3) == 0), "seg3d_gn_apply_mixed: ld_out must be 0 or a multiple of 4 >= C");
+  const int ldo = ld_out ? ld_out : C;
+  const i64 total_vox = (i64)N * S;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(seg3d_ew_grid(total_vox * (C / 4), 256));
+  const bool rb = res && res_bf16, ob = out_bf16 != 0;
+#define GN_APPLY_MIXED(RB, OB)                                                                                     \
+  hipLaunchKernelGGL((gn_apply_bf16_kernel<RB, OB>), grid, dim3(256), 0, s, y, mean_rstd, gamma, beta, res, out, (i64)S, C, \
+                     total_vox, relu, ldo)
+  if (rb && ob) GN_APPLY_MIXED(true, true);
+  else if (rb) GN_APPLY_MIXED(true, false);
+  else if (ob) GN_APPLY_MIXED(false, true);
+  else GN_APPLY_MIXED(false, false);
+#undef GN_APPLY_MIXED
+  SEG3D_LAUNCH_CHECK("seg3d_gn_apply_mixed");
+  return SEG3D_OK;
 }
 
 extern "C" int seg3d_gn_apply(const float* y, const float* mean_rstd, const float* gamma, const float* beta,
@@ -186,14 +233,13 @@ static inline int gn_bwd_vpb(i64 S) {
 }
 
 // fast path: C % 4 == 0 and (C/4) divides 256: thread = (channel quad, voxel lane)
-__global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __restrict__ dout,
-                                                                  const float* __restrict__ out,
-                                                                  const float* __restrict__ y,
-                                                                  const float* __restrict__ mean_rstd,
-                                                                  const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta,
-                                                                  float* __restrict__ part, i64 S, int C, int nblk,
-                                                                  int relu, int vpb, int ldd) {
+// ACT_BF (bf16 mode): dout and out (activation-side tensors) are bf16
+template <bool ACT_BF>
+__device__ __forceinline__ void gn_bwd_reduce_vec_body(const void* __restrict__ dout, const void* __restrict__ out,
+                                                       const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ part, i64 S, int C, int nblk, int relu,
+                                                       int vpb, int ldd) {
   __shared__ float red[256 * 12];
   const int n = blockIdx.y;
   const int CQ = C >> 2, VL = 256 / CQ;
@@ -206,15 +252,25 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __r
   // 4 voxels per trip: 12 independent 16-byte loads in flight per thread (the kernel is pure streaming)
   for (i64 sv = s0 + vl; sv < s1; sv += 4 * VL) {
     float4 g[4], yv[4], o[4];
+    typename Seg3dQuad<ACT_BF>::raw graw[4], oraw[4];
     bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const i64 svu = sv + u * VL;
       ok[u] = svu < s1;
       const i64 off = ((i64)n * S + (ok[u] ? svu : s0)) * C + 4 * q;
-      g[u] = *reinterpret_cast<const float4*>(dout + ((i64)n * S + (ok[u] ? svu : s0)) * ldd + 4 * q);
+      graw[u] = Seg3dQuad<ACT_BF>::load(dout, ((i64)n * S + (ok[u] ? svu : s0)) * ldd + 4 * q);
       yv[u] = *reinterpret_cast<const float4*>(y + off);
-      if (relu && out) o[u] = *reinterpret_cast<const float4*>(out + off);
+      if (relu && out) oraw[u] = Seg3dQuad<ACT_BF>::load(out, off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const seg3d_f32x4 gv = Seg3dQuad<ACT_BF>::cvt(graw[u]);
+      g[u] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+      if (relu && out) {
+        const seg3d_f32x4 ov = Seg3dQuad<ACT_BF>::cvt(oraw[u]);
+        o[u] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      }
     }
     if (relu && !out) {
       // no residual: the forward output is a pure function of y -> recompute it (same expression as gn_apply_kernel)
@@ -260,6 +316,28 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __r
 #pragma unroll
     for (int k = 0; k < 4; ++k) { dst[3 * k + 0] = acc[k]; dst[3 * k + 1] = acc[4 + k]; dst[3 * k + 2] = acc[8 + k]; }
   }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __restrict__ dout,
+                                                                  const float* __restrict__ out,
+                                                                  const float* __restrict__ y,
+                                                                  const float* __restrict__ mean_rstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  float* __restrict__ part, i64 S, int C, int nblk,
+                                                                  int relu, int vpb, int ldd) {
+  gn_bwd_reduce_vec_body<false>(dout, out, y, mean_rstd, gamma, beta, part, S, C, nblk, relu, vpb, ldd);
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_reduce_vec_bf16_kernel(const void* __restrict__ dout,
+                                                                       const void* __restrict__ out,
+                                                                       const float* __restrict__ y,
+                                                                       const float* __restrict__ mean_rstd,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta,
+                                                                       float* __restrict__ part, i64 S, int C, int nblk,
+                                                                       int relu, int vpb, int ldd) {
+  gn_bwd_reduce_vec_body<true>(dout, out, y, mean_rstd, gamma, beta, part, S, C, nblk, relu, vpb, ldd);
 }
 
 // small-C path (C <= 16, e.g. the num_classes-channel head): thread = voxel, channels in registers
@@ -336,6 +414,23 @@ extern "C" int seg3d_gn_bwd_reduce(const float* dout, const float* out, const fl
     SEG3D_UNSUPPORTED("seg3d_gn_bwd_reduce: unsupported channel count %d (need C<=16 or C%%4==0 with C/4 | 256)", C);
   }
   SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_reduce");
+  return SEG3D_OK;
+}
+
+// bf16 mode: dout and out (optional) are bf16 activations-side tensors; y fp32.  C % 4 == 0 with (C/4) | 256.
+extern "C" int seg3d_gn_bwd_reduce_bf16(const void* dout, const void* out, const float* y, const float* mean_rstd,
+                                        const float* gamma, const float* beta, float* part, int N, long long S, int C,
+                                        int relu, int ld_dout, void* stream) {
+  SEG3D_REQUIRE(dout && y && mean_rstd && part && N > 0 && S > 0 && C > 0, "seg3d_gn_bwd_reduce_bf16: bad arguments");
+  SEG3D_REQUIRE(ld_dout == 0 || (ld_dout >= C && (ld_dout & 3) == 0),
+                "seg3d_gn_bwd_reduce_bf16: ld_dout must be 0 or a multiple of 4 >= C");
+  SEG3D_REQUIRE(gn_vec_ok(C), "seg3d_gn_bwd_reduce_bf16: needs C %% 4 == 0 with C/4 dividing 256 (got %d)", C);
+  SEG3D_REQUIRE(!relu || out || (gamma && beta), "seg3d_gn_bwd_reduce_bf16: relu mask needs the forward output or gamma/beta");
+  const int ldd = ld_dout ? ld_dout : C;
+  const int nblk = (int)seg3d_gn_bwd_blocks(S);
+  hipLaunchKernelGGL(gn_bwd_reduce_vec_bf16_kernel, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, dout, out, y,
+                     mean_rstd, gamma, beta, part, (i64)S, C, nblk, relu, gn_bwd_vpb(S), ldd);
+  SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_reduce_bf16");
   return SEG3D_OK;
 }
 
@@ -440,15 +535,18 @@ extern "C" int seg3d_gn_bwd_finalize(const float* part, const float* gamma, cons
 }
 
 // ---- backward apply: dy = rstd (gamma g - s1 - xhat s2),  dres = g -----------------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out,
-                                                             const float* __restrict__ y,
-                                                             const float* __restrict__ mean_rstd,
-                                                             const float* __restrict__ s12,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float* __restrict__ dy,
-                                                             float* __restrict__ dres, i64 S, int C, i64 total_vox,
-                                                             int relu, int ldd) {
+// ACT_BF: dout / out are bf16; DY_BF: dy (the gradient handed to the conv's dgrad / wgrad kernels) is written as bf16.
+// dres (gradient of the identity path, folded into a dgrad epilogue) stays fp32.
+template <bool VEC, bool ACT_BF, bool DY_BF>
+__device__ __forceinline__ void gn_bwd_apply_body(const void* __restrict__ dout_v, const void* __restrict__ out_v,
+                                                  const float* __restrict__ y, const float* __restrict__ mean_rstd,
+                                                  const float* __restrict__ s12, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, void* __restrict__ dy_v,
+                                                  float* __restrict__ dres, i64 S, int C, i64 total_vox, int relu,
+                                                  int ldd) {
+  const float* dout = reinterpret_cast<const float*>(dout_v);   // dereferenced as float only when !ACT_BF
+  const float* out = reinterpret_cast<const float*>(out_v);
+  float* dy = reinterpret_cast<float*>(dy_v);
   if (VEC) {
     const int CQ = C >> 2;
     const i64 total = total_vox * CQ;
@@ -458,13 +556,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       const int n = (int)(v / S);
       const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
       const float s1 = s12[2 * n], s2 = s12[2 * n + 1];
-      float4 g = *reinterpret_cast<const float4*>(dout + v * ldd + 4 * q);
+      const seg3d_f32x4 gq = Seg3dQuad<ACT_BF>::cvt(Seg3dQuad<ACT_BF>::load(dout_v, v * ldd + 4 * q));
+      float4 g = make_float4(gq[0], gq[1], gq[2], gq[3]);
       const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
       const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * q);
       if (relu) {
         float4 o;
         if (out) {
-          o = *reinterpret_cast<const float4*>(out + idx * 4);
+          const seg3d_f32x4 oq = Seg3dQuad<ACT_BF>::cvt(Seg3dQuad<ACT_BF>::load(out_v, idx * 4));
+          o = make_float4(oq[0], oq[1], oq[2], oq[3]);
         } else {
           const float4 bt = *reinterpret_cast<const float4*>(beta + 4 * q);
           o.x = (yv.x - mean) * rstd * gm.x + bt.x; o.y = (yv.y - mean) * rstd * gm.y + bt.y;
@@ -477,7 +577,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       d.y = rstd * (gm.y * g.y - s1 - (yv.y - mean) * rstd * s2);
       d.z = rstd * (gm.z * g.z - s1 - (yv.z - mean) * rstd * s2);
       d.w = rstd * (gm.w * g.w - s1 - (yv.w - mean) * rstd * s2);
-      *reinterpret_cast<float4*>(dy + idx * 4) = d;
+      const seg3d_f32x4 dq = {d.x, d.y, d.z, d.w};
+      Seg3dQuad<DY_BF>::store(dy_v, idx * 4, dq);
       if (dres) *reinterpret_cast<float4*>(dres + idx * 4) = g;
     }
   } else {
@@ -494,6 +595,54 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       if (dres) dres[idx] = g;
     }
   }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                             const float* __restrict__ y,
+                                                             const float* __restrict__ mean_rstd,
+                                                             const float* __restrict__ s12,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ dy,
+                                                             float* __restrict__ dres, i64 S, int C, i64 total_vox,
+                                                             int relu, int ldd) {
+  gn_bwd_apply_body<VEC, false, false>(dout, out, y, mean_rstd, s12, gamma, beta, dy, dres, S, C, total_vox, relu, ldd);
+}
+
+template <bool DY_BF>
+__global__ __launch_bounds__(256) void gn_bwd_apply_bf16_kernel(const void* __restrict__ dout, const void* __restrict__ out,
+                                                                  const float* __restrict__ y,
+                                                                  const float* __restrict__ mean_rstd,
+                                                                  const float* __restrict__ s12,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, void* __restrict__ dy,
+                                                                  float* __restrict__ dres, i64 S, int C, i64 total_vox,
+                                                                  int relu, int ldd) {
+  gn_bwd_apply_body<true, true, DY_BF>(dout, out, y, mean_rstd, s12, gamma, beta, dy, dres, S, C, total_vox, relu, ldd);
+}
+
+// bf16 mode: dout / out bf16; dy bf16 when dy_bf16 (else fp32); dres fp32.  C % 4 == 0.
+extern "C" int seg3d_gn_bwd_apply_bf16(const void* dout, const void* out, const float* y, const float* mean_rstd,
+                                       const float* s12, const float* gamma, const float* beta, void* dy, float* dres,
+                                       int N, long long S, int C, int relu, int ld_dout, int dy_bf16, void* stream) {
+  SEG3D_REQUIRE(dout && y && mean_rstd && s12 && gamma && dy && N > 0 && S > 0 && C > 0,
+                "seg3d_gn_bwd_apply_bf16: bad arguments");
+  SEG3D_REQUIRE((C & 3) == 0, "seg3d_gn_bwd_apply_bf16: C must be a multiple of 4 (got %d)", C);
+  SEG3D_REQUIRE(ld_dout == 0 || (ld_dout >= C && (ld_dout & 3) == 0),
+                "seg3d_gn_bwd_apply_bf16: ld_dout must be 0 or a multiple of 4 >= C");
+  SEG3D_REQUIRE(!relu || out || beta, "seg3d_gn_bwd_apply_bf16: relu mask needs the forward output or beta");
+  const int ldd = ld_dout ? ld_dout : C;
+  const i64 total_vox = (i64)N * S;
+  const dim3 grid(seg3d_ew_grid(total_vox * (C / 4), 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (dy_bf16)
+    hipLaunchKernelGGL((gn_bwd_apply_bf16_kernel<true>), grid, dim3(256), 0, s, dout, out, y, mean_rstd, s12, gamma, beta, dy,
+                       dres, (i64)S, C, total_vox, relu, ldd);
+  else
+    hipLaunchKernelGGL((gn_bwd_apply_bf16_kernel<false>), grid, dim3(256), 0, s, dout, out, y, mean_rstd, s12, gamma, beta,
+                       dy, dres, (i64)S, C, total_vox, relu, ldd);
+  SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_apply_bf16");
+  return SEG3D_OK;
 }
 
 extern "C" int seg3d_gn_bwd_apply(const float* dout, const float* out, const float* y, const float* mean_rstd,

@@ -296,6 +296,48 @@ extern "C" int seg3d_pack_weights_mfma_multi(const Seg3dPackJob* jobs_device, in
   return SEG3D_OK;
 }
 
+// bf16 images of many weight tensors in one launch (bf16 mode, after an optimizer step): one workgroup per packed
+// (32 x 16 x T) chunk, plain gather (the fp32 kernel above stages through LDS; here the 2-byte stores are the small side)
+__global__ __launch_bounds__(256) void pack_mfma_bf16_multi_kernel(const Seg3dPackJob* __restrict__ jobs, int njobs) {
+  __shared__ int sjob;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    sjob = lo;
+  }
+  __syncthreads();
+  const Seg3dPackJob jb = jobs[sjob];
+  const int AB = (jb.A + 15) / 16, T = jb.T;
+  const int chunk = (int)((i64)blockIdx.x - jb.first_block);   // = bb * AB + ab
+  const int ab = chunk % AB, bb = chunk / AB;
+  seg3d_bf16* dst = reinterpret_cast<seg3d_bf16*>(jb.wp) + (i64)chunk * T * 512;
+  for (int i = threadIdx.x; i < T * 512; i += 256) {
+    const int r = i & 7, j = (i >> 3) & 31, h = (i >> 8) & 1, t = i >> 9;
+    const int a = ab * 16 + h * 8 + r, b = bb * 32 + j;
+    float v = 0.f;
+    if (a < jb.A && b < jb.B) v = jb.w[(i64)a * jb.sa + (i64)b * jb.sb + (jb.flip ? T - 1 - t : t)];
+    dst[i] = seg3d_f2bf(v);
+  }
+}
+
+extern "C" long long seg3d_pack_job_blocks_bf16(int A, int B, int T) {
+  (void)T;
+  return (long long)((B + 31) / 32) * ((A + 15) / 16);
+}
+
+extern "C" int seg3d_pack_weights_mfma_bf16_multi(const Seg3dPackJob* jobs_device, int njobs, long long total_blocks,
+                                                  void* stream) {
+  SEG3D_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31),
+                "seg3d_pack_weights_mfma_bf16_multi: bad arguments");
+  hipLaunchKernelGGL(pack_mfma_bf16_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     jobs_device, njobs);
+  SEG3D_LAUNCH_CHECK("seg3d_pack_weights_mfma_bf16_multi");
+  return SEG3D_OK;
+}
+
 extern "C" long long seg3d_packed_mfma_floats(int A, int B, int T) {
   return (long long)((B + 31) / 32) * ((A + 7) / 8) * T * 256;
 }

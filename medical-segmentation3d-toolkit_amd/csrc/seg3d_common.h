@@ -80,6 +80,41 @@ __device__ __forceinline__ unsigned seg3d_pack2bf(float lo, float hi) {
   return (unsigned)seg3d_f2bf(lo) | ((unsigned)seg3d_f2bf(hi) << 16);
 }
 
+// Four consecutive channels of an activation tensor that is fp32 (BF = false) or bf16 (BF = true).  `raw` is what a
+// load returns (kept in staging registers untouched, so that loads stay back to back); cvt() widens it to fp32.
+typedef float seg3d_f32x4 __attribute__((ext_vector_type(4)));
+template <bool BF> struct Seg3dQuad;
+template <> struct Seg3dQuad<false> {
+  typedef seg3d_f32x4 raw;
+  static __device__ __forceinline__ raw load(const void* p, i64 elem) {
+    return *reinterpret_cast<const seg3d_f32x4*>(reinterpret_cast<const float*>(p) + elem);
+  }
+  static __device__ __forceinline__ seg3d_f32x4 cvt(raw r) { return r; }
+  static __device__ __forceinline__ void store(void* p, i64 elem, seg3d_f32x4 v) {
+    *reinterpret_cast<seg3d_f32x4*>(reinterpret_cast<float*>(p) + elem) = v;
+  }
+};
+template <> struct Seg3dQuad<true> {
+  typedef uint2 raw;
+  static __device__ __forceinline__ raw load(const void* p, i64 elem) {
+    return *reinterpret_cast<const uint2*>(reinterpret_cast<const seg3d_bf16*>(p) + elem);
+  }
+  static __device__ __forceinline__ seg3d_f32x4 cvt(raw r) {
+    seg3d_f32x4 v;
+    v[0] = __uint_as_float(r.x << 16);
+    v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16);
+    v[3] = __uint_as_float(r.y & 0xffff0000u);
+    return v;
+  }
+  static __device__ __forceinline__ void store(void* p, i64 elem, seg3d_f32x4 v) {
+    uint2 o;
+    o.x = seg3d_pack2bf(v[0], v[1]);
+    o.y = seg3d_pack2bf(v[2], v[3]);
+    *reinterpret_cast<uint2*>(reinterpret_cast<seg3d_bf16*>(p) + elem) = o;
+  }
+};
+
 // Sum NV values over a 256-thread workgroup. Result valid in thread 0. `red` must hold 4*NV floats.
 template <int NV>
 __device__ __forceinline__ void block_sum_256(float (&v)[NV], float* red) {

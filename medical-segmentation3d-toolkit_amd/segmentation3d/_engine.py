@@ -45,12 +45,23 @@ _SIGNATURES = {
     'seg3d_conv3d_k3_mfma_fwd': (_c_int, [_c_p] * 7 + [_c_int] * 6 + [_c_p]),
     'seg3d_packed_mfma_bf16_elems': (_c_ll, [_c_int, _c_int, _c_int]),
     'seg3d_pack_weights_mfma_bf16': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p]),
+    'seg3d_pack_job_blocks_bf16': (_c_ll, [_c_int, _c_int, _c_int]),
+    'seg3d_pack_weights_mfma_bf16_multi': (_c_int, [_c_p, _c_int, _c_ll, _c_p]),
     'seg3d_f32_to_bf16': (_c_int, [_c_p, _c_p, _c_ll, _c_p]),
     'seg3d_bf16_to_f32': (_c_int, [_c_p, _c_p, _c_ll, _c_p]),
     'seg3d_conv3d_k3_bf16_stats_count': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_bf16_fwd_workspace_floats': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_bf16_variant': (_c_int, [_c_int] * 6),
     'seg3d_conv3d_k3_bf16_fwd': (_c_int, [_c_p] * 7 + [_c_int] * 6 + [_c_p]),
+    'seg3d_conv3d_k3_bf16_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
+    'seg3d_conv3d_k3_bf16_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 7 + [_c_p]),
+    'seg3d_conv3d_k2s2_bf16_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
+    'seg3d_convT3d_k2s2_bf16_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
+    'seg3d_k2_bf16_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_ll, _c_ll, _c_int, _c_p]),
+    'seg3d_conv3d_k3_thin_out_bf16_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 7 + [_c_p]),
+    'seg3d_gn_apply_mixed': (_c_int, [_c_p] * 6 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    'seg3d_gn_bwd_reduce_bf16': (_c_int, [_c_p] * 7 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_p]),
+    'seg3d_gn_bwd_apply_bf16': (_c_int, [_c_p] * 9 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_p]),
     'seg3d_conv3d_k3_mfma_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 7 + [_c_p]),
     'seg3d_conv3d_k2s2_mfma_stats_count': (_c_ll, [_c_int] * 4),

@@ -24,6 +24,42 @@ _KINDS = {'k3': (3, 1, 27, False), 'k2s2': (2, 2, 8, False), 'k1': (1, 1, 1, Fal
 # set to True to force the VALU kernels everywhere (used by tests to cross-check the MFMA path)
 FORCE_DIRECT = False
 
+# bf16 mode (BASELINE config 5): activations between fused units and the gradients handed to the conv kernels are bf16,
+# packed k3 weights are bf16 (fp32 master weights), accumulation / conv outputs / GroupNorm statistics / losses fp32.
+# The reference has no such switch (it computes in fp32 throughout); the default here is fp32 as well.
+_ACT_BF16 = [False]
+
+
+def set_activation_dtype(name):
+    """'fp32' (default, the reference's arithmetic) or 'bf16'; returns the previous setting"""
+    prev = 'bf16' if _ACT_BF16[0] else 'fp32'
+    if name not in ('fp32', 'bf16'):
+        raise ValueError("activation dtype must be 'fp32' or 'bf16', got {!r}".format(name))
+    _ACT_BF16[0] = name == 'bf16'
+    return prev
+
+
+class activation_dtype(object):
+    """context manager form of set_activation_dtype"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = set_activation_dtype(self.name)
+
+    def __exit__(self, *exc):
+        set_activation_dtype(self.prev)
+
+
+def _out_bf16(C):
+    """does a unit with C output channels emit bf16 activations in the current mode (thin heads stay fp32)"""
+    return _ACT_BF16[0] and C >= 16 and C % 16 == 0 and not FORCE_DIRECT
+
+
+def _is_bf16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
 
 # ------------------------------------------------------------------------------------------------------------------
 # layout helpers
@@ -33,8 +69,12 @@ def to_ndhwc(x):
     E.require_device(x)
     if x.dim() != 5:
         raise ValueError('expected a 5-D [N,C,D,H,W] tensor, got shape {}'.format(tuple(x.shape)))
+    if x.dtype == torch.bfloat16:      # bf16 mode: activations travel between units already in NDHWC memory
+        xp = x.permute(0, 2, 3, 4, 1)
+        return xp if xp.is_contiguous() else xp.contiguous()
     if x.dtype != torch.float32:
-        raise TypeError('segmentation3d HIP engine computes in float32, got {}'.format(x.dtype))
+        raise TypeError('segmentation3d HIP engine computes in float32 (or bf16 activations in bf16 mode), got {}'
+                        .format(x.dtype))
     xp = x.permute(0, 2, 3, 4, 1)
     if xp.is_contiguous():
         return xp
@@ -59,7 +99,7 @@ def to_ncdhw_contiguous(t_ndhwc):
 
 
 def _empty(shape, like, dtype=torch.float32):
-    return torch.empty(shape, dtype=dtype, device=like.device)
+    return torch.empty(shape, dtype=dtype, device=like.device)   # fp32 unless asked otherwise (also for bf16 `like`)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -106,18 +146,22 @@ class PackedWeightCache(object):
         self.entries, self._table = {}, None
         self.epoch += 1
 
-    def get(self, w, A, B, T, sa, sb, flip):
-        key = (w.data_ptr(), w.device.index, A, B, T, sa, sb, flip)
+    def get(self, w, A, B, T, sa, sb, flip, bf16=False):
+        key = (w.data_ptr(), w.device.index, A, B, T, sa, sb, flip, bf16)
         e = self.entries.get(key)
         if e is not None and e['epoch'] == self.epoch and e['version'] == w._version:
             return e['wp']
         if e is None:
-            n = E.query('seg3d_packed_mfma_floats', A, B, T)
-            e = {'w': w, 'wp': _empty((n,), w), 'args': (A, B, T, sa, sb, flip)}
+            if bf16:
+                wp = _empty((E.query('seg3d_packed_mfma_bf16_elems', A, B, T),), w, torch.bfloat16)
+            else:
+                wp = _empty((E.query('seg3d_packed_mfma_floats', A, B, T),), w)
+            e = {'w': w, 'wp': wp, 'args': (A, B, T, sa, sb, flip), 'bf16': bf16}
             self.entries[key] = e
             self._table = None
         e['w'] = w
-        E.call('seg3d_pack_weights_mfma', E.ptr(w), E.ptr(e['wp']), A, B, T, sa, sb, flip, E.stream_ptr())
+        E.call('seg3d_pack_weights_mfma_bf16' if bf16 else 'seg3d_pack_weights_mfma', E.ptr(w), E.ptr(e['wp']), A, B, T,
+               sa, sb, flip, E.stream_ptr())
         e['epoch'], e['version'] = self.epoch, w._version
         return e['wp']
 
@@ -127,17 +171,23 @@ class PackedWeightCache(object):
         if not self.entries:
             return
         if self._table is None:
-            jobs, first = (_PackJob * len(self.entries))(), 0
-            dev = None
-            for k, e in enumerate(self.entries.values()):
-                A, B, T, sa, sb, flip = e['args']
-                jobs[k] = _PackJob(e['w'].data_ptr(), e['wp'].data_ptr(), sa, sb, first, A, B, T, flip)
-                first += E.query('seg3d_pack_job_blocks', A, B, T)
-                dev = e['wp'].device
-            host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
-            self._table = (host.to(dev), len(self.entries), first)
-        table, njobs, blocks = self._table
-        E.call('seg3d_pack_weights_mfma_multi', E.ptr(table), njobs, blocks, E.stream_ptr())
+            tables = []
+            for want_bf16 in (False, True):           # one job table (one launch) per packed format
+                group = [e for e in self.entries.values() if e['bf16'] == want_bf16]
+                if not group:
+                    tables.append(None)
+                    continue
+                jobs, first = (_PackJob * len(group))(), 0
+                for k, e in enumerate(group):
+                    A, B, T, sa, sb, flip = e['args']
+                    jobs[k] = _PackJob(e['w'].data_ptr(), e['wp'].data_ptr(), sa, sb, first, A, B, T, flip)
+                    first += E.query('seg3d_pack_job_blocks_bf16' if want_bf16 else 'seg3d_pack_job_blocks', A, B, T)
+                host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+                tables.append((host.to(group[0]['wp'].device), len(group), first))
+            self._table = tables
+        for table, name in zip(self._table, ('seg3d_pack_weights_mfma_multi', 'seg3d_pack_weights_mfma_bf16_multi')):
+            if table is not None:
+                E.call(name, E.ptr(table[0]), table[1], table[2], E.stream_ptr())
         for e in self.entries.values():
             e['epoch'], e['version'] = self.epoch, e['w']._version
 
@@ -154,18 +204,32 @@ def weight_cache(enabled):
     return prev
 
 
-def _pack_mfma(w, A, B, T, sa, sb, flip=0):
+def _pack_mfma(w, A, B, T, sa, sb, flip=0, bf16=False):
     if PACK_CACHE.enabled and not torch.cuda.is_current_stream_capturing():
-        return PACK_CACHE.get(w, A, B, T, sa, sb, flip)
+        return PACK_CACHE.get(w, A, B, T, sa, sb, flip, bf16)
     if PACK_CACHE.enabled:   # inside a hipGraph capture: only a current image may be used (no allocation, no launch)
-        key = (w.data_ptr(), w.device.index, A, B, T, sa, sb, flip)
+        key = (w.data_ptr(), w.device.index, A, B, T, sa, sb, flip, bf16)
         e = PACK_CACHE.entries.get(key)
         if e is not None and e['epoch'] == PACK_CACHE.epoch and e['version'] == w._version:
             return e['wp']
+    if bf16:
+        wp = _empty((E.query('seg3d_packed_mfma_bf16_elems', A, B, T),), w, torch.bfloat16)
+        E.call('seg3d_pack_weights_mfma_bf16', E.ptr(w), E.ptr(wp), A, B, T, sa, sb, flip, E.stream_ptr())
+        return wp
     n = E.query('seg3d_packed_mfma_floats', A, B, T)
     wp = _empty((n,), w)
     E.call('seg3d_pack_weights_mfma', E.ptr(w), E.ptr(wp), A, B, T, sa, sb, flip, E.stream_ptr())
     return wp
+
+
+def _to_f32(t):
+    """bf16 tensor -> fp32 copy (HIP converter kernel); fp32 passes through"""
+    if t.dtype != torch.bfloat16:
+        return t
+    tc = t if t.is_contiguous() else t.contiguous()
+    out = torch.empty(tc.shape, dtype=torch.float32, device=tc.device)
+    E.call('seg3d_bf16_to_f32', E.ptr(tc), E.ptr(out), tc.numel(), E.stream_ptr())
+    return out
 
 
 def _use_mfma(cin, cout):
@@ -178,6 +242,28 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None):
     N, D, H, W_, Cin = xn.shape
     assert Cin == A
     y = _empty((N, D, H, W_, B), xn)
+    if _is_bf16(xn):
+        if A % 16 == 0 and B % 4 == 0 and B >= 8 and not FORCE_DIRECT:
+            wp = _pack_mfma(w, A, B, 27, sa, sb, flip, bf16=True)
+            stats = None
+            if want_stats:
+                stats = _empty((N, E.query('seg3d_conv3d_k3_bf16_stats_count', N, D, H, W_, A, B), 2), xn)
+            nws = E.query('seg3d_conv3d_k3_bf16_fwd_workspace_floats', N, D, H, W_, A, B)
+            ws = _empty((nws,), xn) if nws else None
+            E.call('seg3d_conv3d_k3_bf16_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(addend), E.ptr(y), E.ptr(stats),
+                   E.ptr(ws), N, D, H, W_, A, B, E.stream_ptr())
+            return y, stats
+        if B <= 8 and A % 4 == 0 and addend is None and not FORCE_DIRECT:   # head forward on bf16 activations
+            CO = 2 if B <= 2 else (4 if B <= 4 else 8)
+            wq = _empty(((A + 7) // 8 * 27 * 8 * CO,), w)
+            E.call('seg3d_pack_weights_thin_out', E.ptr(w), E.ptr(wq), A, B, CO, sa, sb, flip, E.stream_ptr())
+            stats = None
+            if want_stats:
+                stats = _empty((N, E.query('seg3d_conv3d_k3_thin_out_stats_count', D, H, W_), 2), xn)
+            E.call('seg3d_conv3d_k3_thin_out_bf16_fwd', E.ptr(xn), E.ptr(wq), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H,
+                   W_, A, B, CO, E.stream_ptr())
+            return y, stats
+        xn = _to_f32(xn)       # shapes outside the bf16 kernels (not produced by vnet / vbnet): widen and continue
     if _use_mfma(A, B):
         wp = _pack_mfma(w, A, B, 27, sa, sb, flip)
         stats = None
@@ -225,8 +311,8 @@ def _k2_gather(xn, w, bias, y, A, B, sa, sb, want_stats):
     stats = None
     if want_stats:
         stats = _empty((N, E.query('seg3d_conv3d_k2s2_mfma_stats_count', Do, Ho, Wo, B), 2), xn)
-    E.call('seg3d_conv3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho, Wo, A, B,
-           E.stream_ptr())
+    E.call('seg3d_conv3d_k2s2_bf16_fwd' if _is_bf16(xn) else 'seg3d_conv3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp),
+           E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho, Wo, A, B, E.stream_ptr())
     return y, stats
 
 
@@ -237,18 +323,20 @@ def _k2_scatter(xn, w, bias, y, A, B, sa, sb, want_stats):
     stats = None
     if want_stats:
         stats = _empty((N, E.query('seg3d_convT3d_k2s2_mfma_stats_count', D, H, W_, B), 2), xn)
-    E.call('seg3d_convT3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
-           E.stream_ptr())
+    E.call('seg3d_convT3d_k2s2_bf16_fwd' if _is_bf16(xn) else 'seg3d_convT3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp),
+           E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B, E.stream_ptr())
     return y, stats
 
 
 def _k2_wgrad(P, Q, CA, CB, out_shape, sa, sb, out=None):
     """dW(t,a,b) = sum_v P[2v + t][a] Q[v][b] on the matrix cores, written to dw[a*sa + b*sb + t] (added when `out`)"""
     N, Dq, Hq, Wq, _ = Q.shape
+    if _is_bf16(P) != _is_bf16(Q):
+        P, Q = _to_f32(P), _to_f32(Q)
     ws = _empty((E.query('seg3d_k2_mfma_wgrad_workspace_floats', N, Dq, Hq, Wq, CA, CB),), P)
     dw = _empty(out_shape, P) if out is None else out
-    E.call('seg3d_k2_mfma_wgrad', E.ptr(P), E.ptr(Q), E.ptr(dw), E.ptr(ws), N, Dq, Hq, Wq, CA, CB, sa, sb,
-           int(out is not None), E.stream_ptr())
+    E.call('seg3d_k2_bf16_wgrad' if _is_bf16(P) else 'seg3d_k2_mfma_wgrad', E.ptr(P), E.ptr(Q), E.ptr(dw), E.ptr(ws), N,
+           Dq, Hq, Wq, CA, CB, sa, sb, int(out is not None), E.stream_ptr())
     return dw
 
 
@@ -278,6 +366,7 @@ def conv_forward(xn, w, bias, kind, want_stats=False):
         y = _empty((N, D // 2, H // 2, W_ // 2, Cout), xn)
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             return _k2_gather(xn, w, bias, y, Cin, Cout, 8, Cin * 8, want_stats)
+        xn = _to_f32(xn)
         wp = _pack_tapmajor(w, Cin, Cout, 8, 8, Cin * 8)
         E.call('seg3d_conv3d_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout, 2, 2,
                E.stream_ptr())
@@ -285,6 +374,7 @@ def conv_forward(xn, w, bias, kind, want_stats=False):
     if kind == 'k1':
         Cout = w.shape[0]
         _check_w(w, (Cout, Cin, 1, 1, 1), kind)
+        xn = _to_f32(xn)
         wp = _pack_tapmajor(w, Cin, Cout, 1, 1, Cin)
         y = _empty((N, D, H, W_, Cout), xn)
         E.call('seg3d_conv3d_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout, 1, 1,
@@ -296,6 +386,7 @@ def conv_forward(xn, w, bias, kind, want_stats=False):
         y = _empty((N, 2 * D, 2 * H, 2 * W_, Cout), xn)
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             return _k2_scatter(xn, w, bias, y, Cin, Cout, Cout * 8, 8, want_stats)
+        xn = _to_f32(xn)
         wp = _pack_tapmajor(w, Cin, Cout, 8, Cout * 8, 8)
         E.call('seg3d_convT3d_k2s2_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout,
                E.stream_ptr())
@@ -321,6 +412,10 @@ def conv_dgrad(dyn, w, kind, addend=None):
         return dx
     if addend is not None:
         return conv_dgrad(dyn, w, kind).add_(addend)
+    if _is_bf16(dyn):
+        cout, cin = (w.shape[0], w.shape[1]) if kind == 'k2s2' else (w.shape[1], w.shape[0])
+        if not (kind in ('k2s2', 'convT') and _use_mfma(cout, cin) and cin % 4 == 0):
+            dyn = _to_f32(dyn)         # only the stride-2 MFMA kernels take bf16 gradients here
     if kind == 'k2s2':
         Cout, Cin = w.shape[0], w.shape[1]
         # dx[2v + t][ci] = sum_co dy[v][co] w[co][ci][t]  == transposed conv of dy
@@ -373,6 +468,13 @@ def conv_wgrad(xn, dyn, w_shape, kind, out=None):
         raise ValueError('weight-gradient destination must be contiguous with shape {}'.format(tuple(w_shape)))
     if kind == 'k3':
         Cout, Cin = w_shape[0], w_shape[1]
+        if _is_bf16(xn) and _is_bf16(dyn) and _use_mfma(Cin, Cout) and Cout % 4 == 0:
+            ws = _empty((E.query('seg3d_conv3d_k3_bf16_wgrad_workspace_floats', N, D, H, W_, Cin, Cout),), xn)
+            dw = _empty(w_shape, xn) if out is None else out
+            E.call('seg3d_conv3d_k3_bf16_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(dw), E.ptr(ws), N, D, H, W_, Cin, Cout,
+                   int(out is not None), E.stream_ptr())
+            return dw
+        xn, dyn = _to_f32(xn), _to_f32(dyn)     # mixed / thin cases (head: bf16 x, fp32 dy): widen, then the fp32 kernels
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             nfl = E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W_, Cin, Cout)
             ws = _empty((nfl,), xn)
@@ -389,16 +491,16 @@ def conv_wgrad(xn, dyn, w_shape, kind, out=None):
         Cout, Cin = w_shape[0], w_shape[1]
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             return _k2_wgrad(xn, dyn, Cin, Cout, w_shape, 8, Cin * 8, out)
-        return _wgrad_direct(xn, dyn, Cin, Cout, 2, 2, 8, w_shape, 8, Cin * 8, out)
+        return _wgrad_direct(_to_f32(xn), _to_f32(dyn), Cin, Cout, 2, 2, 8, w_shape, 8, Cin * 8, out)
     if kind == 'k1':
         Cout, Cin = w_shape[0], w_shape[1]
-        return _wgrad_direct(xn, dyn, Cin, Cout, 1, 1, 1, w_shape, 1, Cin, out)
+        return _wgrad_direct(_to_f32(xn), _to_f32(dyn), Cin, Cout, 1, 1, 1, w_shape, 1, Cin, out)
     if kind == 'convT':
         Cin, Cout = w_shape[0], w_shape[1]
         # dW(t, a=co, b=ci) = sum_i dy[2i + t][co] x[i][ci]  -> w[ci][co][t]
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             return _k2_wgrad(dyn, xn, Cout, Cin, w_shape, 8, Cout * 8, out)
-        return _wgrad_direct(dyn, xn, Cout, Cin, 2, 2, 8, w_shape, 8, Cout * 8, out)
+        return _wgrad_direct(_to_f32(dyn), _to_f32(xn), Cout, Cin, 2, 2, 8, w_shape, 8, Cout * 8, out)
     raise ValueError('unknown conv kind {}'.format(kind))
 
 
@@ -419,18 +521,23 @@ def gn_stats(yn, stats_partial=None, eps=GN_EPS):
     return mean_rstd
 
 
-def gn_apply(yn, mean_rstd, gamma, beta, resn, relu, out=None):
+def gn_apply(yn, mean_rstd, gamma, beta, resn, relu, out=None, out_bf16=False):
     """out: optional destination -- a channel slice [..., c0:c0+C] of a wider contiguous NDHWC buffer (the up-branch
-    half of a skip concatenation is normalised straight into the concatenated tensor)"""
+    half of a skip concatenation is normalised straight into the concatenated tensor).
+    bf16 mode: `resn` may be bf16; the output is bf16 when out_bf16 (or when `out` is a bf16 buffer)."""
     N, D, H, W_, C = yn.shape
     ld = 0
     if out is None:
-        out = torch.empty_like(yn)
+        out = torch.empty(yn.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=yn.device)
     else:
         if tuple(out.shape) != tuple(yn.shape) or out.stride(4) != 1 or out.stride(3) < C or out.stride(3) % 4 or \
                 out.stride(2) != W_ * out.stride(3) or out.stride(1) != H * out.stride(2) or out.stride(0) != D * out.stride(1):
             raise ValueError('gn_apply destination must be a channel slice of a contiguous NDHWC buffer')
         ld = out.stride(3)
+    if _is_bf16(out) or _is_bf16(resn):
+        E.call('seg3d_gn_apply_mixed', E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta), E.ptr(resn), E.ptr(out), N,
+               D * H * W_, C, int(relu), ld, int(_is_bf16(resn)), int(_is_bf16(out)), E.stream_ptr())
+        return out
     E.call('seg3d_gn_apply', E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta), E.ptr(resn), E.ptr(out), N,
            D * H * W_, C, int(relu), ld, E.stream_ptr())
     return out
@@ -448,7 +555,8 @@ def _row_stride(t, C):
     return ld
 
 
-def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_dbias=True, sinks=(None, None, None)):
+def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_dbias=True, sinks=(None, None, None),
+                dy_bf16=False):
     """returns (dy, dres or None, dgamma, dbeta, dbias or None).  `outn` (the unit's forward output) is only read when
     it cannot be recomputed from y, i.e. when a residual was added; pass None otherwise.
     sinks = (dgamma, dbeta, dbias) destinations ([C] tensors) the finalize kernel ADDS into; the matching return
@@ -459,8 +567,13 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
     part = _empty((N, nblk, C, 3), yn)
     mask_src = outn if relu else None
     ldd = _row_stride(doutn, C)   # dout may be a channel slice of the concatenated gradient (UpCatFunction)
-    E.call('seg3d_gn_bwd_reduce', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta),
-           E.ptr(part), N, S, C, int(relu), ldd, E.stream_ptr())
+    act_bf16 = _is_bf16(doutn)    # bf16 mode: the incoming gradient has the dtype of the unit's (bf16) output
+    if act_bf16 != (_is_bf16(mask_src) if mask_src is not None else act_bf16):
+        raise TypeError('GroupNorm backward: gradient and saved output differ in dtype')
+    if dy_bf16 and not act_bf16:
+        raise TypeError('GroupNorm backward: a bf16 conv gradient needs a bf16 unit output')
+    E.call('seg3d_gn_bwd_reduce_bf16' if act_bf16 else 'seg3d_gn_bwd_reduce', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn),
+           E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta), E.ptr(part), N, S, C, int(relu), ldd, E.stream_ptr())
     abx = _empty((N, C, 3), yn)
     s12 = _empty((N, 2), yn)
     sg, sb_, sc = sinks
@@ -473,10 +586,14 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
     acc_mask = (1 if sg is not None else 0) | (2 if sb_ is not None else 0) | (4 if (want_dbias and sc is not None) else 0)
     E.call('seg3d_gn_bwd_finalize', E.ptr(part), E.ptr(gamma), E.ptr(mean_rstd), E.ptr(abx), E.ptr(s12), E.ptr(dgamma),
            E.ptr(dbeta), E.ptr(dbias), N, S, C, acc_mask, E.stream_ptr())
-    dy = torch.empty_like(yn)
+    dy = torch.empty(yn.shape, dtype=torch.bfloat16 if dy_bf16 else torch.float32, device=yn.device)
     dres = torch.empty_like(yn) if want_dres else None
-    E.call('seg3d_gn_bwd_apply', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(s12), E.ptr(gamma),
-           E.ptr(beta), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), ldd, E.stream_ptr())
+    if act_bf16:
+        E.call('seg3d_gn_bwd_apply_bf16', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(s12),
+               E.ptr(gamma), E.ptr(beta), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), ldd, int(dy_bf16), E.stream_ptr())
+    else:
+        E.call('seg3d_gn_bwd_apply', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(s12), E.ptr(gamma),
+               E.ptr(beta), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), ldd, E.stream_ptr())
     return (dy, dres, dgamma if sg is None else None, dbeta if sb_ is None else None,
             dbias if (want_dbias and sc is None) else None)
 
@@ -569,7 +686,11 @@ class ConvGnActFunction(torch.autograd.Function):
             if resn.shape != yn.shape:
                 raise ValueError('residual shape {} does not match conv output {}'.format(tuple(residual.shape),
                                                                                           tuple(from_ndhwc(yn).shape)))
-        outn = gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), resn, relu)
+        C = yn.shape[4]
+        outn = gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), resn, relu, out_bf16=_out_bf16(C))
+        # the gradient w.r.t. the conv output goes to the dgrad / wgrad kernels as bf16 when they take bf16 (same
+        # condition as in forward: bf16 input activations and MFMA-shaped channel counts on both sides)
+        ctx.dy_bf16 = _is_bf16(xn) and _is_bf16(outn) and xn.shape[4] % 16 == 0
         ctx.kind, ctx.relu = kind, bool(relu)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.w_shape = tuple(weight.shape)
@@ -588,7 +709,8 @@ class ConvGnActFunction(torch.autograd.Function):
         sw, sb_, sg, sbt = ctx.sinks
         dy, dres, dgamma, dbeta, dbias = gn_backward(dn, outn, yn, mean_rstd, gamma, beta, ctx.relu,
                                                      want_dres=ctx.has_res and ctx.needs_input_grad[5],
-                                                     want_dbias=ctx.has_bias, sinks=_views(sg, sbt, sb_))
+                                                     want_dbias=ctx.has_bias, sinks=_views(sg, sbt, sb_),
+                                                     dy_bf16=ctx.dy_bf16)
         dx = None
         addend = None
         if ctx.res_is_x and dres is not None and ctx.needs_input_grad[0]:
@@ -637,9 +759,15 @@ class UpCatFunction(torch.autograd.Function):
         Cb = sn.shape[4]
         if Ca % 4 or Cb % 4:
             raise ValueError('fused up + cat needs channel counts that are multiples of 4')
-        cat = _empty((N, D, H, W_, Ca + Cb), yn)
+        bf = _is_bf16(sn)          # bf16 mode: the skip arrives as bf16, the concatenated buffer is bf16 as a whole
+        if bf and (Ca % 16 or Cb % 16):
+            raise ValueError('fused up + cat in bf16 mode needs channel counts that are multiples of 16')
+        cat = _empty((N, D, H, W_, Ca + Cb), yn, torch.bfloat16 if bf else torch.float32)
         gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), None, relu, out=cat[..., :Ca])
-        E.call('seg3d_copy_channels', E.ptr(sn), E.ptr(cat), N * D * H * W_, Cb, Cb, 0, Ca + Cb, Ca, E.stream_ptr())
+        k = 2 if bf else 1         # the copy kernel moves 32-bit words: a bf16 row of C channels is C / 2 of them
+        E.call('seg3d_copy_channels', E.ptr(sn), E.ptr(cat), N * D * H * W_, Cb // k, Cb // k, 0, (Ca + Cb) // k, Ca // k,
+               E.stream_ptr())
+        ctx.dy_bf16 = bf and _is_bf16(xn) and xn.shape[4] % 16 == 0
         ctx.relu, ctx.has_bias, ctx.w_shape, ctx.ca = bool(relu), bias is not None, tuple(weight.shape), Ca
         ctx.sinks = (G.lookup(weight), G.lookup(bias), G.lookup(gamma), G.lookup(beta))
         ctx.save_for_backward(xn, w, gamma.detach(), beta.detach(), yn, mean_rstd)
@@ -651,7 +779,8 @@ class UpCatFunction(torch.autograd.Function):
         dn = to_ndhwc(dout)                                  # [N, D, H, W, Ca + Cb], contiguous
         sw, sb_, sg, sbt = ctx.sinks
         dy, _, dgamma, dbeta, dbias = gn_backward(dn[..., :ctx.ca], None, yn, mean_rstd, gamma, beta, ctx.relu,
-                                                  want_dres=False, want_dbias=ctx.has_bias, sinks=_views(sg, sbt, sb_))
+                                                  want_dres=False, want_dbias=ctx.has_bias, sinks=_views(sg, sbt, sb_),
+                                                  dy_bf16=ctx.dy_bf16)
         dx = from_ndhwc(conv_dgrad(dy, w, 'convT')) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:

@@ -23,6 +23,7 @@
 //   one (ci block, co block) pair and walks a strided share of the spatial tiles; wave w owns taps 7w..7w+6.
 //   A = x[v + tap][ci] and B = dy[v][co] are single ds_read_b32 per lane (lanes 0-31: voxel 2k, 32-63: 2k+1).
 //   Partial slabs are reduced in fixed order by conv3d_k3_wgrad_reduce_kernel (bitwise reproducible).
+#include <type_traits>
 #include "seg3d_common.h"
 #include "seg3d_hip.h"
 #include <math.h>
@@ -1544,6 +1545,287 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix cores (conv3d_k3_wgrad3_bf16_kernel), bf16 mode.
+//   dW[tap][ci][co] = sum_v x[v + tap][ci] dy[v][co]: M = ci, N = co, K = voxels, v_mfma_f32_32x32x16_bf16.  Both operands
+//   want 8 consecutive K values (voxels) of ONE channel per lane, while memory (and an LDS-DMA image of it) is
+//   [voxel][channel]: the hardware transposing read ds_read_b64_tr_b16 closes the gap -- per 16-lane group it takes four
+//   rows (voxels, each with its own address: the tap shift needs no alignment) x 16 channels and hands every lane one
+//   channel's four voxels.  Two such reads make one operand.
+//   Structure as conv3d_k3_wgrad2_kernel: one persistent workgroup per CU, 7 accumulators per wave (taps 7w..7w+6) kept
+//   across the tiles of its slab, tiles (x halo tile [NVH][32] + dy tile [MTV][32], 64-byte rows) arriving by LDS-DMA,
+//   one barrier per tile.  Per 16-voxel step a wave issues 16 transposing reads and 7 MFMAs: a tile is multiplied in
+//   ~1800 cycles, LESS than one trip to memory, so a single tile of lookahead (the fp32 kernels' scheme) left the kernel
+//   waiting for its DMAs at every barrier (measured 4600 cycles per tile).  Hence a ring of 4 LDS buffers: while tile t
+//   is multiplied, tiles t+1 and t+2 are landing and the pieces of t+3 are issued one per step; the barrier of a tile is
+//   preceded by a COUNTED s_waitcnt vmcnt that leaves the younger tiles' DMAs in flight (every wave issues exactly NG
+//   pieces per tile -- the ring slots are padded to whole groups -- so the count is a constant).
+//   Tiles must lie inside the volume (D, H, W multiples of the tile): the launcher falls back to the register-staged
+//   kernel otherwise.
+// ----------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void seg3d_static_for(F&& f) {   // f(integral_constant<int, I>) for I = 0 .. N-1
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    seg3d_static_for<N, I + 1>(f);
+  }
+}
+
+#define SEG3D_WG3_NBUF 4
+#ifndef SEG3D_WG3_EXP_NODMA   // measurement builds only (tools/ubench/README.md): 1 = no DMA in the steady state
+#define SEG3D_WG3_EXP_NODMA 0
+#endif
+#ifndef SEG3D_WG3_EXP_NOMFMA  // 1 = skip the MFMAs (reads and DMA only)
+#define SEG3D_WG3_EXP_NOMFMA 0
+#endif
+// s_waitcnt with only vmcnt set (gfx9 encoding: vmcnt = bits [3:0] and [15:14], expcnt [6:4], lgkmcnt [11:8])
+#define SEG3D_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt((((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8)))
+
+// The transposing reads are issued as inline asm: through the builtin the compiler treats them as LDS reads that may
+// alias the LDS-DMA writes in flight and puts an s_waitcnt vmcnt(0) in front of every step, which serialises the ring.
+// The asm form is invisible to that analysis; the price is a hand-placed s_waitcnt lgkmcnt(0) (SEG3D_TR_WAIT, tied to
+// the operand registers so that no MFMA can be scheduled above it).
+#define SEG3D_TR_READ(dst, addr, imm) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+__device__ __forceinline__ bf16x8 seg3d_tr_join(s16x4 lo, s16x4 hi) {
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int TZ, int TY, int TX>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad3_bf16_kernel(const seg3d_bf16* __restrict__ x,
+                                                                         const seg3d_bf16* __restrict__ dy,
+                                                                         float* __restrict__ part, int N, int D, int H,
+                                                                         int W, int Cin, int Cout, int ntz, int nty, int ntx,
+                                                                         int ntiles, int slabs, int COB32) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HY = TY + 2, HX = TX + 2;
+  constexpr int NVH = (TZ + 2) * HY * HX;              // halo voxels of the x tile
+  constexpr int MTV = TZ * TY * TX;                    // voxels of the dy tile
+  static_assert(MTV % 16 == 0 && (TX == 8 || TX == 4) && TY % 2 == 0, "tile shape");
+  constexpr int XPC = (NVH + 15) / 16, YPC = MTV / 16; // 1-KiB DMA pieces (16 voxels x 32 bf16 channels)
+  constexpr int NP = XPC + YPC;
+  constexpr int NG = (NP + 3) / 4;                     // piece groups per wave per tile
+  constexpr int BUFB = NG * 4 * 1024;                  // bytes per ring slot (padded to whole groups: see the header)
+  constexpr int NBUF = SEG3D_WG3_NBUF;
+  constexpr int STEPS = MTV / 16;                      // K steps (16 voxels) per tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int slab = blockIdx.x % slabs;
+  const int pg = blockIdx.x / slabs;                   // (ci block, co block)
+  const int cib = pg / COB32, cob = pg % COB32;
+  const int ci0 = cib * 32, co0 = cob * 32;
+  const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz;
+  auto fdiv = [](int v, float r) { return (int)(((float)v + 0.5f) * r); };
+
+  int tapoff[7];   // bytes
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    int tap = wave * 7 + j;
+    if (tap > 26) tap = 26;  // idle slot of wave 3 recomputes tap 26 into a discarded accumulator
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    tapoff[j] = ((kz * HY + ky) * HX + kx) * 64;
+  }
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // transposing-read addresses of this lane (bytes): group of 16 lanes = (channel half, K half); lane 4q + p of a group
+  // supplies row q (a voxel), channels 4p .. 4p+3 of the group's 16
+  const int l16 = lane & 15, rq = l16 >> 2, rp = l16 & 3;
+  const int colb = (16 * ((lane >> 4) & 1) + 4 * rp) * 2;
+  const int r0 = 8 * lh + rq, r1 = r0 + 4;             // voxel of the 16-voxel step
+  const int xa0 = ((r0 / TX) * HX + (r0 % TX)) * 64 + colb, xa1 = ((r1 / TX) * HX + (r1 % TX)) * 64 + colb;
+  const int yb0 = XPC * 1024 + r0 * 64 + colb, yb1 = XPC * 1024 + r1 * 64 + colb;
+
+  // DMA pieces: piece p = wave + 4 g; lane -> voxel 16 p' + (lane >> 2), channels 8 (lane & 3) .. +7 (16 bytes)
+  const int lv = lane >> 2, lq = lane & 3;
+  int prel[NG], pflag[NG];  // bf16-element offset from the tile-origin voxel; halo-face bits (bit 6: always zero)
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int p = wave + 4 * g;
+    prel[g] = 0;
+    pflag[g] = 64;
+    if (p < XPC) {
+      const int v = p * 16 + lv;
+      if (v < NVH) {
+        const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
+        prel[g] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + ci0 + 8 * lq;
+        pflag[g] = (hz == 0 ? 1 : 0) | (hz == TZ + 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == TY + 1 ? 8 : 0) |
+                   (hx == 0 ? 16 : 0) | (hx == TX + 1 ? 32 : 0) | (ci0 + 8 * lq < Cin ? 0 : 64);
+      }
+    } else if (p < NP) {
+      const int v = (p - XPC) * 16 + lv;
+      const int co = co0 + 8 * lq;
+      prel[g] = (((v / (TX * TY)) * H + (v / TX) % TY) * W + v % TX) * Cout + co;
+      pflag[g] = co < Cout ? 0 : 64;
+    }                                                   // p >= NP: padding piece (zeros into the slot's tail)
+  }
+  int tn = 0, tz0 = 0, ty0 = 0, tx0 = 0;
+  auto set_tile = [&](int tile) {
+    int b = tile;
+    int q = fdiv(b, rNTX);
+    const int tix = b - q * ntx;
+    b = q;
+    q = fdiv(b, rNTY);
+    const int tiy = b - q * nty;
+    b = q;
+    q = fdiv(b, rNTZ);
+    const int tiz = b - q * ntz;
+    tn = q;
+    tz0 = tiz * TZ, ty0 = tiy * TY, tx0 = tix * TX;
+  };
+  auto issue_piece = [&](int g, char* buf, const seg3d_bf16* xbase, const seg3d_bf16* ybase, int faces) {
+    const int p = wave + 4 * g;                          // every wave issues all NG pieces (counted vmcnt waits)
+    const seg3d_bf16* base = p < XPC ? xbase : ybase;    // uniform
+    const void* src = (pflag[g] & faces) ? (const void*)seg3d_zero16 : (const void*)(base + prel[g]);
+    seg3d_glds16(reinterpret_cast<const float*>(src), reinterpret_cast<float*>(buf + p * 1024));
+  };
+  auto tile_sources = [&](const seg3d_bf16*& xbase, const seg3d_bf16*& ybase, int& faces) {
+    faces = 64 | (tz0 == 0 ? 1 : 0) | (tz0 + TZ >= D ? 2 : 0) | (ty0 == 0 ? 4 : 0) | (ty0 + TY >= H ? 8 : 0) |
+            (tx0 == 0 ? 16 : 0) | (tx0 + TX >= W ? 32 : 0);
+    const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
+    xbase = x + origin * Cin;
+    ybase = dy + origin * Cout;
+  };
+
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const unsigned lds_addr = (unsigned)(size_t)((__attribute__((address_space(3))) char*)ldsb);   // LDS byte offset
+  // Tile walk.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own 4 MB L2, and the
+  // halo tiles of neighbouring tiles overlap by 2.8x: XCD j therefore owns the CONTIGUOUS eighth j of the tile list and its
+  // slabs / 8 workgroups walk it side by side (tile = first_j + k * (slabs / 8) + local), so that the x / y neighbours of
+  // a tile are fetched through the same L2 at about the same time.  (slabs % 8 != 0: plain strided walk.)
+  const bool xcd_walk = (slabs & 7) == 0;
+  const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = slabs >> 3;
+  const int xcd = slab & 7, local = slab >> 3;
+  const int first = xcd_walk ? xcd * per_xcd + local : slab;
+  const int stride = xcd_walk ? wg_per_xcd : slabs;
+  int limit = ntiles;
+  if (xcd_walk && (xcd + 1) * per_xcd < ntiles) limit = (xcd + 1) * per_xcd;
+  // ring: tile number k of this workgroup (tile index first + k * stride) lives in slot k % NBUF
+  const int mytiles = first < limit ? (limit - first + stride - 1) / stride : 0;
+  auto issue_tile_all = [&](int k) {   // prologue only: all pieces of tile k back to back
+    set_tile(first + k * stride);
+    const seg3d_bf16 *xb, *yb;
+    int faces;
+    tile_sources(xb, yb, faces);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) issue_piece(g, ldsb + (k % NBUF) * BUFB, xb, yb, faces);
+  };
+  for (int k = 0; k < NBUF - 1 && k < mytiles; ++k) issue_tile_all(k);
+  for (int k = 0; k < mytiles; ++k) {
+    // tile k has landed once at most the DMAs of the younger tiles in flight (k+1 .. min(k + NBUF - 2, last)) are pending
+    const int younger = (mytiles - 1 - k) < (NBUF - 2) ? (mytiles - 1 - k) : (NBUF - 2);
+    if (younger >= 2) SEG3D_WAIT_VMCNT(2 * NG);
+    else if (younger == 1) SEG3D_WAIT_VMCNT(NG);
+    else SEG3D_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();      // everyone's pieces of tile k landed; everyone done with tile k - 1 (its slot is free)
+    const int kn = k + NBUF - 1;       // tile whose pieces are issued during this one, into the slot of tile k - 1
+    const bool more = kn < mytiles;
+    char* nxt = ldsb + (kn % NBUF) * BUFB;
+    const seg3d_bf16 *xb = x, *yb = dy;
+    int faces = 64;
+    if (more) {
+      set_tile(first + kn * stride);
+      tile_sources(xb, yb, faces);
+    }
+    // LDS byte addresses of this tile's reads: per-lane base + a compile-time offset per step
+    const unsigned cb = lds_addr + (unsigned)((k % NBUF) * BUFB);
+    unsigned xad0[7], xad1[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      xad0[j] = cb + (unsigned)(tapoff[j] + xa0);
+      xad1[j] = cb + (unsigned)(tapoff[j] + xa1);
+    }
+    const unsigned yad0 = cb + (unsigned)yb0, yad1 = cb + (unsigned)yb1;
+    // software pipeline: the 16 reads of step st + 1 are issued before the 7 MFMAs of step st and waited for after them
+    // (macros, not lambdas: the asm offsets must be integer constant expressions)
+    s16x4 lo[2][8], hi[2][8];   // [pipeline slot][0..6 = taps, 7 = dy]
+#define SEG3D_WG3_XO(ST) ((((16 * (ST) / (TX * TY)) * HY + (16 * (ST) / TX) % TY) * HX + (16 * (ST)) % TX) * 64)
+#define SEG3D_WG3_READS(ST, SLOT)                                                   \
+  do {                                                                              \
+    SEG3D_TR_READ(lo[SLOT][7], yad0, 16 * (ST) * 64);                               \
+    SEG3D_TR_READ(hi[SLOT][7], yad1, 16 * (ST) * 64);                               \
+    SEG3D_TR_READ(lo[SLOT][0], xad0[0], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(hi[SLOT][0], xad1[0], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(lo[SLOT][1], xad0[1], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(hi[SLOT][1], xad1[1], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(lo[SLOT][2], xad0[2], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(hi[SLOT][2], xad1[2], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(lo[SLOT][3], xad0[3], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(hi[SLOT][3], xad1[3], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(lo[SLOT][4], xad0[4], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(hi[SLOT][4], xad1[4], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(lo[SLOT][5], xad0[5], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(hi[SLOT][5], xad1[5], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(lo[SLOT][6], xad0[6], SEG3D_WG3_XO(ST));                          \
+    SEG3D_TR_READ(hi[SLOT][6], xad1[6], SEG3D_WG3_XO(ST));                          \
+  } while (0)
+// The reads are a continuous in-order stream, per step: dy, tap 0, tap 1 .. tap 6 (2 reads each).  The reads of
+// (step + 1, tap j) go out right after MFMA (step, j) -- dy with tap 0 -- and an MFMA waits with a COUNTED lgkmcnt that
+// leaves everything younger than its own operands in flight (14 reads, 12 for tap 0; draining to lgkmcnt(0) every 16 reads
+// ran the LDS at a third of its rate with one wave per SIMD).  The empty asm ties the wait to the operand registers.
+#define SEG3D_WG3_LGKM(n) __builtin_amdgcn_s_waitcnt((15 | (3 << 14) | (7 << 4) | ((n) << 8)))
+#define SEG3D_WG3_TIE(SLOT, J) asm volatile("" : "+v"(lo[SLOT][J]), "+v"(hi[SLOT][J]))
+#define SEG3D_WG3_MF(ST, J)                                                                                           \
+  SEG3D_WG3_LGKM(((ST) + 1 < STEPS) ? ((J) == 0 ? 12 : 14) : 2 * (6 - (J)));                                          \
+  SEG3D_WG3_TIE((ST) & 1, J);                                                                                         \
+  if ((J) == 0) {                                                                                                     \
+    SEG3D_WG3_TIE((ST) & 1, 7);                                                                                       \
+    bop = seg3d_tr_join(lo[(ST) & 1][7], hi[(ST) & 1][7]);                                                            \
+  }                                                                                                                   \
+  if (!SEG3D_WG3_EXP_NOMFMA || (ST) == 0)                                                                             \
+    acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(seg3d_tr_join(lo[(ST) & 1][J], hi[(ST) & 1][J]), bop, acc[J], 0, \
+                                                     0, 0);                                                           \
+  if constexpr ((ST) + 1 < STEPS) {                                                                                   \
+    if ((J) == 0) {                                                                                                   \
+      SEG3D_TR_READ(lo[((ST) + 1) & 1][7], yad0, 16 * ((ST) + 1) * 64);                                               \
+      SEG3D_TR_READ(hi[((ST) + 1) & 1][7], yad1, 16 * ((ST) + 1) * 64);                                               \
+    }                                                                                                                 \
+    SEG3D_TR_READ(lo[((ST) + 1) & 1][J], xad0[J], SEG3D_WG3_XO((ST) + 1));                                            \
+    SEG3D_TR_READ(hi[((ST) + 1) & 1][J], xad1[J], SEG3D_WG3_XO((ST) + 1));                                            \
+  }
+#define SEG3D_WG3_STEP(ST)                                                                                            \
+  if constexpr ((ST) < STEPS) {                                                                                       \
+    SEG3D_WG3_MF(ST, 0) SEG3D_WG3_MF(ST, 1) SEG3D_WG3_MF(ST, 2) SEG3D_WG3_MF(ST, 3)                                   \
+    if (more && !SEG3D_WG3_EXP_NODMA) { /* the pieces of tile k + NBUF - 1, spread over the steps */                  \
+      _Pragma("unroll") for (int g = ((ST) * NG) / STEPS; g < (((ST) + 1) * NG) / STEPS; ++g)                         \
+          issue_piece(g, nxt, xb, yb, faces);                                                                         \
+    }                                                                                                                 \
+    SEG3D_WG3_MF(ST, 4) SEG3D_WG3_MF(ST, 5) SEG3D_WG3_MF(ST, 6)                                                       \
+  }
+    bf16x8 bop;
+    SEG3D_WG3_READS(0, 0);   // dy, tap 0 .. tap 6 of step 0
+    SEG3D_WG3_STEP(0) SEG3D_WG3_STEP(1) SEG3D_WG3_STEP(2) SEG3D_WG3_STEP(3)
+    SEG3D_WG3_STEP(4) SEG3D_WG3_STEP(5) SEG3D_WG3_STEP(6) SEG3D_WG3_STEP(7)
+    static_assert(STEPS <= 8, "steps");
+#undef SEG3D_WG3_STEP
+#undef SEG3D_WG3_MF
+#undef SEG3D_WG3_TIE
+#undef SEG3D_WG3_LGKM
+#undef SEG3D_WG3_READS
+#undef SEG3D_WG3_XO
+  }
+
+  // part[slab][pair = cib * COB32 + cob][tap][ci row][co col]
+  const int pair = cib * COB32 + cob;
+  float* dst = part + ((i64)slab * (COB32 * ((Cin + 31) / 32)) + pair) * 27 * 1024;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = wave * 7 + j;
+    if (tap < 27) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[tap * 1024 + mfma_row(r, lh) * 32 + li] = acc[j][r];
+    }
+  }
+}
+
 // dw[a*sa + b*sb + t] = sum_slab part[slab][a/32][b/32][t][a%32][b%32]   (a = reduction-side channel, b = output channel)
 // 64 outputs per workgroup, 4 slab groups per output (coalesced reads of every slab), combined in a fixed order.
 __global__ __launch_bounds__(256) void conv3d_k3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int slabs, int A,
@@ -1689,10 +1971,67 @@ extern "C" int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float
   return SEG3D_OK;
 }
 
-// bf16 mode: x and dy bf16 (first-generation kernel, converted while staging; fp32 MFMA, fp32 dw)
+// bf16 mode: x and dy bf16.  Levels whose extents are multiples of a tile (4x4x8, else 4x4x4) run the bf16-MFMA kernel
+// conv3d_k3_wgrad3_bf16_kernel; other shapes the first-generation kernel with the operands widened while staging.
+struct Seg3dWgrad16Plan {
+  int version;  // 3: bf16 MFMA, transposing LDS reads; 1: register-staged, fp32 MFMA
+  int tx;       // 8 or 4 (version 3)
+  int slabs;
+};
+
+static Seg3dWgrad16Plan seg3d_wgrad16_plan(int N, int D, int H, int W, int Cin, int Cout) {
+  const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
+  const int npairs = CIB32 * COB32;
+  Seg3dWgrad16Plan p;
+  p.version = 1;
+  p.tx = 8;
+  p.slabs = seg3d_wgrad_slabs(N, D, H, W, npairs);
+  static int v3 = -1;
+  if (v3 < 0) {
+    const char* e = getenv("SEG3D_WGRAD_BF16_MFMA");   // 0: always the register-staged kernel (measurement switch)
+    v3 = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!v3 || (Cin & 7) || (Cout & 7) || D % 4 || H % 4 || W % 4) return p;
+  const int tx = (W % 8 == 0) ? 8 : 4;
+  const i64 ntiles = (i64)N * (D / 4) * (H / 4) * (W / tx);
+  if (ntiles >= SEG3D_FDIV_MAX) return p;
+  p.version = 3;
+  p.tx = tx;
+  int slabs = 256 / npairs;   // one resident workgroup per CU over the whole grid
+  if (slabs > (ntiles + 1) / 2) slabs = (int)((ntiles + 1) / 2);
+  if (slabs < 1) slabs = 1;
+  p.slabs = slabs;
+  return p;
+}
+
 extern "C" long long seg3d_conv3d_k3_bf16_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
   const int npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
-  return (long long)seg3d_wgrad_slabs(N, D, H, W, npairs) * npairs * 27 * 1024;
+  return (long long)seg3d_wgrad16_plan(N, D, H, W, Cin, Cout).slabs * npairs * 27 * 1024;
+}
+
+template <int TX>
+static int launch_wgrad3(const void* x, const void* dy, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
+                         int slabs, hipStream_t s) {
+  constexpr int TZ = 4, TY = 4;
+  const int ntz = D / TZ, nty = H / TY, ntx = W / TX;
+  const int ntiles = N * ntz * nty * ntx;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad3_bf16_kernel<TZ, TY, TX>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) {
+      seg3d_set_error("conv3d_k3_wgrad3_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SEG3D_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
+  constexpr int NVH = (TZ + 2) * (TY + 2) * (TX + 2), MTV = TZ * TY * TX;
+  const size_t lds = (size_t)SEG3D_WG3_NBUF * ((((NVH + 15) / 16) + MTV / 16 + 3) / 4) * 4 * 1024;
+  hipLaunchKernelGGL((conv3d_k3_wgrad3_bf16_kernel<TZ, TY, TX>), dim3((unsigned)(slabs * CIB32 * COB32)), dim3(256), lds, s,
+                     reinterpret_cast<const seg3d_bf16*>(x), reinterpret_cast<const seg3d_bf16*>(dy), workspace, N, D, H, W,
+                     Cin, Cout, ntz, nty, ntx, ntiles, slabs, COB32);
+  return SEG3D_OK;
 }
 
 extern "C" int seg3d_conv3d_k3_bf16_wgrad(const void* x, const void* dy, float* dw, float* workspace, int N, int D, int H,
@@ -1705,12 +2044,19 @@ extern "C" int seg3d_conv3d_k3_bf16_wgrad(const void* x, const void* dy, float* 
                 "seg3d_conv3d_k3_bf16_wgrad: tensor exceeds 2^31 elements");
   const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
   const int npairs = CIB32 * COB32;
-  const int ntz = seg3d_cdiv(D, SEG3D_WG_TZ), nty = seg3d_cdiv(H, SEG3D_WG_TY), ntx = seg3d_cdiv(W, SEG3D_WG_TX);
-  const int ntiles = N * ntz * nty * ntx;
-  const int slabs = seg3d_wgrad_slabs(N, D, H, W, npairs);
+  const Seg3dWgrad16Plan plan = seg3d_wgrad16_plan(N, D, H, W, Cin, Cout);
+  const int slabs = plan.slabs;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv3d_k3_wgrad_mfma_bf16_kernel, dim3(slabs, npairs), dim3(256), 0, s, x, dy, workspace, N, D, H, W,
-                     Cin, Cout, ntz, nty, ntx, ntiles, COB32);
+  if (plan.version == 3) {
+    const int rc = plan.tx == 8 ? launch_wgrad3<8>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s)
+                                : launch_wgrad3<4>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
+    if (rc != SEG3D_OK) return rc;
+  } else {
+    const int ntz = seg3d_cdiv(D, SEG3D_WG_TZ), nty = seg3d_cdiv(H, SEG3D_WG_TY), ntx = seg3d_cdiv(W, SEG3D_WG_TX);
+    const int ntiles = N * ntz * nty * ntx;
+    hipLaunchKernelGGL(conv3d_k3_wgrad_mfma_bf16_kernel, dim3(slabs, npairs), dim3(256), 0, s, x, dy, workspace, N, D, H, W,
+                       Cin, Cout, ntz, nty, ntx, ntiles, COB32);
+  }
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_bf16_wgrad");
   const i64 total = (i64)npairs * 27 * 1024;
   hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dw, slabs,

@@ -173,6 +173,34 @@ def test_conv3d_k3_bf16_fwd(hip_device, shape, with_addend):
            err_vs_fp32_conv=float((got - (F.conv3d(x.double(), w.double(), b.double(), padding=1) + (a.double() if with_addend else 0))).abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(1, 32, 32, 8, 8, 16), (2, 64, 32, 12, 12, 12), (1, 16, 48, 4, 8, 8), (2, 128, 128, 4, 4, 8),
+                                   (1, 32, 32, 6, 6, 6), (1, 32, 16, 5, 8, 8), (4, 32, 32, 16, 16, 32)])
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_conv3d_k3_bf16_wgrad(hip_device, shape, accumulate):
+    """bf16 weight gradient (bf16 x and dy, fp32 dw): equals the exact weight gradient of the bf16-rounded operands to
+    fp32 accumulation error -- the bf16-MFMA kernel with transposing LDS reads on tile-multiple levels, the register-staged
+    fallback elsewhere; `accumulate` adds into an existing gradient"""
+    from segmentation3d import _ops, _engine as E
+    N, Cin, Cout, D, H, W = shape
+    x = _t(51, 'wx', (N, Cin, D, H, W)).bfloat16()
+    dy = _t(52, 'wdy', (N, Cout, D, H, W)).bfloat16()
+    xd = x.double()
+    w0 = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.double, requires_grad=True)
+    F.conv3d(xd, w0, None, padding=1).backward(dy.double())
+    ref = w0.grad
+    xn = _ops.to_ndhwc(x.to(hip_device).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3))
+    dyn = _ops.to_ndhwc(dy.to(hip_device).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3))
+    base = _t(53, 'wbase', (Cout, Cin, 3, 3, 3)).to(hip_device)
+    dw = base.clone() if accumulate else torch.empty_like(base)
+    ws = torch.empty(E.query('seg3d_conv3d_k3_bf16_wgrad_workspace_floats', N, D, H, W, Cin, Cout), device=hip_device)
+    E.call('seg3d_conv3d_k3_bf16_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(dw), E.ptr(ws), N, D, H, W, Cin, Cout,
+           int(accumulate), E.stream_ptr())
+    got = dw.double().cpu() - (base.double().cpu() if accumulate else 0)
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    report('bf16wgrad_{}x{}x{}x{}_{}_{}{}'.format(N, D, H, W, Cin, Cout, '_acc' if accumulate else ''), rel_max=err)
+    assert err < 2e-5, err
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 48, 6, 10, 20), (1, 128, 64, 4, 4, 4), (4, 256, 256, 6, 6, 6)])
 def test_conv3d_k3_mfma_stats_partials(hip_device, shape):
     """the conv epilogue's per-workgroup (sum, sumsq) equal the statistics of its own output (incl. the split-K path

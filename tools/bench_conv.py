@@ -1,5 +1,5 @@
 """micro-benchmark of single conv launches (events on the launch stream); used for kernel A/B work and PMC runs.
-usage: python tools/bench_conv.py [fwd|fwd16|wgrad|all] [N D H W Cin Cout] [--iters K]   (fwd16 = bf16-input kernel)"""
+usage: python tools/bench_conv.py [fwd|fwd16|wgrad|wgrad16|all] [N D H W Cin Cout] [--iters K]   (fwd16 / wgrad16 = bf16-input kernels)"""
 import os, sys, time
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,6 +33,11 @@ def run(kind, N, D, H, W, Cin, Cout, iters=10):
         st = torch.empty(N, cnt, 2, device=dev)
         print('variant', E.query('seg3d_conv3d_k3_bf16_variant', N, D, H, W, Cin, Cout), 'ks', nws // (N * D * H * W * Cout))
         fn = lambda: E.call('seg3d_conv3d_k3_bf16_fwd', E.ptr(xb), E.ptr(wp), E.ptr(b), None, E.ptr(y), E.ptr(st), E.ptr(wsp), N, D, H, W, Cin, Cout, E.stream_ptr())
+    elif kind == 'wgrad16':
+        xb, dyb = x.bfloat16(), dy.bfloat16()
+        ws = torch.empty(E.query('seg3d_conv3d_k3_bf16_wgrad_workspace_floats', N, D, H, W, Cin, Cout), device=dev)
+        dw = torch.empty(Cout, Cin, 3, 3, 3, device=dev)
+        fn = lambda: E.call('seg3d_conv3d_k3_bf16_wgrad', E.ptr(xb), E.ptr(dyb), E.ptr(dw), E.ptr(ws), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
     else:
         ws = torch.empty(E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W, Cin, Cout), device=dev)
         dw = torch.empty(Cout, Cin, 3, 3, 3, device=dev)

@@ -55,6 +55,8 @@ def parse():
                     help="fp32 = the headline metric (BASELINE configs 2-4); bf16 = BASELINE config 5's mode (bf16 "
                          "activations / packed weights, fp32 accumulate, statistics and master weights) -- reported "
                          "under its own dtype, never as the fp32 headline")
+    ap.add_argument('--graph', action='store_true',
+                    help='capture the whole train step in one hipGraph (single GPU only; see core/seg_train.TrainStep)')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='enqueue weight-gradient kernels on the main stream (no second HIP stream): use this under '
                          'rocprofv3 --kernel-trace, which serialises concurrent dispatches and distorts their durations')
@@ -237,7 +239,7 @@ def main():
         from segmentation3d import _ops as _ops_cfg
         _ops_cfg.WGRAD_SIDE_STREAM = False
     step = TrainStep(args.net, args.in_channels, args.classes, args.loss, weights if args.loss == 'Dice' else None,
-                     device=device, seed=0)
+                     device=device, seed=0, use_graph=args.graph and world == 1)
     x, t = synthetic_batch(args.batch, args.in_channels, args.classes, args.patch, device, 1000 + rank)
 
     def sync():
@@ -275,7 +277,7 @@ def main():
         try:
             with KernelTimer() as kt:
                 for _ in range(2):
-                    step(x, t)
+                    step._eager(x, t)      # eager launches (a captured step cannot be bracketed launch by launch)
             table = kt.summary()
         finally:
             _ops.WGRAD_SIDE_STREAM = overlap_was
@@ -329,7 +331,7 @@ def main():
                                                                     args.batch, args.patch, args.dtype),
                        'global_batch': world * args.batch, 'patch': args.patch,
                        'parallelism': 'dp{} (bucketed RCCL all-reduce overlapped with backward)'.format(world) if world > 1 else 'single GPU',
-                       'wgrad_overlap': not args.no_wgrad_overlap},
+                       'wgrad_overlap': not args.no_wgrad_overlap, 'train_step_hipgraph': bool(args.graph and world == 1)},
             'final_loss': round(final_loss, 6),
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'infer': infer,
         }

@@ -205,6 +205,11 @@ int seg3d_focal_bwd(const float* probs, const float* target, const float* alpha,
 /* ---- optimizer: optim.Adam(...).step()  (core/seg_train.py:83,127) -------------------------------------------------- */
 int seg3d_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr,
                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+/* the same update with the step count kept on the device (advanced by the call), for train steps captured in a hipGraph:
+ * step_dev = steps taken so far, bc_dev = 2 floats of device scratch */
+int seg3d_adam_step_devstep(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                            int* step_dev, float* bc_dev, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, float grad_scale, void* stream);
 
 /* ---- sliding-window batcher (core/seg_infer.py:208-246, 313-327, 336-339; utils/image_tools.py:435-469;
  *      utils/normalizer.py:6-81) ---------------------------------------------------------------------------------- */

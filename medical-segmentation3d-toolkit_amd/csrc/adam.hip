@@ -9,10 +9,9 @@
 #include "seg3d_common.h"
 #include "seg3d_hip.h"
 
-__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                          float* __restrict__ m, float* __restrict__ v, i64 n, float lr,
-                                                          float beta1, float beta2, float eps, float weight_decay,
-                                                          float bc1, float bc2_sqrt, float grad_scale) {
+__device__ __forceinline__ void adam_step_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, i64 n, float lr, float beta1, float beta2, float eps,
+                                               float weight_decay, float bc1, float bc2_sqrt, float grad_scale) {
   const float step_size = lr / bc1;
   const i64 n4 = n >> 2;
   for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n4; i += (i64)gridDim.x * 256) {
@@ -44,6 +43,47 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, c
     v[i] = vv;
     p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
   }
+}
+
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, i64 n, float lr,
+                                                          float beta1, float beta2, float eps, float weight_decay,
+                                                          float bc1, float bc2_sqrt, float grad_scale) {
+  adam_step_body(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+}
+
+// Device-resident step counter (a train step captured in a hipGraph cannot take the step number as a launch argument):
+// one thread advances *step and writes the two bias corrections, the update kernel reads them from memory.
+__global__ void adam_advance_kernel(int* __restrict__ step, float* __restrict__ bc, float beta1, float beta2) {
+  const int t = *step + 1;
+  *step = t;
+  bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
+  bc[1] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+}
+
+__global__ __launch_bounds__(256) void adam_step_devstep_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                  float* __restrict__ m, float* __restrict__ v, i64 n,
+                                                                  float lr, float beta1, float beta2, float eps,
+                                                                  float weight_decay, const float* __restrict__ bc,
+                                                                  float grad_scale) {
+  adam_step_body(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc[0], bc[1], grad_scale);
+}
+
+// step_dev: device int holding the number of steps taken so far (advanced here); bc_dev: 2 floats of device scratch.
+// Same update as seg3d_adam_step with step = *step_dev + 1.
+extern "C" int seg3d_adam_step_devstep(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                                       int* step_dev, float* bc_dev, float lr, float beta1, float beta2, float eps,
+                                       float weight_decay, float grad_scale, void* stream) {
+  SEG3D_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && step_dev && bc_dev,
+                "seg3d_adam_step_devstep: bad arguments");
+  SEG3D_REQUIRE(((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0 && ((uintptr_t)exp_avg % 16) == 0 &&
+                    ((uintptr_t)exp_avg_sq % 16) == 0,
+                "seg3d_adam_step_devstep: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, bc_dev, beta1, beta2);
+  hipLaunchKernelGGL(adam_step_devstep_kernel, dim3(seg3d_ew_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                     params, grads, exp_avg, exp_avg_sq, (i64)n, lr, beta1, beta2, eps, weight_decay, bc_dev, grad_scale);
+  SEG3D_LAUNCH_CHECK("seg3d_adam_step_devstep");
+  return SEG3D_OK;
 }
 
 // step >= 1 is the 1-based step count AFTER increment (torch increments before use).

@@ -96,6 +96,7 @@ _SIGNATURES = {
     'seg3d_focal_fwd': (_c_int, [_c_p] * 5 + [_c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_f, _c_int, _c_p]),
     'seg3d_focal_bwd': (_c_int, [_c_p] * 5 + [_c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_f, _c_int, _c_p]),
     'seg3d_adam_step': (_c_int, [_c_p] * 4 + [_c_ll, _c_int] + [_c_f] * 6 + [_c_p]),
+    'seg3d_adam_step_devstep': (_c_int, [_c_p] * 4 + [_c_ll, _c_p, _c_p] + [_c_f] * 6 + [_c_p]),
     'seg3d_patch_stats_blocks': (_c_ll, [_c_int] * 3),
     'seg3d_patch_gather_normalize': (_c_int, [_c_p] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_f, _c_p]),
     'seg3d_patch_scatter_accumulate': (_c_int, [_c_p] * 5 + [_c_int] * 7 + [_c_ll, _c_p]),
@@ -137,8 +138,14 @@ def last_error():
     return lib().seg3d_last_error().decode('utf-8', 'replace')
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_ptr():
-    """hipStream_t of torch's current stream (so launches are captured by torch.cuda.graph and ordered with torch ops)"""
+    """hipStream_t of torch's current stream (so launches are captured by torch.cuda.graph and ordered with torch ops).
+    Called once per kernel launch: the raw-handle query is ~10x cheaper than building a torch.cuda.Stream object."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -177,6 +184,15 @@ def call(name, *args):
     return rc
 
 
+_QUERY_CACHE = {}
+
+
 def query(name, *args):
-    """invoke a size/count helper (returns a number)"""
-    return int(getattr(lib(), name)(*args))
+    """invoke a size/count helper (returns a number).  The helpers are pure functions of their integer arguments
+    (tile plans, workspace sizes); results are memoised -- a train step asks ~50 of them, always the same ones."""
+    key = (name,) + args
+    v = _QUERY_CACHE.get(key)
+    if v is None:
+        v = int(getattr(lib(), name)(*args))
+        _QUERY_CACHE[key] = v
+    return v

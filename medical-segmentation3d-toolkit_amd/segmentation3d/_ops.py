@@ -608,6 +608,7 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
 # The main stream joins the side stream when backward finishes (engine callback); consumers that read gradients DURING
 # backward (the bucketed all-reduce, core/ddp.py) call wgrad_stream_join() themselves.
 WGRAD_SIDE_STREAM = os.environ.get('SEG3D_WGRAD_SIDE_STREAM', '1') != '0'
+WGRAD_SIDE_STREAM_IN_GRAPH = os.environ.get('SEG3D_WGRAD_SIDE_STREAM_IN_GRAPH', '1') != '0'
 _SIDE_STREAMS = {}
 _JOIN_QUEUED_FOR = [-1]   # id of the backward pass (graph task) whose end-of-backward join is already queued
 
@@ -634,9 +635,11 @@ def _join_after_backward():
 
 def _wgrad_to_sink(xn, dyn, w_shape, kind, sink_view):
     """conv_wgrad accumulated into `sink_view`, on the side stream when enabled"""
-    if not WGRAD_SIDE_STREAM or torch.cuda.is_current_stream_capturing():
+    if not WGRAD_SIDE_STREAM or (torch.cuda.is_current_stream_capturing() and not WGRAD_SIDE_STREAM_IN_GRAPH):
         conv_wgrad(xn, dyn, w_shape, kind, out=sink_view)
         return
+    # (inside a hipGraph capture the same fork / join becomes graph edges: the side stream joins the capture through
+    # wait_stream and is joined back by the end-of-backward callback before the capture ends)
     side = _side_stream(dyn.device)
     side.wait_stream(torch.cuda.current_stream())       # x and dy are complete on the main stream
     with torch.cuda.stream(side):

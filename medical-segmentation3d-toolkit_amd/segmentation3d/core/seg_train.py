@@ -38,7 +38,7 @@ class TrainStep(object):
     """network + loss + FusedAdam (+ gradient reducer when distributed) on one device"""
 
     def __init__(self, net_name, in_channels, num_classes, loss_name='Dice', obj_weight=None, focal_gamma=2, lr=1e-4,
-                 betas=(0.9, 0.999), device=None, seed=0, distributed=None, num_buckets=4):
+                 betas=(0.9, 0.999), device=None, seed=0, distributed=None, num_buckets=4, use_graph=False):
         self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
         net_module = importlib.import_module('segmentation3d.network.' + net_name)      # core/seg_train.py:72
         torch.manual_seed(seed)
@@ -57,9 +57,45 @@ class TrainStep(object):
             self.reducer.broadcast_parameters([f['params'] for f in self.opt._flat if f is not None], src=0)
             self.opt.grad_scale = 1.0 / self.reducer.world_size
             _ops.PACK_CACHE.invalidate()   # the broadcast rewrote the parameters
+        # use_graph (single process only): after two eager steps the whole step -- zero_grad, forward, loss, backward,
+        # Adam, weight re-pack: ~420 launches -- is captured ONCE in a hipGraph and replayed; the host then costs one
+        # replay per step instead of ~10 ms of launch work (what bounds the bf16 mode, whose kernels take about as long).
+        # Inputs are copied into static buffers; a new input shape re-captures.  Not combined with the gradient reducer:
+        # its collectives stay outside hipGraphs.
+        self.use_graph = bool(use_graph) and self.reducer is None
+        self._graph, self._gx, self._gt, self._gloss, self._eager_calls = None, None, None, None, 0
 
     def __call__(self, crops, masks):
         """one optimisation step; returns the (device) loss tensor of this rank's batch"""
+        if self.use_graph:
+            return self._graphed(crops, masks)
+        return self._eager(crops, masks)
+
+    def _graphed(self, crops, masks):
+        if self._graph is not None and (self._gx.shape != crops.shape or self._gt.shape != masks.shape or
+                                        self._gx.dtype != crops.dtype or self._gt.dtype != masks.dtype):
+            self._graph, self._eager_calls = None, 0          # new geometry: warm up and capture again
+        if self._graph is None:
+            if self._eager_calls < 2:                         # allocator, packed-weight images, plans warm up eagerly
+                self._eager_calls += 1
+                return self._eager(crops, masks)
+            self.opt.use_device_step()
+            self._gx, self._gt = crops.clone(), masks.clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._gloss = self._eager(self._gx, self._gt)
+            for f in self.opt._flat:                          # capture ran the host side of opt.step() once, no kernels
+                if f is not None:
+                    f['step'] -= 1
+            self._graph = graph
+        self._gx.copy_(crops)
+        self._gt.copy_(masks)
+        self._graph.replay()
+        self.opt.note_replayed_step()
+        return self._gloss
+
+    def _eager(self, crops, masks):
         self.opt.zero_grad()
         if self.reducer is not None:
             self.reducer.begin_step()

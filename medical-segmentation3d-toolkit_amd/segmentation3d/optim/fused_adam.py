@@ -26,6 +26,9 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat = []  # per group: dict(params, grads, exp_avg, exp_avg_sq, offsets, step)
         self.grad_scale = 1.0  # set to 1/world_size by the data-parallel wrapper after a sum all-reduce
         self.direct_grads = bool(direct_grads)
+        # device_step: the step count lives on the device and the kernel advances it itself (seg3d_adam_step_devstep), so
+        # that a whole train step can be captured in a hipGraph and replayed; the host count follows in note_replayed_step()
+        self.device_step = False
         for group in self.param_groups:
             self._flat.append(self._flatten_group(group))
 
@@ -60,6 +63,26 @@ class FusedAdam(torch.optim.Optimizer):
                              'exp_avg_sq': flat_v[off:off + n].view(p.shape)}
         return {'list': ps, 'offsets': offsets, 'params': flat_p, 'grads': flat_g, 'exp_avg': flat_m,
                 'exp_avg_sq': flat_v, 'step': 0, 'total': total}
+
+    def use_device_step(self):
+        """switch to the device-resident step counter (before capturing a train step in a hipGraph); idempotent"""
+        for f in self._flat:
+            if f is None:
+                continue
+            dev = f['params'].device
+            f['step_dev'] = torch.full((1,), int(f['step']), dtype=torch.int32, device=dev)
+            f['bc_dev'] = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.device_step = True
+
+    def note_replayed_step(self):
+        """a captured step was replayed: the device advanced its counter, bring the host-side bookkeeping along"""
+        for f in self._flat:
+            if f is None:
+                continue
+            f['step'] += 1
+            step_t = torch.tensor(float(f['step']))
+            for p in f['list']:
+                self.state[p]['step'] = step_t
 
     def flat_grads(self):
         """list of flat gradient buffers (one per parameter group) -- what the data-parallel reducer all-reduces"""
@@ -124,12 +147,19 @@ class FusedAdam(torch.optim.Optimizer):
             self._gather_stray_grads(f)
             f['step'] += 1
             beta1, beta2 = group['betas']
-            E.call('seg3d_adam_step', E.ptr(f['params']), E.ptr(f['grads']), E.ptr(f['exp_avg']), E.ptr(f['exp_avg_sq']),
-                   f['total'], f['step'], float(group['lr']), float(beta1), float(beta2), float(group['eps']),
-                   float(group['weight_decay']), float(self.grad_scale), E.stream_ptr())
+            if self.device_step:
+                E.call('seg3d_adam_step_devstep', E.ptr(f['params']), E.ptr(f['grads']), E.ptr(f['exp_avg']),
+                       E.ptr(f['exp_avg_sq']), f['total'], E.ptr(f['step_dev']), E.ptr(f['bc_dev']), float(group['lr']),
+                       float(beta1), float(beta2), float(group['eps']), float(group['weight_decay']),
+                       float(self.grad_scale), E.stream_ptr())
+            else:
+                E.call('seg3d_adam_step', E.ptr(f['params']), E.ptr(f['grads']), E.ptr(f['exp_avg']),
+                       E.ptr(f['exp_avg_sq']), f['total'], f['step'], float(group['lr']), float(beta1), float(beta2),
+                       float(group['eps']), float(group['weight_decay']), float(self.grad_scale), E.stream_ptr())
             touched = True
+            step_t = torch.tensor(float(f['step']))     # one host tensor shared by the group's per-parameter states
             for p in f['list']:
-                self.state[p]['step'] = torch.tensor(float(f['step']))
+                self.state[p]['step'] = step_t
         if touched:
             # the kernel rewrote the parameters without touching their version counters: refresh (one launch) or
             # invalidate the packed conv-weight images

@@ -104,9 +104,11 @@ long long seg3d_conv3d_k3_bf16_stats_count(int N, int D, int H, int W, int Cin, 
 long long seg3d_conv3d_k3_bf16_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 /* 200 + 10*MA + NB = conv3d_k3_mfma2_bf16_kernel<MA, NB>; 0 = shape not supported */
 int seg3d_conv3d_k3_bf16_variant(int N, int D, int H, int W, int Cin, int Cout);
-int seg3d_conv3d_k3_bf16_fwd(const void* x_bf16, const void* wp_bf16, const float* bias, const float* addend, float* y,
+/* out_bf16 = 1: y is bf16 storage (used for data-gradients, whose consumer is the GroupNorm backward of a bf16 unit);
+ * addend stays fp32 and is added before the rounding */
+int seg3d_conv3d_k3_bf16_fwd(const void* x_bf16, const void* wp_bf16, const float* bias, const float* addend, void* y,
                              float* stats_partial, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
-                             void* stream);
+                             int out_bf16, void* stream);
 
 /* bf16 mode, remaining conv entry points: the INPUT activations (and, for weight gradients, the output gradient) are
  * bf16 and are widened to fp32 while a tile is staged; weights (fp32 pack), accumulation and outputs are fp32.  Each one
@@ -114,10 +116,11 @@ int seg3d_conv3d_k3_bf16_fwd(const void* x_bf16, const void* wp_bf16, const floa
 long long seg3d_conv3d_k3_bf16_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_bf16_wgrad(const void* x_bf16, const void* dy_bf16, float* dw, float* workspace, int N, int D, int H,
                                int W, int Cin, int Cout, int accumulate, void* stream);
-int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp_mfma, const float* bias, float* y, float* stats_partial,
-                               int N, int Do, int Ho, int Wo, int Cin, int Cout, void* stream);
-int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp_mfma, const float* bias, float* y,
-                                float* stats_partial, int N, int Di, int Hi, int Wi, int Cin, int Cout, void* stream);
+int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp_mfma, const float* bias, void* y, float* stats_partial,
+                               int N, int Do, int Ho, int Wo, int Cin, int Cout, int out_bf16, void* stream);
+int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp_mfma, const float* bias, void* y,
+                                float* stats_partial, int N, int Di, int Hi, int Wi, int Cin, int Cout, int out_bf16,
+                                void* stream);
 int seg3d_k2_bf16_wgrad(const void* P_bf16, const void* Q_bf16, float* dw, float* workspace, int N, int Dq, int Hq, int Wq,
                         int CA, int CB, long long sa, long long sb, int accumulate, void* stream);
 int seg3d_conv3d_k3_thin_out_bf16_fwd(const void* x_bf16, const float* wq, const float* bias, float* y,

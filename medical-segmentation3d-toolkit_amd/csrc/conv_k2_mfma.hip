@@ -55,7 +55,7 @@ static K2Tile k2_pick_tile(int D, int H, int W) {
 // ---------------------------------------------------------------------------------------------------------------
 // XBF: the input tensor is bf16 (bf16 mode); it is widened to fp32 when the staged chunk is written to LDS, the
 // weights, the fp32 MFMAs and the fp32 output are the same.
-template <bool XBF>
+template <bool XBF, bool OUT_BF = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __restrict__ x,
                                                                     const float* __restrict__ wp,
                                                                     const float* __restrict__ bias, float* __restrict__ y,
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
           s[0] += v[c];
           s[1] += v[c] * v[c];
         }
-        *reinterpret_cast<f32x4*>(y + ((i64)vo * Cout + co)) = v;
+        Seg3dQuad<OUT_BF>::store(y, (i64)vo * Cout + co, v);
       }
     }
   }
@@ -222,7 +222,7 @@ extern "C" long long seg3d_conv3d_k2s2_mfma_stats_count(int Do, int Ho, int Wo, 
 
 // x [N][2Do][2Ho][2Wo][Cin] -> y [N][Do][Ho][Wo][Cout];  wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 8)
 static int k2_gather_launch(const void* x, int x_bf16, const float* wp, const float* bias, float* y, float* stats, int N,
-                            int Do, int Ho, int Wo, int Cin, int Cout, void* stream) {
+                            int Do, int Ho, int Wo, int Cin, int Cout, void* stream, int out_bf16 = 0) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k2s2_mfma_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && Do > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k2s2_mfma_fwd: bad dims");
   SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
@@ -235,7 +235,10 @@ static int k2_gather_launch(const void* x, int x_bf16, const float* wp, const fl
   const size_t lds = (size_t)(8 * 8 * mt + K2_W_CHUNK + ((mt + 3) & ~3)) * 4;
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "2x2x2 stride-2 MFMA kernels: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
-  if (x_bf16)
+  if (x_bf16 && out_bf16)
+    hipLaunchKernelGGL((conv3d_k2s2_mfma_kernel<true, true>), grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y,
+                       stats, N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
+  else if (x_bf16)
     hipLaunchKernelGGL(conv3d_k2s2_mfma_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, stats, N,
                        Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
   else
@@ -251,15 +254,16 @@ extern "C" int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp, const
 }
 
 // bf16 mode: x is bf16 ([N][2Do][2Ho][2Wo][Cin]); weights (fp32 pack), bias, y and statistics as above
-extern "C" int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp, const float* bias, float* y, float* stats,
-                                          int N, int Do, int Ho, int Wo, int Cin, int Cout, void* stream) {
-  return k2_gather_launch(x_bf16, 1, wp, bias, y, stats, N, Do, Ho, Wo, Cin, Cout, stream);
+extern "C" int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp, const float* bias, void* y, float* stats,
+                                          int N, int Do, int Ho, int Wo, int Cin, int Cout, int out_bf16, void* stream) {
+  return k2_gather_launch(x_bf16, 1, wp, bias, reinterpret_cast<float*>(y), stats, N, Do, Ho, Wo, Cin, Cout, stream,
+                          out_bf16);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // scatter: input tile TZ x TY x TX (<= 128 voxels), one accumulator per tap, output cell 2^3 per input voxel
 // ---------------------------------------------------------------------------------------------------------------
-template <bool XBF>
+template <bool XBF, bool OUT_BF = false>
 __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* __restrict__ x,
                                                                      const float* __restrict__ wp,
                                                                      const float* __restrict__ bias,
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
 #pragma unroll
         for (int tap = 0; tap < 8; ++tap) {
           const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
-          float* dst = y + ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co0;
+          const i64 dsto = ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co0;
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             if (g4 < ng) {
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
                 s[0] += v[c];
                 s[1] += v[c] * v[c];
               }
-              *reinterpret_cast<f32x4*>(dst + 8 * g4) = v;
+              Seg3dQuad<OUT_BF>::store(y, dsto + 8 * g4, v);
             }
           }
         }
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
               s[0] += v[c];
               s[1] += v[c] * v[c];
             }
-            *reinterpret_cast<f32x4*>(y + ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co) = v;
+            Seg3dQuad<OUT_BF>::store(y, ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co, v);
           }
         }
       }
@@ -423,7 +427,7 @@ extern "C" long long seg3d_convT3d_k2s2_mfma_stats_count(int Di, int Hi, int Wi,
 
 // x [N][Di][Hi][Wi][Cin] -> y [N][2Di][2Hi][2Wi][Cout];  wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 8)
 static int k2_scatter_launch(const void* x, int x_bf16, const float* wp, const float* bias, float* y, float* stats, int N,
-                             int Di, int Hi, int Wi, int Cin, int Cout, void* stream) {
+                             int Di, int Hi, int Wi, int Cin, int Cout, void* stream, int out_bf16 = 0) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_convT3d_k2s2_mfma_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && Di > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "seg3d_convT3d_k2s2_mfma_fwd: bad dims");
   SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
@@ -434,7 +438,10 @@ static int k2_scatter_launch(const void* x, int x_bf16, const float* wp, const f
   const int ntz = seg3d_cdiv(Di, t.tz), nty = seg3d_cdiv(Hi, t.ty), ntx = seg3d_cdiv(Wi, t.tx);
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "2x2x2 stride-2 MFMA kernels: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
-  if (x_bf16)
+  if (x_bf16 && out_bf16)
+    hipLaunchKernelGGL((convT3d_k2s2_mfma_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y,
+                       stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
+  else if (x_bf16)
     hipLaunchKernelGGL(convT3d_k2s2_mfma_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, stats, N,
                        Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
   else
@@ -449,9 +456,10 @@ extern "C" int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp, cons
   return k2_scatter_launch(x, 0, wp, bias, y, stats, N, Di, Hi, Wi, Cin, Cout, stream);
 }
 
-extern "C" int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp, const float* bias, float* y, float* stats,
-                                           int N, int Di, int Hi, int Wi, int Cin, int Cout, void* stream) {
-  return k2_scatter_launch(x_bf16, 1, wp, bias, y, stats, N, Di, Hi, Wi, Cin, Cout, stream);
+extern "C" int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp, const float* bias, void* y, float* stats,
+                                           int N, int Di, int Hi, int Wi, int Cin, int Cout, int out_bf16, void* stream) {
+  return k2_scatter_launch(x_bf16, 1, wp, bias, reinterpret_cast<float*>(y), stats, N, Di, Hi, Wi, Cin, Cout, stream,
+                           out_bf16);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -299,7 +299,7 @@ __device__ __forceinline__ void seg3d_glds16(const float* src, float* lds_dst_wa
 // four 32x32x2 fp32 MFMAs per tap.  Accumulators, bias, addend, output and statistics stay fp32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int MA, int NB, bool SPLITK, bool BF16 = false>
+template <int MA, int NB, bool SPLITK, bool BF16 = false, bool OUT_BF = false>
 __device__ __forceinline__ void conv3d_k3_mfma2_body(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ stats, int N, int D, int H, int W, int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
@@ -619,7 +619,7 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
               s0 += v[c];
               s1 += v[c] * v[c];
             }
-            *reinterpret_cast<f32x4*>(y + ((i64)vo[m] * Cout + (co_lane + 32 * q + 8 * g4))) = v;
+            Seg3dQuad<OUT_BF>::store(y, (i64)vo[m] * Cout + (co_lane + 32 * q + 8 * g4), v);   // y: bf16 when OUT_BF
           }
     } else {
 #pragma unroll
@@ -637,7 +637,7 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
                 s0 += v[c];
                 s1 += v[c] * v[c];
               }
-              *reinterpret_cast<f32x4*>(y + ((i64)vo[m] * Cout + co)) = v;
+              Seg3dQuad<OUT_BF>::store(y, (i64)vo[m] * Cout + co, v);
             }
           }
     }
@@ -682,13 +682,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_splitk_kernel(
 }
 
 // bf16-input variants (x, wp: bf16 viewed as words; Cw = Cin / 2 words per voxel)
-template <int MA, int NB>
+// OUT_BF: the output tensor is bf16 (a data-gradient that autograd hands on as the gradient of a bf16 activation); the
+// statistics, when asked for, are still those of the fp32 values
+template <int MA, int NB, bool OUT_BF>
 __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_bf16_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ stats, int N, int D, int H, int W, int Cw, int Cout, int TZ, int TY, int TX, int ntz, int nty,
     int ntx, int ncog, int nitems, const float* __restrict__ addend) {
-  conv3d_k3_mfma2_body<MA, NB, false, true>(x, wp, bias, y, stats, N, D, H, W, Cw, Cout, TZ, TY, TX, ntz, nty, ntx, ncog,
-                                            nitems, addend, nullptr, 1, 0);
+  conv3d_k3_mfma2_body<MA, NB, false, true, OUT_BF>(x, wp, bias, y, stats, N, D, H, W, Cw, Cout, TZ, TY, TX, ntz, nty, ntx,
+                                                    ncog, nitems, addend, nullptr, 1, 0);
 }
 
 template <int MA, int NB>
@@ -700,11 +702,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_bf16_splitk_kernel(
 }
 
 // y[e] = bias[c] + sum_ks part[ks][e]; emits GroupNorm (sum, sumsq) partials per workgroup.  HBM-bound, float4.
-__global__ __launch_bounds__(256) void conv3d_splitk_finish_kernel(const float* __restrict__ part,
-                                                                     const float* __restrict__ bias,
-                                                                     const float* __restrict__ addend, float* __restrict__ y,
-                                                                     float* __restrict__ stats, int KS, i64 M, i64 total,
-                                                                     int Cout, int nblk) {
+template <bool OUT_BF>
+__device__ __forceinline__ void conv3d_splitk_finish_body(const float* __restrict__ part, const float* __restrict__ bias,
+                                                          const float* __restrict__ addend, float* __restrict__ y,
+                                                          float* __restrict__ stats, int KS, i64 M, i64 total, int Cout,
+                                                          int nblk) {
   __shared__ float red[8];
   const int n = blockIdx.y;
   const i64 e0 = (i64)blockIdx.x * SPLITK_CHUNK;
@@ -726,7 +728,8 @@ __global__ __launch_bounds__(256) void conv3d_splitk_finish_kernel(const float* 
       const float4 a = *reinterpret_cast<const float4*>(addend + g);
       acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
     }
-    *reinterpret_cast<float4*>(y + g) = acc;
+    const seg3d_f32x4 accq = {acc.x, acc.y, acc.z, acc.w};
+    Seg3dQuad<OUT_BF>::store(y, g, accq);
     s[0] += (acc.x + acc.y) + (acc.z + acc.w);
     s[1] += (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w);
   }
@@ -735,6 +738,22 @@ __global__ __launch_bounds__(256) void conv3d_splitk_finish_kernel(const float* 
     stats[((i64)n * nblk + blockIdx.x) * 2 + 0] = s[0];
     stats[((i64)n * nblk + blockIdx.x) * 2 + 1] = s[1];
   }
+}
+
+__global__ __launch_bounds__(256) void conv3d_splitk_finish_kernel(const float* __restrict__ part,
+                                                                     const float* __restrict__ bias,
+                                                                     const float* __restrict__ addend, float* __restrict__ y,
+                                                                     float* __restrict__ stats, int KS, i64 M, i64 total,
+                                                                     int Cout, int nblk) {
+  conv3d_splitk_finish_body<false>(part, bias, addend, y, stats, KS, M, total, Cout, nblk);
+}
+
+__global__ __launch_bounds__(256) void conv3d_splitk_finish_bf16out_kernel(const float* __restrict__ part,
+                                                                             const float* __restrict__ bias,
+                                                                             const float* __restrict__ addend,
+                                                                             float* __restrict__ y, float* __restrict__ stats,
+                                                                             int KS, i64 M, i64 total, int Cout, int nblk) {
+  conv3d_splitk_finish_body<true>(part, bias, addend, y, stats, KS, M, total, Cout, nblk);
 }
 
 // Pick the output tile for one level by a small time model: a workgroup's duration is proportional to its MFMA row
@@ -989,7 +1008,7 @@ static int launch_fwd(const float* x, const float* wp, const float* bias, float*
   return SEG3D_OK;
 }
 
-template <int MA, int NB, bool BF16 = false>
+template <int MA, int NB, bool BF16 = false, bool OUT_BF = false>
 static int launch_fwd2(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
                        int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, const float* addend, float* kpart,
                        int ks) {
@@ -998,7 +1017,7 @@ static int launch_fwd2(const float* x, const float* wp, const float* bias, float
     const size_t lds = seg3d_fwd2_lds_bytes(t, NB);
     static bool configured16 = false;
     if (!configured16) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_bf16_kernel<MA, NB>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_bf16_kernel<MA, NB, OUT_BF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_bf16_splitk_kernel<MA, NB>),
@@ -1017,8 +1036,8 @@ static int launch_fwd2(const float* x, const float* wp, const float* bias, float
       hipLaunchKernelGGL((conv3d_k3_mfma2_bf16_splitk_kernel<MA, NB>), grid, dim3(256), lds, s, x, wp, kpart, N, D, H, W,
                          Cin / 2, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, ks, cpk);
     else
-      hipLaunchKernelGGL((conv3d_k3_mfma2_bf16_kernel<MA, NB>), grid, dim3(256), lds, s, x, wp, bias, y, stats, N, D, H,
-                         W, Cin / 2, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, addend);
+      hipLaunchKernelGGL((conv3d_k3_mfma2_bf16_kernel<MA, NB, OUT_BF>), grid, dim3(256), lds, s, x, wp, bias, y, stats, N,
+                         D, H, W, Cin / 2, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, addend);
     return SEG3D_OK;
   }
   const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
@@ -1115,9 +1134,10 @@ extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const f
 
 // bf16 inputs: x [N][D][H][W][Cin] bf16, wp = seg3d_pack_weights_mfma_bf16(A = Cin, B = Cout, T = 27); bias, addend,
 // y, stats, workspace fp32 exactly as in seg3d_conv3d_k3_mfma_fwd.  Needs Cin % 16 == 0 and Cout % 4 == 0.
-extern "C" int seg3d_conv3d_k3_bf16_fwd(const void* x, const void* wp, const float* bias, const float* addend, float* y,
+extern "C" int seg3d_conv3d_k3_bf16_fwd(const void* x, const void* wp, const float* bias, const float* addend, void* yv,
                                         float* stats, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
-                                        void* stream) {
+                                        int out_bf16, void* stream) {
+  float* y = reinterpret_cast<float*>(yv);   // bf16 storage when out_bf16 (the kernels cast back)
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_bf16_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k3_bf16_fwd: bad dims");
   SEG3D_REQUIRE((Cin % 16) == 0 && (Cout % 4) == 0,
@@ -1134,23 +1154,33 @@ extern "C" int seg3d_conv3d_k3_bf16_fwd(const void* x, const void* wp, const flo
   const Seg3dTile t = plan.t;
   hipStream_t s = (hipStream_t)stream;
   int rc;
+#define SEG3D_BF16_LAUNCH(MA_, NB_)                                                                                    \
+  rc = out_bf16 ? launch_fwd2<MA_, NB_, true, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, \
+                                                    ks)                                                               \
+                : launch_fwd2<MA_, NB_, true, false>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend,      \
+                                                     workspace, ks)
   switch (plan.ma * 10 + plan.nb) {
-    case 11: rc = launch_fwd2<1, 1, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
-    case 21: rc = launch_fwd2<2, 1, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
-    case 31: rc = launch_fwd2<3, 1, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
-    case 41: rc = launch_fwd2<4, 1, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
-    case 12: rc = launch_fwd2<1, 2, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
-    case 22: rc = launch_fwd2<2, 2, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, ks); break;
+    case 11: SEG3D_BF16_LAUNCH(1, 1); break;
+    case 21: SEG3D_BF16_LAUNCH(2, 1); break;
+    case 31: SEG3D_BF16_LAUNCH(3, 1); break;
+    case 41: SEG3D_BF16_LAUNCH(4, 1); break;
+    case 12: SEG3D_BF16_LAUNCH(1, 2); break;
+    case 22: SEG3D_BF16_LAUNCH(2, 2); break;
     default:
       SEG3D_UNSUPPORTED("seg3d_conv3d_k3_bf16_fwd: internal plan error (ma=%d nb=%d)", plan.ma, plan.nb);
   }
+#undef SEG3D_BF16_LAUNCH
   if (rc != SEG3D_OK) return rc;
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_bf16_fwd");
   if (ks > 1) {
     const i64 M = (i64)D * H * W * Cout;
     const int nblk = (int)((M + SPLITK_CHUNK - 1) / SPLITK_CHUNK);
-    hipLaunchKernelGGL(conv3d_splitk_finish_kernel, dim3(nblk, N), dim3(256), 0, s, workspace, bias, addend, y, stats, ks,
-                       M, (i64)N * M, Cout, nblk);
+    if (out_bf16)
+      hipLaunchKernelGGL(conv3d_splitk_finish_bf16out_kernel, dim3(nblk, N), dim3(256), 0, s, workspace, bias, addend, y,
+                         stats, ks, M, (i64)N * M, Cout, nblk);
+    else
+      hipLaunchKernelGGL(conv3d_splitk_finish_kernel, dim3(nblk, N), dim3(256), 0, s, workspace, bias, addend, y, stats, ks,
+                         M, (i64)N * M, Cout, nblk);
     SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_bf16_fwd(split-K finish)");
   }
   return SEG3D_OK;

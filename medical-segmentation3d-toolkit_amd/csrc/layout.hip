@@ -223,12 +223,14 @@ extern "C" int seg3d_bf16_to_f32(const void* src, float* dst, long long n, void*
 // Many weight tensors in ONE launch (after an optimizer step every conv weight has to be re-packed, for the forward
 // and for the data-gradient orientation: 52 tiny launches per V-Net step otherwise).  `jobs` is a device array;
 // job k owns the workgroups [first_block[k], first_block[k+1]), one per packed (32 x 8 x T) chunk.
-__global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob* __restrict__ jobs, int njobs) {
+// AW = reduction channels per chunk: 8 (fp32 image) or 16 (bf16 image, 8 per half)
+template <int AW, bool BF>
+__device__ __forceinline__ void pack_mfma_multi_body(const Seg3dPackJob* __restrict__ jobs, int njobs) {
   // One workgroup per packed chunk (8 reduction channels x 32 output channels x T taps = exactly one LDS image of the
   // conv kernels).  In both reference layouts one of the two channel strides equals T, so the chunk's source elements
   // form long contiguous runs: they are read in memory order (coalesced), transposed through LDS and written in packed
   // order (coalesced).  The first version gathered single floats straight from global memory and moved 5x the bytes.
-  __shared__ float tile[8 * 32 * 27];
+  __shared__ float tile[AW * 32 * 27];
   __shared__ int sjob;
   if (threadIdx.x == 0) {
     int lo = 0, hi = njobs - 1;  // last job whose first_block <= blockIdx.x
@@ -240,14 +242,14 @@ __global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob
   }
   __syncthreads();
   const Seg3dPackJob jb = jobs[sjob];
-  const int AB = (jb.A + 7) / 8, T = jb.T;
+  const int AB = (jb.A + AW - 1) / AW, T = jb.T;
   const int chunk = (int)((i64)blockIdx.x - jb.first_block);   // = bb * AB + ab
   const int ab = chunk % AB, bb = chunk / AB;
-  const int a0 = ab * 8, b0 = bb * 32;
-  const int n = 8 * 32 * T;                                     // elements of this chunk, tile[(a * 32 + b) * T + t]
+  const int a0 = ab * AW, b0 = bb * 32;
+  const int n = AW * 32 * T;                                     // elements of this chunk, tile[(a * 32 + b) * T + t]
   if (T <= 27 && jb.sa == T) {
     // w[b][a][t]: for a fixed output channel b the 8 x T values of this chunk are contiguous
-    const int run = 8 * T;
+    const int run = AW * T;
     for (int i = threadIdx.x; i < 32 * run; i += 256) {
       const int b = i / run, r = i - b * run;
       const int a = r / T, t = r - a * T;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob
   } else if (T <= 27 && jb.sb == T) {
     // w[a][b][t]: for a fixed reduction channel a the 32 x T values are contiguous
     const int run = 32 * T;
-    for (int i = threadIdx.x; i < 8 * run; i += 256) {
+    for (int i = threadIdx.x; i < AW * run; i += 256) {
       const int a = i / run, r = i - a * run;
       float v = 0.f;
       if (a0 + a < jb.A && b0 + r / T < jb.B) v = jb.w[(i64)(a0 + a) * jb.sa + (i64)b0 * T + r];
@@ -275,11 +277,22 @@ __global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob
   }
   __syncthreads();
   // packed order inside the chunk: [t][h][j][r]  with a = 4 h + r, b = j
-  float* dst = jb.wp + (i64)chunk * n;
+  constexpr int HW = AW / 2;   // channels per half
   for (int i = threadIdx.x; i < n; i += 256) {
-    const int r = i & 3, j = (i >> 2) & 31, h = (i >> 7) & 1, t = i >> 8;
-    dst[i] = tile[((4 * h + r) * 32 + j) * T + (jb.flip ? T - 1 - t : t)];
+    const int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, t = i / (HW * 64);
+    const float v = tile[((HW * h + r) * 32 + j) * T + (jb.flip ? T - 1 - t : t)];
+    if (BF) reinterpret_cast<seg3d_bf16*>(jb.wp)[(i64)chunk * n + i] = seg3d_f2bf(v);
+    else jb.wp[(i64)chunk * n + i] = v;
   }
+}
+
+__global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob* __restrict__ jobs, int njobs) {
+  pack_mfma_multi_body<8, false>(jobs, njobs);
+}
+
+// bf16 images (bf16 mode): 16 reduction channels per chunk, the same coalesced read / LDS transpose / coalesced write
+__global__ __launch_bounds__(256) void pack_mfma_bf16_multi_kernel(const Seg3dPackJob* __restrict__ jobs, int njobs) {
+  pack_mfma_multi_body<16, true>(jobs, njobs);
 }
 
 extern "C" long long seg3d_pack_job_blocks(int A, int B, int T) {
@@ -294,33 +307,6 @@ extern "C" int seg3d_pack_weights_mfma_multi(const Seg3dPackJob* jobs_device, in
                      njobs);
   SEG3D_LAUNCH_CHECK("seg3d_pack_weights_mfma_multi");
   return SEG3D_OK;
-}
-
-// bf16 images of many weight tensors in one launch (bf16 mode, after an optimizer step): one workgroup per packed
-// (32 x 16 x T) chunk, plain gather (the fp32 kernel above stages through LDS; here the 2-byte stores are the small side)
-__global__ __launch_bounds__(256) void pack_mfma_bf16_multi_kernel(const Seg3dPackJob* __restrict__ jobs, int njobs) {
-  __shared__ int sjob;
-  if (threadIdx.x == 0) {
-    int lo = 0, hi = njobs - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (jobs[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    sjob = lo;
-  }
-  __syncthreads();
-  const Seg3dPackJob jb = jobs[sjob];
-  const int AB = (jb.A + 15) / 16, T = jb.T;
-  const int chunk = (int)((i64)blockIdx.x - jb.first_block);   // = bb * AB + ab
-  const int ab = chunk % AB, bb = chunk / AB;
-  seg3d_bf16* dst = reinterpret_cast<seg3d_bf16*>(jb.wp) + (i64)chunk * T * 512;
-  for (int i = threadIdx.x; i < T * 512; i += 256) {
-    const int r = i & 7, j = (i >> 3) & 31, h = (i >> 8) & 1, t = i >> 9;
-    const int a = ab * 16 + h * 8 + r, b = bb * 32 + j;
-    float v = 0.f;
-    if (a < jb.A && b < jb.B) v = jb.w[(i64)a * jb.sa + (i64)b * jb.sb + (jb.flip ? T - 1 - t : t)];
-    dst[i] = seg3d_f2bf(v);
-  }
 }
 
 extern "C" long long seg3d_pack_job_blocks_bf16(int A, int B, int T) {

@@ -237,11 +237,13 @@ def _use_mfma(cin, cout):
     return (not FORCE_DIRECT) and cin % 4 == 0 and cin >= 8 and cout >= 8
 
 
-def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None):
+def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, out_bf16=False):
     """y[v][b] = bias[b] + sum_{t,a} x[v + t - 1][a] W(a,b,t) [+ addend];  returns (y, stats_partial or None)"""
     N, D, H, W_, Cin = xn.shape
     assert Cin == A
-    y = _empty((N, D, H, W_, B), xn)
+    if out_bf16 and not (_is_bf16(xn) and A % 16 == 0 and B % 4 == 0 and B >= 8 and not FORCE_DIRECT):
+        out_bf16 = False      # only the bf16 MFMA kernel writes bf16 (callers treat the flag as a request)
+    y = _empty((N, D, H, W_, B), xn, torch.bfloat16 if out_bf16 else torch.float32)
     if _is_bf16(xn):
         if A % 16 == 0 and B % 4 == 0 and B >= 8 and not FORCE_DIRECT:
             wp = _pack_mfma(w, A, B, 27, sa, sb, flip, bf16=True)
@@ -251,7 +253,7 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None):
             nws = E.query('seg3d_conv3d_k3_bf16_fwd_workspace_floats', N, D, H, W_, A, B)
             ws = _empty((nws,), xn) if nws else None
             E.call('seg3d_conv3d_k3_bf16_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(addend), E.ptr(y), E.ptr(stats),
-                   E.ptr(ws), N, D, H, W_, A, B, E.stream_ptr())
+                   E.ptr(ws), N, D, H, W_, A, B, int(out_bf16), E.stream_ptr())
             return y, stats
         if B <= 8 and A % 4 == 0 and addend is None and not FORCE_DIRECT:   # head forward on bf16 activations
             CO = 2 if B <= 2 else (4 if B <= 4 else 8)
@@ -311,8 +313,12 @@ def _k2_gather(xn, w, bias, y, A, B, sa, sb, want_stats):
     stats = None
     if want_stats:
         stats = _empty((N, E.query('seg3d_conv3d_k2s2_mfma_stats_count', Do, Ho, Wo, B), 2), xn)
-    E.call('seg3d_conv3d_k2s2_bf16_fwd' if _is_bf16(xn) else 'seg3d_conv3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp),
-           E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho, Wo, A, B, E.stream_ptr())
+    if _is_bf16(xn):
+        E.call('seg3d_conv3d_k2s2_bf16_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho, Wo, A, B,
+               int(_is_bf16(y)), E.stream_ptr())
+        return y, stats
+    E.call('seg3d_conv3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho, Wo, A, B,
+           E.stream_ptr())
     return y, stats
 
 
@@ -323,8 +329,12 @@ def _k2_scatter(xn, w, bias, y, A, B, sa, sb, want_stats):
     stats = None
     if want_stats:
         stats = _empty((N, E.query('seg3d_convT3d_k2s2_mfma_stats_count', D, H, W_, B), 2), xn)
-    E.call('seg3d_convT3d_k2s2_bf16_fwd' if _is_bf16(xn) else 'seg3d_convT3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp),
-           E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B, E.stream_ptr())
+    if _is_bf16(xn):
+        E.call('seg3d_convT3d_k2s2_bf16_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
+               int(_is_bf16(y)), E.stream_ptr())
+        return y, stats
+    E.call('seg3d_convT3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
+           E.stream_ptr())
     return y, stats
 
 
@@ -408,7 +418,8 @@ def conv_dgrad(dyn, w, kind, addend=None):
     if kind == 'k3':
         Cout, Cin = w.shape[0], w.shape[1]
         # dx[v][ci] = sum_{t',co} dy[v + t' - 1][co] w[co][ci][26 - t']
-        dx, _ = _conv_k3_generic(dyn, w, None, Cout, Cin, Cin * 27, 27, 1, False, addend=addend)
+        # (a bf16 dy means the unit's input is a bf16 activation: its gradient is written as bf16 by the kernel itself)
+        dx, _ = _conv_k3_generic(dyn, w, None, Cout, Cin, Cin * 27, 27, 1, False, addend=addend, out_bf16=_is_bf16(dyn))
         return dx
     if addend is not None:
         return conv_dgrad(dyn, w, kind).add_(addend)
@@ -419,9 +430,10 @@ def conv_dgrad(dyn, w, kind, addend=None):
     if kind == 'k2s2':
         Cout, Cin = w.shape[0], w.shape[1]
         # dx[2v + t][ci] = sum_co dy[v][co] w[co][ci][t]  == transposed conv of dy
-        dx = _empty((N, 2 * D, 2 * H, 2 * W_, Cin), dyn)
         if _use_mfma(Cout, Cin) and Cin % 4 == 0:
+            dx = _empty((N, 2 * D, 2 * H, 2 * W_, Cin), dyn, dyn.dtype)     # bf16 dy -> bf16 dx, written by the kernel
             return _k2_scatter(dyn, w, None, dx, Cout, Cin, Cin * 8, 8, False)[0]
+        dx = _empty((N, 2 * D, 2 * H, 2 * W_, Cin), dyn)
         wp = _pack_tapmajor(w, Cout, Cin, 8, Cin * 8, 8)
         E.call('seg3d_convT3d_k2s2_fwd_direct', E.ptr(dyn), E.ptr(wp), None, E.ptr(dx), N, D, H, W_, Cout, Cin,
                E.stream_ptr())
@@ -436,9 +448,10 @@ def conv_dgrad(dyn, w, kind, addend=None):
     if kind == 'convT':
         Cin, Cout = w.shape[0], w.shape[1]
         # dx[i][ci] = sum_{t,co} dy[2i + t][co] w[ci][co][t]  == k2 s2 conv of dy
-        dx = _empty((N, D // 2, H // 2, W_ // 2, Cin), dyn)
         if _use_mfma(Cout, Cin) and Cin % 4 == 0:
+            dx = _empty((N, D // 2, H // 2, W_ // 2, Cin), dyn, dyn.dtype)
             return _k2_gather(dyn, w, None, dx, Cout, Cin, 8, Cout * 8, False)[0]
+        dx = _empty((N, D // 2, H // 2, W_ // 2, Cin), dyn)
         wp = _pack_tapmajor(w, Cout, Cin, 8, 8, Cout * 8)
         E.call('seg3d_conv3d_fwd_direct', E.ptr(dyn), E.ptr(wp), None, E.ptr(dx), N, D, H, W_, Cout, Cin, 2, 2,
                E.stream_ptr())

@@ -157,7 +157,7 @@ def test_conv3d_k3_bf16_fwd(hip_device, shape, with_addend):
     an = _ops.to_ndhwc(a.to(hip_device)) if with_addend else None
     bd = b.to(hip_device)
     E.call('seg3d_conv3d_k3_bf16_fwd', E.ptr(xb), E.ptr(wp), E.ptr(bd), E.ptr(an), E.ptr(y), E.ptr(st), E.ptr(ws),
-           N, D, H, W, Cin, Cout, E.stream_ptr())
+           N, D, H, W, Cin, Cout, 0, E.stream_ptr())
     ref = F.conv3d(x.bfloat16().double(), w.bfloat16().double(), b.double(), padding=1)
     if with_addend:
         ref = ref + a.double()
@@ -171,6 +171,52 @@ def test_conv3d_k3_bf16_fwd(hip_device, shape, with_addend):
            variant=float(E.query('seg3d_conv3d_k3_bf16_variant', N, D, H, W, Cin, Cout)),
            max_abs_err=float((got - ref).abs().max()), out_scale=scale,
            err_vs_fp32_conv=float((got - (F.conv3d(x.double(), w.double(), b.double(), padding=1) + (a.double() if with_addend else 0))).abs().max()))
+
+
+def test_bf16_multi_pack_equals_single_pack(hip_device):
+    """PackedWeightCache.repack_all() refreshes every bf16 weight image with ONE launch (pack_mfma_bf16_multi_kernel,
+    coalesced read / LDS transpose); the images equal those of the per-tensor pack kernel bit for bit, both weight
+    orientations (forward: w[b][a][t]; data-gradient: flipped taps, w[a][b][t] strides), partial channel blocks included"""
+    from segmentation3d import _ops, _engine as E
+    cache = _ops.PackedWeightCache()
+    cache.enabled = True
+    specs = [(32, 32), (64, 16), (16, 48), (256, 128)]
+    ws, images = [], []
+    for k, (cin, cout) in enumerate(specs):
+        w = _t(80 + k, 'pk', (cout, cin, 3, 3, 3), std=0.1).to(hip_device)
+        ws.append(w)
+        images.append(cache.get(w, cin, cout, 27, 27, cin * 27, 0, bf16=True))          # forward orientation
+        images.append(cache.get(w, cout, cin, 27, cin * 27, 27, 1, bf16=True))          # data-gradient orientation
+    for w in ws:
+        w.mul_(1.5).add_(0.01)
+    cache.repack_all()
+    k = 0
+    for w, (cin, cout) in zip(ws, specs):
+        for (A, B, sa, sb, flip) in ((cin, cout, 27, cin * 27, 0), (cout, cin, cin * 27, 27, 1)):
+            ref = torch.empty(E.query('seg3d_packed_mfma_bf16_elems', A, B, 27), dtype=torch.bfloat16, device=hip_device)
+            E.call('seg3d_pack_weights_mfma_bf16', E.ptr(w), E.ptr(ref), A, B, 27, sa, sb, flip, E.stream_ptr())
+            assert torch.equal(images[k].view(torch.int16).cpu(), ref.view(torch.int16).cpu()), (cin, cout, flip)
+            k += 1
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 32, 16, 16, 16), (2, 48, 20, 4, 12, 20), (4, 256, 256, 6, 6, 6)])
+def test_conv3d_k3_bf16_out_bf16_is_rounded_fp32(hip_device, shape):
+    """out_bf16 = 1 (data-gradient outputs): the stored tensor is exactly the bf16 rounding of what the fp32-output
+    launch stores (same accumulators, bias and addend; whole-K and split-K paths)"""
+    from segmentation3d import _ops, _engine as E
+    N, Cin, Cout, D, H, W = shape
+    xb = _ops.to_ndhwc(_t(45, 'ox', (N, Cin, D, H, W)).to(hip_device)).bfloat16()
+    wd = _t(46, 'ow', (Cout, Cin, 3, 3, 3), std=0.05).to(hip_device)
+    an = _ops.to_ndhwc(_t(47, 'oa', (N, Cout, D, H, W)).to(hip_device))
+    wp = torch.empty(E.query('seg3d_packed_mfma_bf16_elems', Cin, Cout, 27), dtype=torch.bfloat16, device=hip_device)
+    E.call('seg3d_pack_weights_mfma_bf16', E.ptr(wd), E.ptr(wp), Cin, Cout, 27, 27, Cin * 27, 0, E.stream_ptr())
+    ws = torch.empty(max(E.query('seg3d_conv3d_k3_bf16_fwd_workspace_floats', N, D, H, W, Cin, Cout), 1), device=hip_device)
+    y32 = torch.empty(N, D, H, W, Cout, device=hip_device)
+    y16 = torch.empty(N, D, H, W, Cout, device=hip_device, dtype=torch.bfloat16)
+    for y, flag in ((y32, 0), (y16, 1)):
+        E.call('seg3d_conv3d_k3_bf16_fwd', E.ptr(xb), E.ptr(wp), None, E.ptr(an), E.ptr(y), None, E.ptr(ws),
+               N, D, H, W, Cin, Cout, flag, E.stream_ptr())
+    assert torch.equal(y16.view(torch.int16).cpu(), y32.bfloat16().view(torch.int16).cpu())
 
 
 @pytest.mark.parametrize('shape', [(1, 32, 32, 8, 8, 16), (2, 64, 32, 12, 12, 12), (1, 16, 48, 4, 8, 8), (2, 128, 128, 4, 4, 8),

@@ -21,7 +21,7 @@ def run(kind, N, D, H, W, Cin, Cout, iters=10):
         st = torch.empty(N, cnt, 2, device=dev)
         ad = torch.randn(N, D, H, W, Cout, device=dev) if '--addend' in sys.argv else None
         nostats = '--nostats' in sys.argv
-        fn = lambda: E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(x), E.ptr(wp), None if nostats else E.ptr(b), E.ptr(ad), E.ptr(y), None if nostats else E.ptr(st), E.ptr(wsp), N, D, H, W, Cin, Cout, E.stream_ptr())
+        fn = lambda: E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(x), E.ptr(wp), None if nostats else E.ptr(b), E.ptr(ad), E.ptr(y), None if nostats else E.ptr(st), E.ptr(wsp), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
     elif kind == 'fwd16':
         xb = x.bfloat16()
         wp = torch.empty(E.query('seg3d_packed_mfma_bf16_elems', Cin, Cout, 27), dtype=torch.bfloat16, device=dev)
@@ -32,7 +32,7 @@ def run(kind, N, D, H, W, Cin, Cout, iters=10):
         wsp = torch.empty(max(nws, 1), device=dev)
         st = torch.empty(N, cnt, 2, device=dev)
         print('variant', E.query('seg3d_conv3d_k3_bf16_variant', N, D, H, W, Cin, Cout), 'ks', nws // (N * D * H * W * Cout))
-        fn = lambda: E.call('seg3d_conv3d_k3_bf16_fwd', E.ptr(xb), E.ptr(wp), E.ptr(b), None, E.ptr(y), E.ptr(st), E.ptr(wsp), N, D, H, W, Cin, Cout, E.stream_ptr())
+        fn = lambda: E.call('seg3d_conv3d_k3_bf16_fwd', E.ptr(xb), E.ptr(wp), E.ptr(b), None, E.ptr(y), E.ptr(st), E.ptr(wsp), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
     elif kind == 'wgrad16':
         xb, dyb = x.bfloat16(), dy.bfloat16()
         ws = torch.empty(E.query('seg3d_conv3d_k3_bf16_wgrad_workspace_floats', N, D, H, W, Cin, Cout), device=dev)

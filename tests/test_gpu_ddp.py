@@ -27,13 +27,15 @@ def _data():
     return x, t
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, mode):
     from conftest import PKG  # noqa: F401  (sys.path)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from segmentation3d.core.seg_train import TrainStep
+    from segmentation3d import _ops
+    _ops.set_activation_dtype(mode)
     step = TrainStep('vnet', 1, 2, 'Dice', [0.5, 0.5], device=torch.device('cuda:0'), seed=rank)  # different init per rank
     x, t = _data()
     dev = step.device
@@ -47,9 +49,11 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_train_step_matches_global_batch(hip_device, tmp_path):
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_two_rank_train_step_matches_global_batch(hip_device, tmp_path, mode):
+    """(bf16 mode: the gradients that are all-reduced are fp32 either way; the reference run below uses the same mode)"""
     world, port, out = 2, _free_port(), str(tmp_path / 'rank{}.pt')
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, mode), nprocs=world, join=True)
     r0 = torch.load(out.format(0), weights_only=True)
     r1 = torch.load(out.format(1), weights_only=True)
     assert torch.equal(r0['params'], r1['params'])          # broadcast at start + identical reduced gradients
@@ -59,13 +63,23 @@ def test_two_rank_train_step_matches_global_batch(hip_device, tmp_path):
     # gradients straight into the flat buffer; autograd still fires the leaf hooks)
     assert r0['overlapped'] == 4 and r1['overlapped'] == 4
     from segmentation3d.core.seg_train import TrainStep
+    from segmentation3d import _ops
     ref = TrainStep('vnet', 1, 2, 'Dice', [0.5, 0.5], device=hip_device, seed=0, distributed=False)
     x, t = _data()
     ref.opt.zero_grad()
-    loss = ref.loss_func(ref.net(x.to(hip_device)), t.to(hip_device))
-    loss.backward()
+    with _ops.activation_dtype(mode):
+        loss = ref.loss_func(ref.net(x.to(hip_device)), t.to(hip_device))
+        loss.backward()
     g_ref = ref.opt._flat[0]['grads'].cpu()
     g_ddp = r0['grads'] / 2.0                                # buffer holds the SUM over ranks
     rel = float((g_ddp - g_ref).abs().max() / g_ref.abs().max())
-    assert abs(0.5 * (r0['loss'] + r1['loss']) - float(loss)) < 1e-5
-    assert rel < 2e-2, rel
+    if mode == 'fp32':
+        assert abs(0.5 * (r0['loss'] + r1['loss']) - float(loss)) < 1e-5
+        assert rel < 2e-2, rel
+    else:
+        # batch 1 per rank and batch 2 in one process pick different tile plans, i.e. another fp32 summation order; in
+        # bf16 mode such a 1e-7 difference can flip the rounding of an activation (4e-3 of its value), and this random-init
+        # net amplifies that (tests/test_gpu_bf16.py): compare the loss to 1e-3 and the gradient by direction
+        cos = float((g_ddp.double() * g_ref.double()).sum() / (g_ddp.double().norm() * g_ref.double().norm()))
+        assert abs(0.5 * (r0['loss'] + r1['loss']) - float(loss)) < 1e-3
+        assert cos > 0.98, (cos, rel)

@@ -154,6 +154,10 @@ int seg3d_conv3d_k3_thin_out_fwd(const float* x, const float* wq, const float* b
 long long seg3d_k3_thin_wgrad_workspace_floats(int N, int D, int H, int W, int CT, int CF);
 int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* dw, float* workspace, int N, int D, int H, int W, int CT,
                         int CF, long long s_ct, long long s_cf, int flip, int accumulate, void* stream);
+/* bf16 mode: the same with a bf16 `fat` operand (head weight gradient on a bf16 activation) */
+int seg3d_k3_thin_wgrad_fatbf16(const float* thin, const void* fat_bf16, float* dw, float* workspace, int N, int D, int H,
+                                int W, int CT, int CF, long long s_ct, long long s_cf, int flip, int accumulate,
+                                void* stream);
 
 /* ---- GroupNorm(1, C) [+ ReLU] [+ residual]  (network/module/conv_gn_relu3.py:11,14; residual_block3.py:24,46) ------ */
 long long seg3d_gn_stats_count(long long M);
@@ -176,15 +180,16 @@ int seg3d_gn_bwd_apply(const float* dout, const float* out /* NULL: recompute */
 
 /* bf16 mode GroupNorm: the conv output y, the statistics and all arithmetic stay fp32; the activation-side tensors
  * (residual, unit output, incoming gradient) are bf16 where flagged.  ld_out / ld_dout count elements of that tensor. */
-int seg3d_gn_apply_mixed(const float* y, const float* mean_rstd, const float* gamma, const float* beta, const void* res,
+/* y_bf16: the conv output y itself is bf16 storage (the conv epilogue rounded it after taking the fp32 statistics) */
+int seg3d_gn_apply_mixed(const void* y, const float* mean_rstd, const float* gamma, const float* beta, const void* res,
                          void* out, int N, long long S, int C, int relu, int ld_out, int res_bf16, int out_bf16,
-                         void* stream);
-int seg3d_gn_bwd_reduce_bf16(const void* dout_bf16, const void* out_bf16, const float* y, const float* mean_rstd,
+                         int y_bf16, void* stream);
+int seg3d_gn_bwd_reduce_bf16(const void* dout_bf16, const void* out_bf16, const void* y, const float* mean_rstd,
                              const float* gamma, const float* beta, float* part, int N, long long S, int C, int relu,
-                             int ld_dout, void* stream);
-int seg3d_gn_bwd_apply_bf16(const void* dout_bf16, const void* out_bf16, const float* y, const float* mean_rstd,
+                             int ld_dout, int y_bf16, void* stream);
+int seg3d_gn_bwd_apply_bf16(const void* dout_bf16, const void* out_bf16, const void* y, const float* mean_rstd,
                             const float* s12, const float* gamma, const float* beta, void* dy, float* dres, int N,
-                            long long S, int C, int relu, int ld_dout, int dy_bf16, void* stream);
+                            long long S, int C, int relu, int ld_dout, int dy_bf16, int y_bf16, void* stream);
 
 /* ---- head softmax (network/module/vnet_outblock.py:18,23) ---------------------------------------------------------- */
 int seg3d_softmax_fwd(const float* in_ndhwc, float* probs_ncdhw, int N, int C, long long S, void* stream);

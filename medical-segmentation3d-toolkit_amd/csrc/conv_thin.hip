@@ -483,8 +483,9 @@ static int thin_out_launch(const void* xv, int x_bf16, const float* wq, const fl
 // ---------------------------------------------------------------------------------------------------------------
 // thin weight gradient: G[t][ct][cf] = sum_u fat[u][cf] * thin[u + off(t)][ct]
 // ---------------------------------------------------------------------------------------------------------------
-template <int CT>
-__global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __restrict__ thin, const float* __restrict__ fat,
+// FAT_BF (bf16 mode, head weight gradient): the fat operand (the unit's bf16 input) is widened at the LDS store
+template <int CT, bool FAT_BF>
+__device__ __forceinline__ void k3_thin_wgrad_body(const float* __restrict__ thin, const void* __restrict__ fat,
                                                                  float* __restrict__ part, int N, int D, int H, int W,
                                                                  int CF, int ntz, int nty, int ntx, int ntiles) {
   constexpr int ROWS = 27 * CT;
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
   // the MFMA block of the current one)
   constexpr int TE = (TH_NV * CT + 255) / 256, FE = (TH_MT * 8) / 256;
   float tst[TE];
-  f32x4 fst[FE];
+  typename Seg3dQuad<FAT_BF>::raw fst[FE];
   static_assert(TE + FE <= 32, "okmask is 32 bits");
   unsigned okmask = 0;  // zero-select deferred to store_tile: a select right at the load would serialise the loads
   auto load_tile = [&](int tile) {
@@ -552,8 +553,7 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
       const int tz = t / TH_TY;
       const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
       const bool ok = fq_ok && gz < D && gy < H && gx < W;
-      fst[k] = *reinterpret_cast<const f32x4*>(
-          fat + (ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * CF + cf0 + 4 * q : (i64)0));
+      fst[k] = Seg3dQuad<FAT_BF>::load(fat, ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * CF + cf0 + 4 * q : (i64)0);
       okmask |= (ok ? 1u : 0u) << (TE + k);
     }
   };
@@ -566,7 +566,8 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
     }
 #pragma unroll
     for (int k = 0; k < FE; ++k)
-      *reinterpret_cast<f32x4*>(fs + ((tid + k * 256) >> 3) * 32 + 4 * q) = ((okmask >> (TE + k)) & 1u) ? fst[k] : zero;
+      *reinterpret_cast<f32x4*>(fs + ((tid + k * 256) >> 3) * 32 + 4 * q) =
+          ((okmask >> (TE + k)) & 1u) ? Seg3dQuad<FAT_BF>::cvt(fst[k]) : zero;
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -634,6 +635,21 @@ __global__ __launch_bounds__(256) void k3_thin_wgrad_reduce_kernel(const float* 
   }
 }
 
+template <int CT>
+__global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __restrict__ thin, const float* __restrict__ fat,
+                                                                 float* __restrict__ part, int N, int D, int H, int W,
+                                                                 int CF, int ntz, int nty, int ntx, int ntiles) {
+  k3_thin_wgrad_body<CT, false>(thin, fat, part, N, D, H, W, CF, ntz, nty, ntx, ntiles);
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void k3_thin_wgrad_fatbf16_kernel(const float* __restrict__ thin,
+                                                                         const void* __restrict__ fat,
+                                                                 float* __restrict__ part, int N, int D, int H, int W,
+                                                                 int CF, int ntz, int nty, int ntx, int ntiles) {
+  k3_thin_wgrad_body<CT, true>(thin, fat, part, N, D, H, W, CF, ntz, nty, ntx, ntiles);
+}
+
 static int thin_wgrad_slabs(int N, int D, int H, int W) {
   const int ntiles = N * seg3d_cdiv(D, TH_TZ) * seg3d_cdiv(H, TH_TY) * seg3d_cdiv(W, TH_TX);
   const int want = (ntiles + 7) / 8;  // >= 8 tiles per workgroup keeps the slab count (and the serial reduce) small
@@ -646,19 +662,40 @@ extern "C" long long seg3d_k3_thin_wgrad_workspace_floats(int N, int D, int H, i
 }
 
 template <int CT>
-static void launch_thin_wgrad(const float* thin, const float* fat, float* part, int N, int D, int H, int W, int CF, int slabs,
-                              hipStream_t s) {
+static void launch_thin_wgrad(const float* thin, const void* fat, int fat_bf16, float* part, int N, int D, int H, int W,
+                              int CF, int slabs, hipStream_t s) {
   const int ntz = seg3d_cdiv(D, TH_TZ), nty = seg3d_cdiv(H, TH_TY), ntx = seg3d_cdiv(W, TH_TX);
-  hipLaunchKernelGGL((k3_thin_wgrad_kernel<CT>), dim3(slabs, (CF + 31) / 32), dim3(256), 0, s, thin, fat, part, N, D, H, W, CF,
-                     ntz, nty, ntx, N * ntz * nty * ntx);
+  if (fat_bf16)
+    hipLaunchKernelGGL((k3_thin_wgrad_fatbf16_kernel<CT>), dim3(slabs, (CF + 31) / 32), dim3(256), 0, s, thin, fat, part, N,
+                       D, H, W, CF, ntz, nty, ntx, N * ntz * nty * ntx);
+  else
+    hipLaunchKernelGGL((k3_thin_wgrad_kernel<CT>), dim3(slabs, (CF + 31) / 32), dim3(256), 0, s, thin,
+                       reinterpret_cast<const float*>(fat), part, N, D, H, W, CF, ntz, nty, ntx, N * ntz * nty * ntx);
 }
 
 // thin [N][D][H][W][CT] (CT <= 8), fat [N][D][H][W][CF] (CF % 4 == 0); dw[ct*s_ct + cf*s_cf + tap]
 // stem wgrad: thin = x, fat = dy, s_ct = 27, s_cf = Cin*27, flip = 0;  head wgrad: thin = dy, fat = x,
 // s_ct = Cin*27, s_cf = 27, flip = 1.
+static int thin_wgrad_launch(const float* thin, const void* fat, int fat_bf16, float* dw, float* workspace, int N, int D,
+                             int H, int W, int CT, int CF, long long s_ct, long long s_cf, int flip, int accumulate,
+                             void* stream);
+
 extern "C" int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* dw, float* workspace, int N, int D, int H,
                                    int W, int CT, int CF, long long s_ct, long long s_cf, int flip, int accumulate,
                                    void* stream) {
+  return thin_wgrad_launch(thin, fat, 0, dw, workspace, N, D, H, W, CT, CF, s_ct, s_cf, flip, accumulate, stream);
+}
+
+// bf16 mode: the fat operand is bf16 (head weight gradient: thin = fp32 dy of the 2..5-channel head, fat = bf16 input)
+extern "C" int seg3d_k3_thin_wgrad_fatbf16(const float* thin, const void* fat_bf16, float* dw, float* workspace, int N, int D,
+                                           int H, int W, int CT, int CF, long long s_ct, long long s_cf, int flip,
+                                           int accumulate, void* stream) {
+  return thin_wgrad_launch(thin, fat_bf16, 1, dw, workspace, N, D, H, W, CT, CF, s_ct, s_cf, flip, accumulate, stream);
+}
+
+static int thin_wgrad_launch(const float* thin, const void* fat, int fat_bf16, float* dw, float* workspace, int N, int D,
+                             int H, int W, int CT, int CF, long long s_ct, long long s_cf, int flip, int accumulate,
+                             void* stream) {
   SEG3D_REQUIRE(thin && fat && dw && workspace, "seg3d_k3_thin_wgrad: null pointer");
   SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "seg3d_k3_thin_wgrad: bad dims");
   SEG3D_REQUIRE(CT >= 1 && CT <= 8 && CF > 0 && (CF % 4) == 0, "seg3d_k3_thin_wgrad: need 1 <= CT <= 8 and CF %% 4 == 0");
@@ -666,14 +703,14 @@ extern "C" int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* d
   const int RB = (27 * CT + 31) / 32, CFB = (CF + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
   switch (CT) {
-    case 1: launch_thin_wgrad<1>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
-    case 2: launch_thin_wgrad<2>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
-    case 3: launch_thin_wgrad<3>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
-    case 4: launch_thin_wgrad<4>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
-    case 5: launch_thin_wgrad<5>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
-    case 6: launch_thin_wgrad<6>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
-    case 7: launch_thin_wgrad<7>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
-    default: launch_thin_wgrad<8>(thin, fat, workspace, N, D, H, W, CF, slabs, s); break;
+    case 1: launch_thin_wgrad<1>(thin, fat, fat_bf16, workspace, N, D, H, W, CF, slabs, s); break;
+    case 2: launch_thin_wgrad<2>(thin, fat, fat_bf16, workspace, N, D, H, W, CF, slabs, s); break;
+    case 3: launch_thin_wgrad<3>(thin, fat, fat_bf16, workspace, N, D, H, W, CF, slabs, s); break;
+    case 4: launch_thin_wgrad<4>(thin, fat, fat_bf16, workspace, N, D, H, W, CF, slabs, s); break;
+    case 5: launch_thin_wgrad<5>(thin, fat, fat_bf16, workspace, N, D, H, W, CF, slabs, s); break;
+    case 6: launch_thin_wgrad<6>(thin, fat, fat_bf16, workspace, N, D, H, W, CF, slabs, s); break;
+    case 7: launch_thin_wgrad<7>(thin, fat, fat_bf16, workspace, N, D, H, W, CF, slabs, s); break;
+    default: launch_thin_wgrad<8>(thin, fat, fat_bf16, workspace, N, D, H, W, CF, slabs, s); break;
   }
   SEG3D_LAUNCH_CHECK("seg3d_k3_thin_wgrad");
   const i64 total = (i64)27 * CT * CF;

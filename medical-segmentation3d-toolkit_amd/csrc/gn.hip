@@ -112,7 +112,7 @@ extern "C" int seg3d_gn_stats_finalize(const float* part, float* mean_rstd, int 
 
 // ---- apply: out = act(gamma*(y-mean)*rstd + beta (+ res)) -------------------------------------------------------
 // RES_BF / OUT_BF (bf16 mode): the residual / the output are bf16 activations; y, statistics and the arithmetic fp32
-template <bool VEC, bool RES_BF, bool OUT_BF>
+template <bool VEC, bool RES_BF, bool OUT_BF, bool Y_BF = false>
 __device__ __forceinline__ void gn_apply_body(const float* __restrict__ y, const float* __restrict__ mean_rstd,
                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                               const void* __restrict__ res_v, void* __restrict__ out_v, i64 S, int C,
@@ -127,7 +127,8 @@ __device__ __forceinline__ void gn_apply_body(const float* __restrict__ y, const
       const int q = (int)(idx - v * CQ);
       const int n = (int)(v / S);
       const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
-      const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
+      const seg3d_f32x4 yq = Seg3dQuad<Y_BF>::cvt(Seg3dQuad<Y_BF>::load(y, idx * 4));   // y: bf16 storage when Y_BF
+      const float4 yv = make_float4(yq[0], yq[1], yq[2], yq[3]);
       const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * q);
       const float4 b = *reinterpret_cast<const float4*>(beta + 4 * q);
       float4 o;
@@ -168,21 +169,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   gn_apply_body<VEC, false, false>(y, mean_rstd, gamma, beta, res, out, S, C, total_vox, relu, ldo);
 }
 
-template <bool RES_BF, bool OUT_BF>
+template <bool RES_BF, bool OUT_BF, bool Y_BF>
 __global__ __launch_bounds__(256) void gn_apply_bf16_kernel(const float* __restrict__ y,
                                                               const float* __restrict__ mean_rstd,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const void* __restrict__ res,
                                                               void* __restrict__ out, i64 S, int C, i64 total_vox,
                                                               int relu, int ldo) {
-  gn_apply_body<true, RES_BF, OUT_BF>(y, mean_rstd, gamma, beta, res, out, S, C, total_vox, relu, ldo);
+  gn_apply_body<true, RES_BF, OUT_BF, Y_BF>(y, mean_rstd, gamma, beta, res, out, S, C, total_vox, relu, ldo);
 }
 
 // bf16 mode: `res` (optional) is bf16 when res_bf16, `out` is bf16 when out_bf16 (ld_out then counts bf16 elements);
 // y fp32.  C % 4 == 0.
-extern "C" int seg3d_gn_apply_mixed(const float* y, const float* mean_rstd, const float* gamma, const float* beta,
+extern "C" int seg3d_gn_apply_mixed(const void* yv, const float* mean_rstd, const float* gamma, const float* beta,
                                     const void* res, void* out, int N, long long S, int C, int relu, int ld_out,
-                                    int res_bf16, int out_bf16, void* stream) {
+                                    int res_bf16, int out_bf16, int y_bf16, void* stream) {
+  const float* y = reinterpret_cast<const float*>(yv);   // bf16 storage when y_bf16
   SEG3D_REQUIRE(y && mean_rstd && gamma && beta && out && N > 0 && S > 0 && C > 0, "seg3d_gn_apply_mixed: bad arguments");
   SEG3D_REQUIRE((C & 3) == 0, "seg3d_gn_apply_mixed: C must be a multiple of 4 (got %d)", C);
   SEG3D_REQUIRE(ld_out == 0 || (ld_out >= C && (ld_out & 3) == 0), "seg3d_gn_apply_mixed: ld_out must be 0 or a multiple of 4 >= C");
@@ -192,8 +194,14 @@ extern "C" int seg3d_gn_apply_mixed(const float* y, const float* mean_rstd, cons
   const dim3 grid(seg3d_ew_grid(total_vox * (C / 4), 256));
   const bool rb = res && res_bf16, ob = out_bf16 != 0;
 #define GN_APPLY_MIXED(RB, OB)                                                                                     \
-  hipLaunchKernelGGL((gn_apply_bf16_kernel<RB, OB>), grid, dim3(256), 0, s, y, mean_rstd, gamma, beta, res, out, (i64)S, C, \
-                     total_vox, relu, ldo)
+  do {                                                                                                             \
+    if (y_bf16)                                                                                                    \
+      hipLaunchKernelGGL((gn_apply_bf16_kernel<RB, OB, true>), grid, dim3(256), 0, s, y, mean_rstd, gamma, beta, res, out, \
+                         (i64)S, C, total_vox, relu, ldo);                                                         \
+    else                                                                                                           \
+      hipLaunchKernelGGL((gn_apply_bf16_kernel<RB, OB, false>), grid, dim3(256), 0, s, y, mean_rstd, gamma, beta, res,   \
+                         out, (i64)S, C, total_vox, relu, ldo);                                                    \
+  } while (0)
   if (rb && ob) GN_APPLY_MIXED(true, true);
   else if (rb) GN_APPLY_MIXED(true, false);
   else if (ob) GN_APPLY_MIXED(false, true);
@@ -234,7 +242,7 @@ static inline int gn_bwd_vpb(i64 S) {
 
 // fast path: C % 4 == 0 and (C/4) divides 256: thread = (channel quad, voxel lane)
 // ACT_BF (bf16 mode): dout and out (activation-side tensors) are bf16
-template <bool ACT_BF>
+template <bool ACT_BF, bool Y_BF = false>
 __device__ __forceinline__ void gn_bwd_reduce_vec_body(const void* __restrict__ dout, const void* __restrict__ out,
                                                        const float* __restrict__ y, const float* __restrict__ mean_rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -253,6 +261,7 @@ __device__ __forceinline__ void gn_bwd_reduce_vec_body(const void* __restrict__ 
   for (i64 sv = s0 + vl; sv < s1; sv += 4 * VL) {
     float4 g[4], yv[4], o[4];
     typename Seg3dQuad<ACT_BF>::raw graw[4], oraw[4];
+    typename Seg3dQuad<Y_BF>::raw yraw[4];
     bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -260,13 +269,15 @@ __device__ __forceinline__ void gn_bwd_reduce_vec_body(const void* __restrict__ 
       ok[u] = svu < s1;
       const i64 off = ((i64)n * S + (ok[u] ? svu : s0)) * C + 4 * q;
       graw[u] = Seg3dQuad<ACT_BF>::load(dout, ((i64)n * S + (ok[u] ? svu : s0)) * ldd + 4 * q);
-      yv[u] = *reinterpret_cast<const float4*>(y + off);
+      yraw[u] = Seg3dQuad<Y_BF>::load(y, off);
       if (relu && out) oraw[u] = Seg3dQuad<ACT_BF>::load(out, off);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const seg3d_f32x4 gv = Seg3dQuad<ACT_BF>::cvt(graw[u]);
       g[u] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+      const seg3d_f32x4 yq = Seg3dQuad<Y_BF>::cvt(yraw[u]);
+      yv[u] = make_float4(yq[0], yq[1], yq[2], yq[3]);
       if (relu && out) {
         const seg3d_f32x4 ov = Seg3dQuad<ACT_BF>::cvt(oraw[u]);
         o[u] = make_float4(ov[0], ov[1], ov[2], ov[3]);
@@ -329,6 +340,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_kernel(const float* __r
   gn_bwd_reduce_vec_body<false>(dout, out, y, mean_rstd, gamma, beta, part, S, C, nblk, relu, vpb, ldd);
 }
 
+template <bool Y_BF>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_bf16_kernel(const void* __restrict__ dout,
                                                                        const void* __restrict__ out,
                                                                        const float* __restrict__ y,
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_vec_bf16_kernel(const void*
                                                                        const float* __restrict__ beta,
                                                                        float* __restrict__ part, i64 S, int C, int nblk,
                                                                        int relu, int vpb, int ldd) {
-  gn_bwd_reduce_vec_body<true>(dout, out, y, mean_rstd, gamma, beta, part, S, C, nblk, relu, vpb, ldd);
+  gn_bwd_reduce_vec_body<true, Y_BF>(dout, out, y, mean_rstd, gamma, beta, part, S, C, nblk, relu, vpb, ldd);
 }
 
 // small-C path (C <= 16, e.g. the num_classes-channel head): thread = voxel, channels in registers
@@ -418,9 +430,10 @@ extern "C" int seg3d_gn_bwd_reduce(const float* dout, const float* out, const fl
 }
 
 // bf16 mode: dout and out (optional) are bf16 activations-side tensors; y fp32.  C % 4 == 0 with (C/4) | 256.
-extern "C" int seg3d_gn_bwd_reduce_bf16(const void* dout, const void* out, const float* y, const float* mean_rstd,
+extern "C" int seg3d_gn_bwd_reduce_bf16(const void* dout, const void* out, const void* yv, const float* mean_rstd,
                                         const float* gamma, const float* beta, float* part, int N, long long S, int C,
-                                        int relu, int ld_dout, void* stream) {
+                                        int relu, int ld_dout, int y_bf16, void* stream) {
+  const float* y = reinterpret_cast<const float*>(yv);
   SEG3D_REQUIRE(dout && y && mean_rstd && part && N > 0 && S > 0 && C > 0, "seg3d_gn_bwd_reduce_bf16: bad arguments");
   SEG3D_REQUIRE(ld_dout == 0 || (ld_dout >= C && (ld_dout & 3) == 0),
                 "seg3d_gn_bwd_reduce_bf16: ld_dout must be 0 or a multiple of 4 >= C");
@@ -428,8 +441,12 @@ extern "C" int seg3d_gn_bwd_reduce_bf16(const void* dout, const void* out, const
   SEG3D_REQUIRE(!relu || out || (gamma && beta), "seg3d_gn_bwd_reduce_bf16: relu mask needs the forward output or gamma/beta");
   const int ldd = ld_dout ? ld_dout : C;
   const int nblk = (int)seg3d_gn_bwd_blocks(S);
-  hipLaunchKernelGGL(gn_bwd_reduce_vec_bf16_kernel, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, dout, out, y,
-                     mean_rstd, gamma, beta, part, (i64)S, C, nblk, relu, gn_bwd_vpb(S), ldd);
+  if (y_bf16)
+    hipLaunchKernelGGL(gn_bwd_reduce_vec_bf16_kernel<true>, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, dout, out, y,
+                       mean_rstd, gamma, beta, part, (i64)S, C, nblk, relu, gn_bwd_vpb(S), ldd);
+  else
+    hipLaunchKernelGGL(gn_bwd_reduce_vec_bf16_kernel<false>, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, dout, out, y,
+                       mean_rstd, gamma, beta, part, (i64)S, C, nblk, relu, gn_bwd_vpb(S), ldd);
   SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_reduce_bf16");
   return SEG3D_OK;
 }
@@ -537,7 +554,7 @@ extern "C" int seg3d_gn_bwd_finalize(const float* part, const float* gamma, cons
 // ---- backward apply: dy = rstd (gamma g - s1 - xhat s2),  dres = g -----------------------------------------------
 // ACT_BF: dout / out are bf16; DY_BF: dy (the gradient handed to the conv's dgrad / wgrad kernels) is written as bf16.
 // dres (gradient of the identity path, folded into a dgrad epilogue) stays fp32.
-template <bool VEC, bool ACT_BF, bool DY_BF>
+template <bool VEC, bool ACT_BF, bool DY_BF, bool Y_BF = false>
 __device__ __forceinline__ void gn_bwd_apply_body(const void* __restrict__ dout_v, const void* __restrict__ out_v,
                                                   const float* __restrict__ y, const float* __restrict__ mean_rstd,
                                                   const float* __restrict__ s12, const float* __restrict__ gamma,
@@ -558,7 +575,8 @@ __device__ __forceinline__ void gn_bwd_apply_body(const void* __restrict__ dout_
       const float s1 = s12[2 * n], s2 = s12[2 * n + 1];
       const seg3d_f32x4 gq = Seg3dQuad<ACT_BF>::cvt(Seg3dQuad<ACT_BF>::load(dout_v, v * ldd + 4 * q));
       float4 g = make_float4(gq[0], gq[1], gq[2], gq[3]);
-      const float4 yv = *reinterpret_cast<const float4*>(y + idx * 4);
+      const seg3d_f32x4 yq = Seg3dQuad<Y_BF>::cvt(Seg3dQuad<Y_BF>::load(y, idx * 4));
+      const float4 yv = make_float4(yq[0], yq[1], yq[2], yq[3]);
       const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * q);
       if (relu) {
         float4 o;
@@ -609,7 +627,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   gn_bwd_apply_body<VEC, false, false>(dout, out, y, mean_rstd, s12, gamma, beta, dy, dres, S, C, total_vox, relu, ldd);
 }
 
-template <bool DY_BF>
+template <bool DY_BF, bool Y_BF>
 __global__ __launch_bounds__(256) void gn_bwd_apply_bf16_kernel(const void* __restrict__ dout, const void* __restrict__ out,
                                                                   const float* __restrict__ y,
                                                                   const float* __restrict__ mean_rstd,
@@ -618,13 +636,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_bf16_kernel(const void* __re
                                                                   const float* __restrict__ beta, void* __restrict__ dy,
                                                                   float* __restrict__ dres, i64 S, int C, i64 total_vox,
                                                                   int relu, int ldd) {
-  gn_bwd_apply_body<true, true, DY_BF>(dout, out, y, mean_rstd, s12, gamma, beta, dy, dres, S, C, total_vox, relu, ldd);
+  gn_bwd_apply_body<true, true, DY_BF, Y_BF>(dout, out, y, mean_rstd, s12, gamma, beta, dy, dres, S, C, total_vox, relu,
+                                             ldd);
 }
 
 // bf16 mode: dout / out bf16; dy bf16 when dy_bf16 (else fp32); dres fp32.  C % 4 == 0.
-extern "C" int seg3d_gn_bwd_apply_bf16(const void* dout, const void* out, const float* y, const float* mean_rstd,
+extern "C" int seg3d_gn_bwd_apply_bf16(const void* dout, const void* out, const void* yv, const float* mean_rstd,
                                        const float* s12, const float* gamma, const float* beta, void* dy, float* dres,
-                                       int N, long long S, int C, int relu, int ld_dout, int dy_bf16, void* stream) {
+                                       int N, long long S, int C, int relu, int ld_dout, int dy_bf16, int y_bf16,
+                                       void* stream) {
+  const float* y = reinterpret_cast<const float*>(yv);
   SEG3D_REQUIRE(dout && y && mean_rstd && s12 && gamma && dy && N > 0 && S > 0 && C > 0,
                 "seg3d_gn_bwd_apply_bf16: bad arguments");
   SEG3D_REQUIRE((C & 3) == 0, "seg3d_gn_bwd_apply_bf16: C must be a multiple of 4 (got %d)", C);
@@ -635,12 +656,14 @@ extern "C" int seg3d_gn_bwd_apply_bf16(const void* dout, const void* out, const 
   const i64 total_vox = (i64)N * S;
   const dim3 grid(seg3d_ew_grid(total_vox * (C / 4), 256));
   hipStream_t s = (hipStream_t)stream;
-  if (dy_bf16)
-    hipLaunchKernelGGL((gn_bwd_apply_bf16_kernel<true>), grid, dim3(256), 0, s, dout, out, y, mean_rstd, s12, gamma, beta, dy,
-                       dres, (i64)S, C, total_vox, relu, ldd);
-  else
-    hipLaunchKernelGGL((gn_bwd_apply_bf16_kernel<false>), grid, dim3(256), 0, s, dout, out, y, mean_rstd, s12, gamma, beta,
-                       dy, dres, (i64)S, C, total_vox, relu, ldd);
+#define GN_BWD_APPLY16(DB, YB)                                                                                   \
+  hipLaunchKernelGGL((gn_bwd_apply_bf16_kernel<DB, YB>), grid, dim3(256), 0, s, dout, out, y, mean_rstd, s12, gamma, beta, \
+                     dy, dres, (i64)S, C, total_vox, relu, ldd)
+  if (dy_bf16 && y_bf16) GN_BWD_APPLY16(true, true);
+  else if (dy_bf16) GN_BWD_APPLY16(true, false);
+  else if (y_bf16) GN_BWD_APPLY16(false, true);
+  else GN_BWD_APPLY16(false, false);
+#undef GN_BWD_APPLY16
   SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_apply_bf16");
   return SEG3D_OK;
 }

@@ -59,9 +59,9 @@ _SIGNATURES = {
     'seg3d_convT3d_k2s2_bf16_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 7 + [_c_p]),
     'seg3d_k2_bf16_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_ll, _c_ll, _c_int, _c_p]),
     'seg3d_conv3d_k3_thin_out_bf16_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 7 + [_c_p]),
-    'seg3d_gn_apply_mixed': (_c_int, [_c_p] * 6 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
-    'seg3d_gn_bwd_reduce_bf16': (_c_int, [_c_p] * 7 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_p]),
-    'seg3d_gn_bwd_apply_bf16': (_c_int, [_c_p] * 9 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    'seg3d_gn_apply_mixed': (_c_int, [_c_p] * 6 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    'seg3d_gn_bwd_reduce_bf16': (_c_int, [_c_p] * 7 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    'seg3d_gn_bwd_apply_bf16': (_c_int, [_c_p] * 9 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_int, _c_int, _c_p]),
     'seg3d_conv3d_k3_mfma_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 7 + [_c_p]),
     'seg3d_conv3d_k2s2_mfma_stats_count': (_c_ll, [_c_int] * 4),
@@ -79,6 +79,7 @@ _SIGNATURES = {
     'seg3d_conv3d_k3_thin_out_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 7 + [_c_p]),
     'seg3d_k3_thin_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
     'seg3d_k3_thin_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_ll, _c_ll, _c_int, _c_int, _c_p]),
+    'seg3d_k3_thin_wgrad_fatbf16': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_ll, _c_ll, _c_int, _c_int, _c_p]),
     'seg3d_gn_stats_count': (_c_ll, [_c_ll]),
     'seg3d_gn_stats_partial': (_c_int, [_c_p, _c_p, _c_int, _c_ll, _c_p]),
     'seg3d_gn_stats_finalize': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_f, _c_p]),

@@ -28,6 +28,9 @@ FORCE_DIRECT = False
 # packed k3 weights are bf16 (fp32 master weights), accumulation / conv outputs / GroupNorm statistics / losses fp32.
 # The reference has no such switch (it computes in fp32 throughout); the default here is fp32 as well.
 _ACT_BF16 = [False]
+# bf16 mode, second switch: the raw conv output y (read by GroupNorm forward and backward, saved for backward) is bf16 as
+# well -- rounded by the conv epilogue AFTER the fp32 (sum, sumsq) statistics are taken.  SEG3D_BF16_Y=0 keeps y in fp32.
+BF16_CONV_OUTPUT = os.environ.get('SEG3D_BF16_Y', '1') != '0'
 
 
 def set_activation_dtype(name):
@@ -355,27 +358,31 @@ def _thin_wgrad(thin, fat, CT, CF, out_shape, s_ct, s_cf, flip, out=None):
     N, D, H, W_, _ = thin.shape
     ws = _empty((E.query('seg3d_k3_thin_wgrad_workspace_floats', N, D, H, W_, CT, CF),), thin)
     dw = _empty(out_shape, thin) if out is None else out
-    E.call('seg3d_k3_thin_wgrad', E.ptr(thin), E.ptr(fat), E.ptr(dw), E.ptr(ws), N, D, H, W_, CT, CF, s_ct, s_cf, flip,
-           int(out is not None), E.stream_ptr())
+    thin = _to_f32(thin)
+    E.call('seg3d_k3_thin_wgrad_fatbf16' if _is_bf16(fat) else 'seg3d_k3_thin_wgrad', E.ptr(thin), E.ptr(fat), E.ptr(dw),
+           E.ptr(ws), N, D, H, W_, CT, CF, s_ct, s_cf, flip, int(out is not None), E.stream_ptr())
     return dw
 
 
-def conv_forward(xn, w, bias, kind, want_stats=False):
-    """xn: [N,D,H,W,Cin] contiguous; w in the reference layout; returns (y NDHWC, stats_partial or None)"""
+def conv_forward(xn, w, bias, kind, want_stats=False, out_bf16=False):
+    """xn: [N,D,H,W,Cin] contiguous; w in the reference layout; returns (y NDHWC, stats_partial or None).
+    out_bf16 (bf16 mode): REQUEST a bf16 y; honoured by the kernels that take bf16 input (check y.dtype)"""
     ks, stride, T, transposed = _KINDS[kind]
     N, D, H, W_, Cin = xn.shape
     if kind == 'k3':
         Cout = w.shape[0]
         _check_w(w, (Cout, Cin, 3, 3, 3), kind)
-        return _conv_k3_generic(xn, w, bias, Cin, Cout, 27, Cin * 27, 0, want_stats)
+        return _conv_k3_generic(xn, w, bias, Cin, Cout, 27, Cin * 27, 0, want_stats, out_bf16=out_bf16)
     if kind == 'k2s2':
         Cout = w.shape[0]
         _check_w(w, (Cout, Cin, 2, 2, 2), kind)
         if D % 2 or H % 2 or W_ % 2:
             raise ValueError('Conv3d k2 s2 needs even spatial dims, got {}'.format((D, H, W_)))
-        y = _empty((N, D // 2, H // 2, W_ // 2, Cout), xn)
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
+            ydt = torch.bfloat16 if (out_bf16 and _is_bf16(xn)) else torch.float32
+            y = _empty((N, D // 2, H // 2, W_ // 2, Cout), xn, ydt)
             return _k2_gather(xn, w, bias, y, Cin, Cout, 8, Cin * 8, want_stats)
+        y = _empty((N, D // 2, H // 2, W_ // 2, Cout), xn)
         xn = _to_f32(xn)
         wp = _pack_tapmajor(w, Cin, Cout, 8, 8, Cin * 8)
         E.call('seg3d_conv3d_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout, 2, 2,
@@ -393,9 +400,11 @@ def conv_forward(xn, w, bias, kind, want_stats=False):
     if kind == 'convT':
         Cout = w.shape[1]
         _check_w(w, (Cin, Cout, 2, 2, 2), kind)
-        y = _empty((N, 2 * D, 2 * H, 2 * W_, Cout), xn)
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
+            ydt = torch.bfloat16 if (out_bf16 and _is_bf16(xn)) else torch.float32
+            y = _empty((N, 2 * D, 2 * H, 2 * W_, Cout), xn, ydt)
             return _k2_scatter(xn, w, bias, y, Cin, Cout, Cout * 8, 8, want_stats)
+        y = _empty((N, 2 * D, 2 * H, 2 * W_, Cout), xn)
         xn = _to_f32(xn)
         wp = _pack_tapmajor(w, Cin, Cout, 8, Cout * 8, 8)
         E.call('seg3d_convT3d_k2s2_fwd_direct', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), N, D, H, W_, Cin, Cout,
@@ -487,7 +496,11 @@ def conv_wgrad(xn, dyn, w_shape, kind, out=None):
             E.call('seg3d_conv3d_k3_bf16_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(dw), E.ptr(ws), N, D, H, W_, Cin, Cout,
                    int(out is not None), E.stream_ptr())
             return dw
-        xn, dyn = _to_f32(xn), _to_f32(dyn)     # mixed / thin cases (head: bf16 x, fp32 dy): widen, then the fp32 kernels
+        if _is_bf16(xn) and not _is_bf16(dyn) and not FORCE_DIRECT and Cout <= 8 and Cin % 4 == 0 and \
+                not (_use_mfma(Cin, Cout) and Cout % 4 == 0):
+            # bf16-mode head: thin = fp32 dy, fat = the unit's bf16 input, widened inside the kernel
+            return _thin_wgrad(dyn, xn, Cout, Cin, w_shape, Cin * 27, 27, 1, out)
+        xn, dyn = _to_f32(xn), _to_f32(dyn)     # remaining mixed cases: widen, then the fp32 kernels
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             nfl = E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W_, Cin, Cout)
             ws = _empty((nfl,), xn)
@@ -525,6 +538,7 @@ def gn_stats(yn, stats_partial=None, eps=GN_EPS):
     N = yn.shape[0]
     M = yn[0].numel()
     if stats_partial is None:
+        yn = _to_f32(yn)
         cnt = E.query('seg3d_gn_stats_count', M)
         stats_partial = _empty((N, cnt, 2), yn)
         E.call('seg3d_gn_stats_partial', E.ptr(yn), E.ptr(stats_partial), N, M, E.stream_ptr())
@@ -540,6 +554,8 @@ def gn_apply(yn, mean_rstd, gamma, beta, resn, relu, out=None, out_bf16=False):
     bf16 mode: `resn` may be bf16; the output is bf16 when out_bf16 (or when `out` is a bf16 buffer)."""
     N, D, H, W_, C = yn.shape
     ld = 0
+    if _is_bf16(yn) and C % 4:
+        yn = _to_f32(yn)
     if out is None:
         out = torch.empty(yn.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=yn.device)
     else:
@@ -547,9 +563,9 @@ def gn_apply(yn, mean_rstd, gamma, beta, resn, relu, out=None, out_bf16=False):
                 out.stride(2) != W_ * out.stride(3) or out.stride(1) != H * out.stride(2) or out.stride(0) != D * out.stride(1):
             raise ValueError('gn_apply destination must be a channel slice of a contiguous NDHWC buffer')
         ld = out.stride(3)
-    if _is_bf16(out) or _is_bf16(resn):
+    if _is_bf16(out) or _is_bf16(resn) or _is_bf16(yn):
         E.call('seg3d_gn_apply_mixed', E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta), E.ptr(resn), E.ptr(out), N,
-               D * H * W_, C, int(relu), ld, int(_is_bf16(resn)), int(_is_bf16(out)), E.stream_ptr())
+               D * H * W_, C, int(relu), ld, int(_is_bf16(resn)), int(_is_bf16(out)), int(_is_bf16(yn)), E.stream_ptr())
         return out
     E.call('seg3d_gn_apply', E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta), E.ptr(resn), E.ptr(out), N,
            D * H * W_, C, int(relu), ld, E.stream_ptr())
@@ -585,8 +601,15 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
         raise TypeError('GroupNorm backward: gradient and saved output differ in dtype')
     if dy_bf16 and not act_bf16:
         raise TypeError('GroupNorm backward: a bf16 conv gradient needs a bf16 unit output')
-    E.call('seg3d_gn_bwd_reduce_bf16' if act_bf16 else 'seg3d_gn_bwd_reduce', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn),
-           E.ptr(mean_rstd), E.ptr(gamma), E.ptr(beta), E.ptr(part), N, S, C, int(relu), ldd, E.stream_ptr())
+    if _is_bf16(yn) and not act_bf16:
+        yn = _to_f32(yn)              # (not produced by the fused units: a bf16 y always comes with a bf16 output)
+    y16 = int(_is_bf16(yn))
+    if act_bf16:
+        E.call('seg3d_gn_bwd_reduce_bf16', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma),
+               E.ptr(beta), E.ptr(part), N, S, C, int(relu), ldd, y16, E.stream_ptr())
+    else:
+        E.call('seg3d_gn_bwd_reduce', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(gamma),
+               E.ptr(beta), E.ptr(part), N, S, C, int(relu), ldd, E.stream_ptr())
     abx = _empty((N, C, 3), yn)
     s12 = _empty((N, 2), yn)
     sg, sb_, sc = sinks
@@ -600,10 +623,11 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
     E.call('seg3d_gn_bwd_finalize', E.ptr(part), E.ptr(gamma), E.ptr(mean_rstd), E.ptr(abx), E.ptr(s12), E.ptr(dgamma),
            E.ptr(dbeta), E.ptr(dbias), N, S, C, acc_mask, E.stream_ptr())
     dy = torch.empty(yn.shape, dtype=torch.bfloat16 if dy_bf16 else torch.float32, device=yn.device)
-    dres = torch.empty_like(yn) if want_dres else None
+    dres = torch.empty(yn.shape, dtype=torch.float32, device=yn.device) if want_dres else None
     if act_bf16:
         E.call('seg3d_gn_bwd_apply_bf16', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(s12),
-               E.ptr(gamma), E.ptr(beta), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), ldd, int(dy_bf16), E.stream_ptr())
+               E.ptr(gamma), E.ptr(beta), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), ldd, int(dy_bf16), y16,
+               E.stream_ptr())
     else:
         E.call('seg3d_gn_bwd_apply', E.ptr(doutn), E.ptr(mask_src), E.ptr(yn), E.ptr(mean_rstd), E.ptr(s12), E.ptr(gamma),
                E.ptr(beta), E.ptr(dy), E.ptr(dres), N, S, C, int(relu), ldd, E.stream_ptr())
@@ -694,7 +718,8 @@ class ConvGnActFunction(torch.autograd.Function):
         E.require_device(x, weight, bias, gamma, beta, residual)
         xn = to_ndhwc(x)
         w = weight.detach()
-        yn, partial = conv_forward(xn, w, None if bias is None else bias.detach(), kind, want_stats=True)
+        want16 = BF16_CONV_OUTPUT and _is_bf16(xn) and _out_bf16(w.shape[1] if kind == 'convT' else w.shape[0])
+        yn, partial = conv_forward(xn, w, None if bias is None else bias.detach(), kind, want_stats=True, out_bf16=want16)
         mean_rstd = gn_stats(yn, partial, eps)
         resn = None
         if residual is not None:
@@ -767,7 +792,8 @@ class UpCatFunction(torch.autograd.Function):
         xn = to_ndhwc(x)
         sn = to_ndhwc(skip)
         w = weight.detach()
-        yn, partial = conv_forward(xn, w, None if bias is None else bias.detach(), 'convT', want_stats=True)
+        want16 = BF16_CONV_OUTPUT and _is_bf16(xn) and _is_bf16(sn) and _out_bf16(w.shape[1])
+        yn, partial = conv_forward(xn, w, None if bias is None else bias.detach(), 'convT', want_stats=True, out_bf16=want16)
         if sn.shape[:4] != yn.shape[:4]:
             raise ValueError('cat: spatial shapes differ: {} vs {}'.format(tuple(from_ndhwc(yn).shape), tuple(skip.shape)))
         mean_rstd = gn_stats(yn, partial, eps)

@@ -33,10 +33,12 @@ def _bf(t):
 @pytest.mark.parametrize('kind,cin,cout,shape,residual', [
     ('k3', 32, 32, (2, 8, 8, 16), False), ('k3', 16, 16, (1, 6, 10, 12), True), ('k3', 64, 16, (1, 4, 6, 6), False),
     ('k2s2', 16, 32, (2, 8, 8, 8), False), ('convT', 64, 16, (1, 4, 4, 6), False)])
-def test_fused_unit_bf16_exact_operands(hip_device, kind, cin, cout, shape, residual):
+@pytest.mark.parametrize('y16', [True, False])
+def test_fused_unit_bf16_exact_operands(hip_device, kind, cin, cout, shape, residual, y16):
     """out = bf16(relu(GN(conv(x_bf16, w) + b) [+ res_bf16])): equals the double-precision evaluation of the same
     expression on the bf16-rounded operands up to one bf16 rounding of the result; input / weight gradients equal the
-    double-precision gradients of that expression with the same roundings of the intermediate gradient (dy -> bf16)"""
+    double-precision gradients of that expression with the same roundings of the intermediate gradient (dy -> bf16).
+    y16: the conv output itself is stored as bf16 (rounded after the fp32 statistics were taken) -- the default -- or fp32"""
     from segmentation3d import _ops
     N, D, H, W = shape
     x = torch.from_numpy(detgen.normal(71, 'u/x', (N, cin, D, H, W))).bfloat16()
@@ -57,7 +59,12 @@ def test_fused_unit_bf16_exact_operands(hip_device, kind, cin, cout, shape, resi
     res = None
     if residual:
         res = torch.from_numpy(detgen.normal(76, 'u/r', tuple(y.shape))).bfloat16()
-    o = F.group_norm(y, 1, g.double(), be.double(), eps=1e-5)
+    # GroupNorm(1, C) with the statistics of the exact y; with y16 the normalised tensor is bf16(y) (straight-through)
+    dims = (1, 2, 3, 4)
+    mu = y.mean(dims, keepdim=True)
+    rstd = 1.0 / torch.sqrt(y.var(dims, unbiased=False, keepdim=True) + 1e-5)
+    y_used = y + (y.bfloat16().double() - y).detach() if y16 else y
+    o = (y_used - mu) * rstd * g.double().view(1, -1, 1, 1, 1) + be.double().view(1, -1, 1, 1, 1)
     if res is not None:
         o = o + res.double()
     o = F.relu(o)
@@ -65,6 +72,8 @@ def test_fused_unit_bf16_exact_operands(hip_device, kind, cin, cout, shape, resi
     o.backward(dout.double())
 
     dev = hip_device
+    y_was = _ops.BF16_CONV_OUTPUT
+    _ops.BF16_CONV_OUTPUT = y16
     with _ops.activation_dtype('bf16'):
         xg = x.to(dev).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3).requires_grad_(True)   # NDHWC memory
         wg = w.to(dev).requires_grad_(True)
@@ -73,6 +82,7 @@ def test_fused_unit_bf16_exact_operands(hip_device, kind, cin, cout, shape, resi
         out = _ops.conv_gn_act(xg, wg, bg, gg, beg, residual=rg, kind=kind, relu=True)
         assert out.dtype == torch.bfloat16
         out.backward(dout.to(dev))
+    _ops.BF16_CONV_OUTPUT = y_was
     torch.cuda.synchronize()
     ref = o.detach()
     got = out.detach().double().cpu()
@@ -82,8 +92,8 @@ def test_fused_unit_bf16_exact_operands(hip_device, kind, cin, cout, shape, resi
     # down in the sums; compare in relative L2
     e_dx = rel_err(xg.grad.double().cpu(), xd.grad)
     e_dw = rel_err(wg.grad.double().cpu(), wq.grad)
-    report('bf16_unit_{}_{}_{}{}'.format(kind, cin, cout, '_res' if residual else ''), out_rel_max=e_out, dx_rel=e_dx,
-           dw_rel=e_dw)
+    report('bf16_unit_{}_{}_{}{}{}'.format(kind, cin, cout, '_res' if residual else '', '_y16' if y16 else ''),
+           out_rel_max=e_out, dx_rel=e_dx, dw_rel=e_dw)
     assert e_out <= 2.0 ** -8 * 1.01 + 1e-6, e_out          # one bf16 rounding of the result
     assert e_dx < 5e-3 and e_dw < 5e-3, (e_dx, e_dw)
 

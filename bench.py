@@ -31,6 +31,7 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (v_mfma_f32_32x32x16_bf16)
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E
 HBM_PEAK_GBS = 8000.0
 
 
@@ -99,7 +100,7 @@ class KernelTimer(object):
             b.record()
             ma = E.query('seg3d_conv3d_k3_bf16_variant' if 'bf16' in name else 'seg3d_conv3d_k3_mfma_variant',
                          N, D, H, W, Cin, Cout)
-            timer.records.append(((N, D, H, W, Cin, Cout, ma), a, b))
+            timer.records.append(((N, D, H, W, Cin, Cout, ma), a, b, 2 if 'bf16' in name else 4))
             return rc
         E.call = call
         return self
@@ -110,21 +111,24 @@ class KernelTimer(object):
     def summary(self):
         torch.cuda.synchronize()
         table = {}
-        for key, a, b in self.records:
+        for key, a, b, elem_bytes in self.records:
             N, D, H, W, Cin, Cout, ma = key
             ms = a.elapsed_time(b)
             flops = 2.0 * N * D * H * W * 27 * Cin * Cout
-            e = table.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+            e = table.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
             e['launches'] += 1
             e['ms'] += ms
             e['flops'] += flops
+            # algorithmic bytes: input + output once (+ the packed weights); bf16 mode moves 2-byte elements both ways
+            e['bytes'] += elem_bytes * (float(N) * D * H * W * (Cin + Cout) + 27.0 * Cin * Cout)
         return table
 
 
 def variant_kernel_name(v):
     """seg3d_conv3d_k3_mfma_variant code -> kernel symbol as rocprofv3 prints it"""
     if v >= 200:
-        return 'conv3d_k3_mfma2_bf16_kernel<{}, {}>'.format((v - 200) // 10, v % 10)
+        # third template argument: bf16 output -- every data-gradient, and every forward launch unless SEG3D_BF16_Y=0
+        return 'conv3d_k3_mfma2_bf16_kernel<{}, {}, true>'.format((v - 200) // 10, v % 10)
     if v >= 100:
         return 'conv3d_k3_mfma2_kernel<{}, {}>'.format((v - 100) // 10, v % 10)
     return 'conv3d_k3_mfma_kernel<{}>'.format(v)
@@ -135,7 +139,8 @@ def pmc_traffic_gb(kernel_name):
     (profiles/r01_pmc_fetch_write_per_kernel.json: FETCH_SIZE and WRITE_SIZE in KB, collected in separate --pmc
     passes).  gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE under-reports wide coalesced reads
     by 2x, WRITE_SIZE is exact.  Counters cannot be collected from inside bench.py; returns None when absent."""
-    path = os.path.join(REPO, 'profiles', 'r01_pmc_fetch_write_per_kernel.json')
+    path = os.path.join(REPO, 'profiles', 'r01_h_bf16_pmc_fetch_write_per_kernel.json' if 'bf16' in kernel_name
+                        else 'r01_pmc_fetch_write_per_kernel.json')
     if not os.path.isfile(path):
         return None
     with open(path) as f:
@@ -284,7 +289,7 @@ def main():
     if not args.no_roofline and rank == 0:
         by_variant = {}
         for key, e in table.items():
-            v = by_variant.setdefault(key[6], {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+            v = by_variant.setdefault(key[6], {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
             for k in v:
                 v[k] += e[k]
         dom = max(by_variant, key=lambda m: by_variant[m]['ms'])
@@ -293,6 +298,8 @@ def main():
         d = by_variant[dom]
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
+        gbps = d['bytes'] / (d['ms'] * 1e-3) / 1e9
+        hbm_frac = gbps / HBM_PEAK_GBPS
         roofline = {'kernel': kname, 'bound': 'mfma', 'achieved': round(achieved, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                     'traffic': traffic, 'traffic_unit': 'GB per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, see profiles/)',
@@ -302,6 +309,13 @@ def main():
                     'share_of_step_ms': round(d['ms'] / 2, 3),
                     'note': 'launch durations from 2 instrumented steps with the weight-gradient side stream off '
                             '(kernels back to back on one stream); value/ms_per_step are measured with it on'}
+        if hbm_frac > achieved / peak:
+            # (bf16 mode) the same launches priced against HBM: algorithmic bytes = input + output once
+            roofline.update({'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                             'frac': round(hbm_frac, 4), 'gb_per_launch': round(d['bytes'] / d['launches'] / 1e9, 4),
+                             'mfma_tflops': round(achieved, 2), 'mfma_frac': round(achieved / peak, 4)})
+        else:
+            roofline['hbm_frac_of_algorithmic_bytes'] = round(hbm_frac, 4)
         kernels = [{'N_D_H_W_Cin_Cout_variant': list(k), 'launches_per_step': e['launches'] // 2,
                     'avg_ms': round(e['ms'] / e['launches'], 4),
                     'tflops': round(e['flops'] / (e['ms'] * 1e-3) / 1e12, 2)} for k, e in sorted(table.items())]

@@ -619,7 +619,9 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
               s0 += v[c];
               s1 += v[c] * v[c];
             }
+#ifndef SEG3D_EXP_NOSTORE   // measurement builds only: skip the interior stores to price them
             Seg3dQuad<OUT_BF>::store(y, (i64)vo[m] * Cout + (co_lane + 32 * q + 8 * g4), v);   // y: bf16 when OUT_BF
+#endif
           }
     } else {
 #pragma unroll

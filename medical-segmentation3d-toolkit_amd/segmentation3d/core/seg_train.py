@@ -136,8 +136,10 @@ def train(train_config_file, data_iter_factory=None):
     if cfg.general.num_gpus <= 0:
         raise RuntimeError('segmentation3d HIP engine needs general.num_gpus > 0 (no CPU training path)')
     num_modality = int(getattr(cfg.dataset, 'num_modality', 1))
+    _ops.set_activation_dtype(str(getattr(cfg.train, 'compute_dtype', 'fp32')))
     step = TrainStep(cfg.net.name, num_modality, cfg.dataset.num_classes, cfg.loss.name, cfg.loss.obj_weight,
-                     cfg.loss.focal_gamma, cfg.train.lr, tuple(cfg.train.betas), seed=cfg.general.seed)
+                     cfg.loss.focal_gamma, cfg.train.lr, tuple(cfg.train.betas), seed=cfg.general.seed,
+                     use_graph=bool(getattr(cfg.train, 'use_graph', False)))
     assert np.all(np.array(cfg.dataset.crop_size) % step.max_stride == 0), 'crop size not divisible by max stride'
     last_save_epoch, batch_idx = 0, 0
     if cfg.general.resume_epoch >= 0:

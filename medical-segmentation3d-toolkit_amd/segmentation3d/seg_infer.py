@@ -16,7 +16,12 @@ def main():
     parser.add_argument('-g', '--gpu_id', type=int, default=0, help='GPU to run on (>= 0; the engine has no CPU path)')
     parser.add_argument('--save_image', action='store_true', help='also save the input image')
     parser.add_argument('--save_prob', action='store_true', help='also save every class probability map')
+    parser.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                        help='fp32 = the reference arithmetic (default); bf16 = bf16 activations / packed weights with '
+                             'fp32 accumulation (about 3x faster, probabilities within ~1e-2)')
     args = parser.parse_args()
+    from segmentation3d import _ops
+    _ops.set_activation_dtype(args.dtype)
     segmentation(args.input, args.model, args.output, args.seg_name, args.gpu_id, False, True, args.save_image,
                  args.save_prob)
 

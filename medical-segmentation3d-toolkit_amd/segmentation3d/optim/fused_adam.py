@@ -196,3 +196,5 @@ class FusedAdam(torch.optim.Optimizer):
                 step = max(step, int(float(st['step'])))
                 st['step'] = torch.tensor(float(step))
             f['step'] = step
+            if self.device_step and 'step_dev' in f:
+                f['step_dev'].fill_(int(step))        # a captured step reads its count from the device

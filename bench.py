@@ -169,7 +169,17 @@ def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):
         torch_ref.train_step(sd, opt, x, t, net_name, loss_name, kw)
         times.append(time.time() - t0)
     steady = times[1:]
+    # the CPU side of the inference metric (BASELINE config 1 / 4: one forward per 96^3 patch): same oracle, forward only
+    fwd = []
+    with torch.no_grad():
+        sd_eval = {k: v.detach() for k, v in sd.items()}
+        for i in range(3):
+            t0 = time.time()
+            torch_ref.segmentation_net(x, sd_eval, net_name)
+            fwd.append(time.time() - t0)
+    fwd_steady = fwd[1:]
     return {'value': round(1.0 / (sum(steady) / len(steady)), 4), 'unit': 'patches/s', 'cores': torch.get_num_threads(),
+            'forward_only_patches_per_s': round(1.0 / (sum(fwd_steady) / len(fwd_steady)), 4),
             'kind': 'port',
             'sample': '{} timed train steps (fwd+{}+bwd+Adam) of {}({},{}) on one {}^3 patch, batch 1, after 1 warm-up; '
                       'oracle/torch_ref.py = the stock torch CPU ops the reference composes'.format(

@@ -844,6 +844,15 @@ static int seg3d_fwd_v2_ksplit_enabled() {  // SEG3D_FWD_V2_KSPLIT=0: whole-K it
   return v;
 }
 
+static int seg3d_force_ks() {   // SEG3D_FWD_V2_FORCE_KS=n: measurement switch, forces the K split where it is legal
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEG3D_FWD_V2_FORCE_KS");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 // time model (cycles): 256 workgroups run at once, every round costs one workgroup's duration =
 // K-chunks x 27 taps x 4 x MA x NB MFMAs of 64 cycles + DMA issue + a fixed prologue/epilogue
 // With ks > 1 an item covers only ceil(cib / ks) chunks and a finish pass (read ks slabs, write y) is added; that pays
@@ -877,6 +886,7 @@ static bool seg3d_pick_tile_v2(int N, int D, int H, int W, int Cin, int Cout, Se
           const double pieces = (((8 * nv + 255) >> 8) + 27 * nb) / 4.0;
           for (int ks : cand_ks) {
             if (ks > 1 && (2 * ks > cib || !seg3d_fwd_v2_ksplit_enabled())) break;
+            if (seg3d_force_ks() > 0 && ks != seg3d_force_ks() && 2 * seg3d_force_ks() <= cib) continue;
             const int cpk = (cib + ks - 1) / ks;
             const int slabs = (cib + cpk - 1) / cpk;
             if (slabs != ks) continue;  // this ks leaves an empty slab; a smaller one covers the same split

@@ -1602,8 +1602,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
 //   is multiplied, tiles t+1 and t+2 are landing and the pieces of t+3 are issued one per step; the barrier of a tile is
 //   preceded by a COUNTED s_waitcnt vmcnt that leaves the younger tiles' DMAs in flight (every wave issues exactly NG
 //   pieces per tile -- the ring slots are padded to whole groups -- so the count is a constant).
-//   Tiles must lie inside the volume (D, H, W multiples of the tile): the launcher falls back to the register-staged
-//   kernel otherwise.
+//   Tiles that stick out of the volume (IRR instantiation) pad by the voxel's coordinates; channel counts that are not
+//   multiples of 8 take the register-staged kernel.
 // ----------------------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -1636,7 +1636,9 @@ __device__ __forceinline__ bf16x8 seg3d_tr_join(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int TZ, int TY, int TX>
+// IRR: tiles may stick out of the volume (D, H, W not multiples of the tile, e.g. the 6^3 level): a piece is zero padding
+// when its voxel lies outside the volume, tested on the voxel's coordinates instead of the tile's halo-face bits
+template <int TZ, int TY, int TX, bool IRR>
 __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad3_bf16_kernel(const seg3d_bf16* __restrict__ x,
                                                                          const seg3d_bf16* __restrict__ dy,
                                                                          float* __restrict__ part, int N, int D, int H,
@@ -1689,11 +1691,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad3_bf16_kernel(const seg
   // DMA pieces: piece p = wave + 4 g; lane -> voxel 16 p' + (lane >> 2), channels 8 (lane & 3) .. +7 (16 bytes)
   const int lv = lane >> 2, lq = lane & 3;
   int prel[NG], pflag[NG];  // bf16-element offset from the tile-origin voxel; halo-face bits (bit 6: always zero)
+  int pcoord[NG];           // IRR: halo coordinates hz | hy << 8 | hx << 16 of the piece's voxel (dy pieces: tile coords + 1)
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int p = wave + 4 * g;
     prel[g] = 0;
     pflag[g] = 64;
+    pcoord[g] = 0;
     if (p < XPC) {
       const int v = p * 16 + lv;
       if (v < NVH) {
@@ -1701,12 +1705,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad3_bf16_kernel(const seg
         prel[g] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + ci0 + 8 * lq;
         pflag[g] = (hz == 0 ? 1 : 0) | (hz == TZ + 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == TY + 1 ? 8 : 0) |
                    (hx == 0 ? 16 : 0) | (hx == TX + 1 ? 32 : 0) | (ci0 + 8 * lq < Cin ? 0 : 64);
+        pcoord[g] = hz | (hy << 8) | (hx << 16);
       }
     } else if (p < NP) {
       const int v = (p - XPC) * 16 + lv;
       const int co = co0 + 8 * lq;
       prel[g] = (((v / (TX * TY)) * H + (v / TX) % TY) * W + v % TX) * Cout + co;
       pflag[g] = co < Cout ? 0 : 64;
+      pcoord[g] = (v / (TX * TY) + 1) | (((v / TX) % TY + 1) << 8) | ((v % TX + 1) << 16);
     }                                                   // p >= NP: padding piece (zeros into the slot's tail)
   }
   int tn = 0, tz0 = 0, ty0 = 0, tx0 = 0;
@@ -1726,12 +1732,18 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad3_bf16_kernel(const seg
   auto issue_piece = [&](int g, char* buf, const seg3d_bf16* xbase, const seg3d_bf16* ybase, int faces) {
     const int p = wave + 4 * g;                          // every wave issues all NG pieces (counted vmcnt waits)
     const seg3d_bf16* base = p < XPC ? xbase : ybase;    // uniform
-    const void* src = (pflag[g] & faces) ? (const void*)seg3d_zero16 : (const void*)(base + prel[g]);
+    bool pad = (pflag[g] & faces) != 0;
+    if (IRR) {   // (faces only carries bit 6 here: the coordinate test covers halo faces and the overhang alike)
+      const int gz = tz0 + (pcoord[g] & 255) - 1, gy = ty0 + ((pcoord[g] >> 8) & 255) - 1, gx = tx0 + (pcoord[g] >> 16) - 1;
+      pad = pad || (unsigned)gz >= (unsigned)D || (unsigned)gy >= (unsigned)H || (unsigned)gx >= (unsigned)W;
+    }
+    const void* src = pad ? (const void*)seg3d_zero16 : (const void*)(base + prel[g]);
     seg3d_glds16(reinterpret_cast<const float*>(src), reinterpret_cast<float*>(buf + p * 1024));
   };
   auto tile_sources = [&](const seg3d_bf16*& xbase, const seg3d_bf16*& ybase, int& faces) {
-    faces = 64 | (tz0 == 0 ? 1 : 0) | (tz0 + TZ >= D ? 2 : 0) | (ty0 == 0 ? 4 : 0) | (ty0 + TY >= H ? 8 : 0) |
-            (tx0 == 0 ? 16 : 0) | (tx0 + TX >= W ? 32 : 0);
+    faces = IRR ? 64
+                : 64 | (tz0 == 0 ? 1 : 0) | (tz0 + TZ >= D ? 2 : 0) | (ty0 == 0 ? 4 : 0) | (ty0 + TY >= H ? 8 : 0) |
+                      (tx0 == 0 ? 16 : 0) | (tx0 + TX >= W ? 32 : 0);
     const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
     xbase = x + origin * Cin;
     ybase = dy + origin * Cout;
@@ -2033,9 +2045,12 @@ static Seg3dWgrad16Plan seg3d_wgrad16_plan(int N, int D, int H, int W, int Cin, 
     const char* e = getenv("SEG3D_WGRAD_BF16_MFMA");   // 0: always the register-staged kernel (measurement switch)
     v3 = (e && e[0] == '0') ? 0 : 1;
   }
-  if (!v3 || (Cin & 7) || (Cout & 7) || D % 4 || H % 4 || W % 4) return p;
-  const int tx = (W % 8 == 0) ? 8 : 4;
-  const i64 ntiles = (i64)N * (D / 4) * (H / 4) * (W / tx);
+  if (!v3 || (Cin & 7) || (Cout & 7)) return p;
+  // tile 4x4x8 unless 4x4x4 wastes fewer voxels (levels that are multiples of 4 but not of 8, e.g. 12^3)
+  const i64 vol8 = (i64)seg3d_cdiv(D, 4) * seg3d_cdiv(H, 4) * seg3d_cdiv(W, 8) * 128;
+  const i64 vol4 = (i64)seg3d_cdiv(D, 4) * seg3d_cdiv(H, 4) * seg3d_cdiv(W, 4) * 64;
+  const int tx = (vol4 < vol8) ? 4 : 8;
+  const i64 ntiles = (i64)N * seg3d_cdiv(D, 4) * seg3d_cdiv(H, 4) * seg3d_cdiv(W, tx);
   if (ntiles >= SEG3D_FDIV_MAX) return p;
   p.version = 3;
   p.tx = tx;
@@ -2051,15 +2066,15 @@ extern "C" long long seg3d_conv3d_k3_bf16_wgrad_workspace_floats(int N, int D, i
   return (long long)seg3d_wgrad16_plan(N, D, H, W, Cin, Cout).slabs * npairs * 27 * 1024;
 }
 
-template <int TX>
+template <int TX, bool IRR>
 static int launch_wgrad3(const void* x, const void* dy, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
                          int slabs, hipStream_t s) {
   constexpr int TZ = 4, TY = 4;
-  const int ntz = D / TZ, nty = H / TY, ntx = W / TX;
+  const int ntz = seg3d_cdiv(D, TZ), nty = seg3d_cdiv(H, TY), ntx = seg3d_cdiv(W, TX);
   const int ntiles = N * ntz * nty * ntx;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad3_bf16_kernel<TZ, TY, TX>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad3_bf16_kernel<TZ, TY, TX, IRR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     if (e != hipSuccess) {
       seg3d_set_error("conv3d_k3_wgrad3_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -2070,7 +2085,7 @@ static int launch_wgrad3(const void* x, const void* dy, float* workspace, int N,
   const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
   constexpr int NVH = (TZ + 2) * (TY + 2) * (TX + 2), MTV = TZ * TY * TX;
   const size_t lds = (size_t)SEG3D_WG3_NBUF * ((((NVH + 15) / 16) + MTV / 16 + 3) / 4) * 4 * 1024;
-  hipLaunchKernelGGL((conv3d_k3_wgrad3_bf16_kernel<TZ, TY, TX>), dim3((unsigned)(slabs * CIB32 * COB32)), dim3(256), lds, s,
+  hipLaunchKernelGGL((conv3d_k3_wgrad3_bf16_kernel<TZ, TY, TX, IRR>), dim3((unsigned)(slabs * CIB32 * COB32)), dim3(256), lds, s,
                      reinterpret_cast<const seg3d_bf16*>(x), reinterpret_cast<const seg3d_bf16*>(dy), workspace, N, D, H, W,
                      Cin, Cout, ntz, nty, ntx, ntiles, slabs, COB32);
   return SEG3D_OK;
@@ -2090,8 +2105,14 @@ extern "C" int seg3d_conv3d_k3_bf16_wgrad(const void* x, const void* dy, float* 
   const int slabs = plan.slabs;
   hipStream_t s = (hipStream_t)stream;
   if (plan.version == 3) {
-    const int rc = plan.tx == 8 ? launch_wgrad3<8>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s)
-                                : launch_wgrad3<4>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
+    const bool irr = D % 4 || H % 4 || W % plan.tx;
+    int rc;
+    if (irr)
+      rc = plan.tx == 8 ? launch_wgrad3<8, true>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s)
+                        : launch_wgrad3<4, true>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
+    else
+      rc = plan.tx == 8 ? launch_wgrad3<8, false>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s)
+                        : launch_wgrad3<4, false>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
     if (rc != SEG3D_OK) return rc;
   } else {
     const int ntz = seg3d_cdiv(D, SEG3D_WG_TZ), nty = seg3d_cdiv(H, SEG3D_WG_TY), ntx = seg3d_cdiv(W, SEG3D_WG_TX);

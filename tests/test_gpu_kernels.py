@@ -220,12 +220,14 @@ def test_conv3d_k3_bf16_out_bf16_is_rounded_fp32(hip_device, shape):
 
 
 @pytest.mark.parametrize('shape', [(1, 32, 32, 8, 8, 16), (2, 64, 32, 12, 12, 12), (1, 16, 48, 4, 8, 8), (2, 128, 128, 4, 4, 8),
-                                   (1, 32, 32, 6, 6, 6), (1, 32, 16, 5, 8, 8), (4, 32, 32, 16, 16, 32)])
+                                   (1, 32, 32, 6, 6, 6), (1, 32, 16, 5, 8, 8), (4, 32, 32, 16, 16, 32), (2, 64, 64, 7, 9, 10),
+                                   (4, 256, 256, 6, 6, 6), (1, 16, 16, 3, 3, 3), (1, 12, 20, 4, 8, 8)])
 @pytest.mark.parametrize('accumulate', [False, True])
 def test_conv3d_k3_bf16_wgrad(hip_device, shape, accumulate):
     """bf16 weight gradient (bf16 x and dy, fp32 dw): equals the exact weight gradient of the bf16-rounded operands to
-    fp32 accumulation error -- the bf16-MFMA kernel with transposing LDS reads on tile-multiple levels, the register-staged
-    fallback elsewhere; `accumulate` adds into an existing gradient"""
+    fp32 accumulation error -- the bf16-MFMA kernel with transposing LDS reads (tiles inside the volume and tiles that
+    stick out of it), the register-staged fallback for channel counts that are not multiples of 8; `accumulate` adds into
+    an existing gradient"""
     from segmentation3d import _ops, _engine as E
     N, Cin, Cout, D, H, W = shape
     x = _t(51, 'wx', (N, Cin, D, H, W)).bfloat16()

@@ -116,11 +116,13 @@ int seg3d_conv3d_k3_bf16_fwd(const void* x_bf16, const void* wp_bf16, const floa
 long long seg3d_conv3d_k3_bf16_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_bf16_wgrad(const void* x_bf16, const void* dy_bf16, float* dw, float* workspace, int N, int D, int H,
                                int W, int Cin, int Cout, int accumulate, void* stream);
-int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp_mfma, const float* bias, void* y, float* stats_partial,
-                               int N, int Do, int Ho, int Wo, int Cin, int Cout, int out_bf16, void* stream);
-int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp_mfma, const float* bias, void* y,
+/* w_bf16 = 1: wp is a seg3d_pack_weights_mfma_bf16(T = 8) image and the kernel runs the bf16 MFMA (Cin % 16 == 0);
+ * w_bf16 = 0: fp32 image, the bf16 input is widened while staging */
+int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const void* wp_mfma, const float* bias, void* y, float* stats_partial,
+                               int N, int Do, int Ho, int Wo, int Cin, int Cout, int out_bf16, int w_bf16, void* stream);
+int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const void* wp_mfma, const float* bias, void* y,
                                 float* stats_partial, int N, int Di, int Hi, int Wi, int Cin, int Cout, int out_bf16,
-                                void* stream);
+                                int w_bf16, void* stream);
 int seg3d_k2_bf16_wgrad(const void* P_bf16, const void* Q_bf16, float* dw, float* workspace, int N, int Dq, int Hq, int Wq,
                         int CA, int CB, long long sa, long long sb, int accumulate, void* stream);
 int seg3d_conv3d_k3_thin_out_bf16_fwd(const void* x_bf16, const float* wq, const float* bias, float* y,

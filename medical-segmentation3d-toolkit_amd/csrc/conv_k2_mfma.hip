@@ -53,9 +53,47 @@ static K2Tile k2_pick_tile(int D, int H, int W) {
 // ---------------------------------------------------------------------------------------------------------------
 // gather: output tile TZ x TY x TX (<= 128 voxels), input tile 2TZ x 2TY x 2TX staged 8 channels at a time
 // ---------------------------------------------------------------------------------------------------------------
-// XBF: the input tensor is bf16 (bf16 mode); it is widened to fp32 when the staged chunk is written to LDS, the
-// weights, the fp32 MFMAs and the fp32 output are the same.
-template <bool XBF, bool OUT_BF = false>
+// Input / arithmetic mode of the gather and scatter kernels:
+//   0  fp32 input, fp32 weight image, four v_mfma_f32_32x32x2_f32 per tap and 8-channel chunk
+//   1  bf16 input widened to fp32 when the staged chunk is written to LDS; weights and MFMAs as in mode 0
+//   2  bf16 input AND bf16 weight image (seg3d_pack_weights_mfma_bf16, T = 8): the staged 16 bytes per (voxel, half) are
+//      8 bf16 channels, a chunk is 16 channels, one v_mfma_f32_32x32x16_bf16 per tap -- same LDS bytes, 1/8 of the MFMA
+//      cycles (the fp32 forms of these layers were MFMA-bound: N = 16..32 output channels fill half an MFMA tile)
+typedef __bf16 k2_bf16x8 __attribute__((ext_vector_type(8)));
+template <int MODE> struct K2In;
+template <> struct K2In<0> {
+  typedef f32x4 raw;
+  static constexpr int CPH = 4;   // channels per (voxel, half) entry
+  static __device__ __forceinline__ raw load(const void* p, i64 e) { return Seg3dQuad<false>::load(p, e); }
+  static __device__ __forceinline__ f32x4 cvt(raw r) { return r; }
+};
+template <> struct K2In<1> {
+  typedef uint2 raw;
+  static constexpr int CPH = 4;
+  static __device__ __forceinline__ raw load(const void* p, i64 e) { return Seg3dQuad<true>::load(p, e); }
+  static __device__ __forceinline__ f32x4 cvt(raw r) { return Seg3dQuad<true>::cvt(r); }
+};
+template <> struct K2In<2> {
+  typedef f32x4 raw;              // 16 raw bytes = 8 bf16 channels
+  static constexpr int CPH = 8;
+  static __device__ __forceinline__ raw load(const void* p, i64 e) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const seg3d_bf16*>(p) + e);
+  }
+  static __device__ __forceinline__ f32x4 cvt(raw r) { return r; }
+};
+template <int MODE>
+__device__ __forceinline__ f32x16 k2_mfma_step(f32x4 bw, f32x4 av, f32x16 acc) {
+  if constexpr (MODE == 2) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(k2_bf16x8, bw), __builtin_bit_cast(k2_bf16x8, av), acc,
+                                                   0, 0, 0);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[r], av[r], acc, 0, 0, 0);
+    return acc;
+  }
+}
+
+template <int MODE, bool OUT_BF = false>
 __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __restrict__ x,
                                                                     const float* __restrict__ wp,
                                                                     const float* __restrict__ bias, float* __restrict__ y,
@@ -74,7 +112,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int CIB = (Cin + 7) >> 3;
+  constexpr int CPH = K2In<MODE>::CPH, CPC = 2 * CPH;   // channels per half / per chunk
+  const int CIB = (Cin + CPC - 1) / CPC;
   const int cob = blockIdx.y;
   // index decoding by float reciprocal (seg3d_fdiv): a workgroup owns ONE tile, so this prologue is paid per tile
   const float rHX = 1.0f / (float)HX, rHY = 1.0f / (float)HY, rTX = 1.0f / (float)TX, rTY = 1.0f / (float)TY;
@@ -101,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
       const int hz = seg3d_fdiv(t, rHY);
       const int hy = t - hz * HY;
       const int gz = 2 * z0 + hz, gy = 2 * y0 + hy, gx = 2 * x0 + hx;
-      if (gz < Di && gy < Hi && gx < Wi) goff[e] = (((n * Di + gz) * Hi + gy) * Wi + gx) * Cin + hh * 4;
+      if (gz < Di && gy < Hi && gx < Wi) goff[e] = (((n * Di + gz) * Hi + gy) * Wi + gx) * Cin + hh * CPH;
     }
   }
   for (int idx = tid; idx < MT; idx += 256) {
@@ -133,28 +172,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
   // Register-prefetch pipeline: all loads of chunk c+1 are issued back to back (branch-free, clamped addresses; the
   // zero-select happens at the LDS store) before the MFMAs of chunk c, so a workgroup keeps 32 KB in flight -- at the
   // top level this kernel is HBM-bound and a load consumed right where it is issued serialises on memory latency.
-  typename Seg3dQuad<XBF>::raw xst[K2_MAXE];
+  typename K2In<MODE>::raw xst[K2_MAXE];
   f32x4 wst[2];
   auto load_chunk = [&](int cib) {
-    const bool half_ok = cib * 8 + hh * 4 < Cin;
+    const bool half_ok = cib * CPC + hh * CPH < Cin;
 #pragma unroll
     for (int e = 0; e < K2_MAXE; ++e) {
       const bool ok = goff[e] >= 0 && half_ok;
-      xst[e] = Seg3dQuad<XBF>::load(x, ok ? (i64)goff[e] + cib * 8 : (i64)0);
+      xst[e] = K2In<MODE>::load(x, ok ? (i64)goff[e] + cib * CPC : (i64)0);
     }
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * K2_W_CHUNK);
 #pragma unroll
     for (int k = 0; k < 2; ++k) wst[k] = wsrc[tid + k * 256];
   };
   auto store_chunk = [&](int cib) {
-    const bool half_ok = cib * 8 + hh * 4 < Cin;
+    const bool half_ok = cib * CPC + hh * CPH < Cin;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < K2_MAXE; ++e) {
       const int eidx = tid + e * 256;
       if (eidx < 2 * NV)
         *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) =
-            (goff[e] >= 0 && half_ok) ? Seg3dQuad<XBF>::cvt(xst[e]) : zero;
+            (goff[e] >= 0 && half_ok) ? K2In<MODE>::cvt(xst[e]) : zero;
     }
     f32x4* wdst = reinterpret_cast<f32x4*>(ws);
 #pragma unroll
@@ -172,9 +211,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
       const int tapoff = ((kz * HY + ky) * HX + kx) * 4;
       const f32x4 bw = *reinterpret_cast<const f32x4*>(ws + tap * 256 + bbase);
       const f32x4 av = *reinterpret_cast<const f32x4*>(xs + abase + tapoff);
-#pragma unroll
       // A = weights, B = voxels: D[co][voxel] -- a lane owns voxel (lane & 31) and channels 8 g + 4 (lane >> 5) + c
-      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[r], av[r], acc, 0, 0, 0);
+      acc = k2_mfma_step<MODE>(bw, av, acc);
     }
   }
 
@@ -235,15 +273,17 @@ static int k2_gather_launch(const void* x, int x_bf16, const float* wp, const fl
   const size_t lds = (size_t)(8 * 8 * mt + K2_W_CHUNK + ((mt + 3) & ~3)) * 4;
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "2x2x2 stride-2 MFMA kernels: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
-  if (x_bf16 && out_bf16)
-    hipLaunchKernelGGL((conv3d_k2s2_mfma_kernel<true, true>), grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y,
-                       stats, N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
-  else if (x_bf16)
-    hipLaunchKernelGGL(conv3d_k2s2_mfma_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, stats, N,
-                       Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
-  else
-    hipLaunchKernelGGL(conv3d_k2s2_mfma_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, stats, N,
-                       Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
+  // x_bf16: 0 = fp32 input, 1 = bf16 input widened while staging (fp32 weight image), 2 = bf16 input + bf16 weight image
+  SEG3D_REQUIRE(x_bf16 != 2 || (Cin % 16) == 0, "seg3d_conv3d_k2s2_bf16_fwd: the bf16 weight image needs Cin %% 16 == 0");
+#define K2_GATHER(MODE_, OB_)                                                                                        \
+  hipLaunchKernelGGL((conv3d_k2s2_mfma_kernel<MODE_, OB_>), grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, stats, \
+                     N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx)
+  if (x_bf16 == 2 && out_bf16) K2_GATHER(2, true);
+  else if (x_bf16 == 2) K2_GATHER(2, false);
+  else if (x_bf16 && out_bf16) K2_GATHER(1, true);
+  else if (x_bf16) K2_GATHER(1, false);
+  else K2_GATHER(0, false);
+#undef K2_GATHER
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k2s2_mfma_fwd");
   return SEG3D_OK;
 }
@@ -253,17 +293,19 @@ extern "C" int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp, const
   return k2_gather_launch(x, 0, wp, bias, y, stats, N, Do, Ho, Wo, Cin, Cout, stream);
 }
 
-// bf16 mode: x is bf16 ([N][2Do][2Ho][2Wo][Cin]); weights (fp32 pack), bias, y and statistics as above
-extern "C" int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp, const float* bias, void* y, float* stats,
-                                          int N, int Do, int Ho, int Wo, int Cin, int Cout, int out_bf16, void* stream) {
-  return k2_gather_launch(x_bf16, 1, wp, bias, reinterpret_cast<float*>(y), stats, N, Do, Ho, Wo, Cin, Cout, stream,
-                          out_bf16);
+// bf16 mode: x is bf16 ([N][2Do][2Ho][2Wo][Cin]); wp = fp32 image (w_bf16 = 0) or seg3d_pack_weights_mfma_bf16 image
+// (w_bf16 = 1, Cin % 16 == 0: bf16 MFMA); bias, statistics fp32; y fp32 or bf16 (out_bf16)
+extern "C" int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const void* wp, const float* bias, void* y, float* stats,
+                                          int N, int Do, int Ho, int Wo, int Cin, int Cout, int out_bf16, int w_bf16,
+                                          void* stream) {
+  return k2_gather_launch(x_bf16, w_bf16 ? 2 : 1, reinterpret_cast<const float*>(wp), bias, reinterpret_cast<float*>(y),
+                          stats, N, Do, Ho, Wo, Cin, Cout, stream, out_bf16);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // scatter: input tile TZ x TY x TX (<= 128 voxels), one accumulator per tap, output cell 2^3 per input voxel
 // ---------------------------------------------------------------------------------------------------------------
-template <bool XBF, bool OUT_BF = false>
+template <int MODE, bool OUT_BF = false>
 __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* __restrict__ x,
                                                                      const float* __restrict__ wp,
                                                                      const float* __restrict__ bias,
@@ -278,7 +320,8 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int CIB = (Cin + 7) >> 3;
+  constexpr int CPH = K2In<MODE>::CPH, CPC = 2 * CPH;
+  const int CIB = (Cin + CPC - 1) / CPC;
   const int cob = blockIdx.y;
   int b = blockIdx.x;
   int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
@@ -300,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
     const int ty = t - tz * TY;
     const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
     if (gz < Di && gy < Hi && gx < Wi) {
-      goff = (((n * Di + gz) * Hi + gy) * Wi + gx) * Cin + hh * 4;
+      goff = (((n * Di + gz) * Hi + gy) * Wi + gx) * Cin + hh * CPH;
       if (hh == 0) obase[sv] = (((n * 2 * Di + 2 * gz) * Ho + 2 * gy) * Wo + 2 * gx);
     } else if (hh == 0) {
       obase[sv] = -1;
@@ -315,11 +358,11 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   // register prefetch of the next chunk (one float4 of x + two of weights per thread) behind the 32 MFMAs of this one
-  typename Seg3dQuad<XBF>::raw xst;
+  typename K2In<MODE>::raw xst;
   f32x4 wst[2];
   auto load_chunk = [&](int cib) {
-    const bool ok = goff >= 0 && cib * 8 + hh * 4 < Cin;
-    xst = Seg3dQuad<XBF>::load(x, ok ? (i64)goff + cib * 8 : (i64)0);
+    const bool ok = goff >= 0 && cib * CPC + hh * CPH < Cin;
+    xst = K2In<MODE>::load(x, ok ? (i64)goff + cib * CPC : (i64)0);
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * K2_W_CHUNK);
 #pragma unroll
     for (int k = 0; k < 2; ++k) wst[k] = wsrc[tid + k * 256];
@@ -330,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
     if (sv < MT) {
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(xs + (hh * MT + sv) * 4) =
-          (goff >= 0 && cib * 8 + hh * 4 < Cin) ? Seg3dQuad<XBF>::cvt(xst) : zero;
+          (goff >= 0 && cib * CPC + hh * CPH < Cin) ? K2In<MODE>::cvt(xst) : zero;
     }
     {
       f32x4* wdst = reinterpret_cast<f32x4*>(ws);
@@ -344,8 +387,7 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
 #pragma unroll
     for (int tap = 0; tap < 8; ++tap) {
       const f32x4 bw = *reinterpret_cast<const f32x4*>(ws + tap * 256 + bbase);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[r], av[r], acc[tap], 0, 0, 0);
+      acc[tap] = k2_mfma_step<MODE>(bw, av, acc[tap]);
     }
   }
 
@@ -438,15 +480,16 @@ static int k2_scatter_launch(const void* x, int x_bf16, const float* wp, const f
   const int ntz = seg3d_cdiv(Di, t.tz), nty = seg3d_cdiv(Hi, t.ty), ntx = seg3d_cdiv(Wi, t.tx);
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "2x2x2 stride-2 MFMA kernels: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
-  if (x_bf16 && out_bf16)
-    hipLaunchKernelGGL((convT3d_k2s2_mfma_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y,
-                       stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
-  else if (x_bf16)
-    hipLaunchKernelGGL(convT3d_k2s2_mfma_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, stats, N,
-                       Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
-  else
-    hipLaunchKernelGGL(convT3d_k2s2_mfma_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, stats, N,
-                       Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx);
+  SEG3D_REQUIRE(x_bf16 != 2 || (Cin % 16) == 0, "seg3d_convT3d_k2s2_bf16_fwd: the bf16 weight image needs Cin %% 16 == 0");
+#define K2_SCATTER(MODE_, OB_)                                                                                       \
+  hipLaunchKernelGGL((convT3d_k2s2_mfma_kernel<MODE_, OB_>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, stats, \
+                     N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx)
+  if (x_bf16 == 2 && out_bf16) K2_SCATTER(2, true);
+  else if (x_bf16 == 2) K2_SCATTER(2, false);
+  else if (x_bf16 && out_bf16) K2_SCATTER(1, true);
+  else if (x_bf16) K2_SCATTER(1, false);
+  else K2_SCATTER(0, false);
+#undef K2_SCATTER
   SEG3D_LAUNCH_CHECK("seg3d_convT3d_k2s2_mfma_fwd");
   return SEG3D_OK;
 }
@@ -456,10 +499,11 @@ extern "C" int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp, cons
   return k2_scatter_launch(x, 0, wp, bias, y, stats, N, Di, Hi, Wi, Cin, Cout, stream);
 }
 
-extern "C" int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const float* wp, const float* bias, void* y, float* stats,
-                                           int N, int Di, int Hi, int Wi, int Cin, int Cout, int out_bf16, void* stream) {
-  return k2_scatter_launch(x_bf16, 1, wp, bias, reinterpret_cast<float*>(y), stats, N, Di, Hi, Wi, Cin, Cout, stream,
-                           out_bf16);
+extern "C" int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const void* wp, const float* bias, void* y, float* stats,
+                                           int N, int Di, int Hi, int Wi, int Cin, int Cout, int out_bf16, int w_bf16,
+                                           void* stream) {
+  return k2_scatter_launch(x_bf16, w_bf16 ? 2 : 1, reinterpret_cast<const float*>(wp), bias, reinterpret_cast<float*>(y),
+                           stats, N, Di, Hi, Wi, Cin, Cout, stream, out_bf16);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

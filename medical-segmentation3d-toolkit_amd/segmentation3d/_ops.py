@@ -31,6 +31,8 @@ _ACT_BF16 = [False]
 # bf16 mode, second switch: the raw conv output y (read by GroupNorm forward and backward, saved for backward) is bf16 as
 # well -- rounded by the conv epilogue AFTER the fp32 (sum, sumsq) statistics are taken.  SEG3D_BF16_Y=0 keeps y in fp32.
 BF16_CONV_OUTPUT = os.environ.get('SEG3D_BF16_Y', '1') != '0'
+# bf16 mode, stride-2 layers: bf16 weight images + bf16 MFMA (SEG3D_K2_BF16_MFMA=0: fp32 images, input widened while staging)
+K2_BF16_MFMA = os.environ.get('SEG3D_K2_BF16_MFMA', '1') != '0'
 
 
 def set_activation_dtype(name):
@@ -312,13 +314,14 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
 def _k2_gather(xn, w, bias, y, A, B, sa, sb, want_stats):
     """y[v][b] = bias[b] + sum_{t,a} x[2v + t][a] W(a,b,t) on the matrix cores; y preallocated [N,Do,Ho,Wo,B]"""
     N, Do, Ho, Wo, _ = y.shape
-    wp = _pack_mfma(w, A, B, 8, sa, sb)
+    w16 = _is_bf16(xn) and A % 16 == 0 and K2_BF16_MFMA    # bf16 weight image -> the kernel's bf16-MFMA mode
+    wp = _pack_mfma(w, A, B, 8, sa, sb, bf16=w16)
     stats = None
     if want_stats:
         stats = _empty((N, E.query('seg3d_conv3d_k2s2_mfma_stats_count', Do, Ho, Wo, B), 2), xn)
     if _is_bf16(xn):
         E.call('seg3d_conv3d_k2s2_bf16_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho, Wo, A, B,
-               int(_is_bf16(y)), E.stream_ptr())
+               int(_is_bf16(y)), int(w16), E.stream_ptr())
         return y, stats
     E.call('seg3d_conv3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho, Wo, A, B,
            E.stream_ptr())
@@ -328,13 +331,14 @@ def _k2_gather(xn, w, bias, y, A, B, sa, sb, want_stats):
 def _k2_scatter(xn, w, bias, y, A, B, sa, sb, want_stats):
     """y[2i + t][b] = bias[b] + sum_a x[i][a] W(a,b,t) on the matrix cores; y preallocated [N,2D,2H,2W,B]"""
     N, D, H, W_, _ = xn.shape
-    wp = _pack_mfma(w, A, B, 8, sa, sb)
+    w16 = _is_bf16(xn) and A % 16 == 0 and K2_BF16_MFMA
+    wp = _pack_mfma(w, A, B, 8, sa, sb, bf16=w16)
     stats = None
     if want_stats:
         stats = _empty((N, E.query('seg3d_convT3d_k2s2_mfma_stats_count', D, H, W_, B), 2), xn)
     if _is_bf16(xn):
         E.call('seg3d_convT3d_k2s2_bf16_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
-               int(_is_bf16(y)), E.stream_ptr())
+               int(_is_bf16(y)), int(w16), E.stream_ptr())
         return y, stats
     E.call('seg3d_convT3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
            E.stream_ptr())

@@ -49,7 +49,7 @@ def test_fused_unit_bf16_exact_operands(hip_device, kind, cin, cout, shape, resi
     be = torch.from_numpy(detgen.normal(75, 'u/be', (cout,), std=0.3))
     # exact expression in double on the CPU
     xd = x.double().requires_grad_(True)
-    wq = (_bf(w) if kind == 'k3' else w.double()).requires_grad_(True)   # only the k3 MFMA kernel rounds its weights
+    wq = _bf(w).requires_grad_(True)   # the bf16 MFMA kernels (3x3x3 and stride-2, Cin % 16 == 0) use bf16 weight images
     if kind == 'k3':
         y = F.conv3d(xd, wq, b.double(), padding=1)
     elif kind == 'k2s2':

@@ -660,6 +660,177 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const void* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// pair-reduce weight gradient on the bf16 matrix cores (bf16 mode): the tiles stay bf16 in LDS ([voxel][32 channels],
+// 64-byte rows, written by the same register-staged pipeline without widening), and ds_read_b64_tr_b16 -- the transposing
+// LDS read, four rows with independent addresses per 16-lane group -- turns them into the K-major MFMA operands
+// (8 consecutive Q voxels of one channel per lane; for P the rows are the stride-2 positions 2v + t of those voxels).
+// 4 K-steps x 2 taps per wave = 8 v_mfma_f32_32x32x16_bf16 per tile instead of 64 fp32 MFMAs: the kernel is bound by its
+// tile loads.  Same partial layout and reduce kernel as k2_wgrad_mfma_kernel.  Needs CA % 8 == 0 and CB % 8 == 0.
+// ---------------------------------------------------------------------------------------------------------------
+typedef short k2_s16x4 __attribute__((ext_vector_type(4)));
+#define K2_TR_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+__device__ __forceinline__ k2_bf16x8 k2_tr_join(k2_s16x4 lo, k2_s16x4 hi) {
+  return __builtin_bit_cast(k2_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256, 2) void k2_wgrad_bf16_mfma_kernel(const seg3d_bf16* __restrict__ P,
+                                                                      const seg3d_bf16* __restrict__ Q,
+                                                                      float* __restrict__ part, int N, int Dq, int Hq,
+                                                                      int Wq, int CA, int CB, int ntz, int nty, int ntx,
+                                                                      int ntiles, int BB32) {
+  __shared__ __attribute__((aligned(16))) seg3d_bf16 ps[K2W_NV * 32];   // 32 KB
+  __shared__ __attribute__((aligned(16))) seg3d_bf16 qs[K2W_MT * 32];   //  4 KB
+  const int Dp = 2 * Dq, Hp = 2 * Hq, Wp = 2 * Wq;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int ab = blockIdx.y / BB32, bb = blockIdx.y % BB32;
+  const int a0 = ab * 32, b0 = bb * 32;
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // staging: entry = (voxel, 8-channel quarter); 16 bytes per entry
+  const int q8 = tid & 3;
+  const bool pq_ok = a0 + 8 * q8 < CA;
+  const bool qq_ok = b0 + 8 * q8 < CB;
+  constexpr int PE = (K2W_NV * 4) / 256, QE = (K2W_MT * 4) / 256;   // 8, 1
+  f32x4 pst[PE], qst[QE];
+  unsigned okmask = 0;
+  int prel[PE], qrel[QE];
+#pragma unroll
+  for (int e = 0; e < PE; ++e) {
+    const int v = (tid + e * 256) >> 2;
+    const int hx = v % K2W_HX, hy = (v / K2W_HX) % K2W_HY, hz = v / (K2W_HX * K2W_HY);
+    prel[e] = ((hz * Hp + hy) * Wp + hx) * CA + a0 + 8 * q8;
+  }
+#pragma unroll
+  for (int e = 0; e < QE; ++e) {
+    const int v = (tid + e * 256) >> 2;
+    const int tx = v % K2W_TX, ty = (v / K2W_TX) % K2W_TY, tz = v / (K2W_TX * K2W_TY);
+    qrel[e] = ((tz * Hq + ty) * Wq + tx) * CB + b0 + 8 * q8;
+  }
+  const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz;
+  auto ld16 = [](const seg3d_bf16* p, i64 e) { return *reinterpret_cast<const f32x4*>(p + e); };
+  auto load_tile = [&](int tile) {
+    int b = tile;
+    int qd = seg3d_fdiv(b, rNTX);
+    const int tix = b - qd * ntx; b = qd;
+    qd = seg3d_fdiv(b, rNTY);
+    const int tiy = b - qd * nty; b = qd;
+    qd = seg3d_fdiv(b, rNTZ);
+    const int tiz = b - qd * ntz;
+    const int n = qd;
+    const int z0 = tiz * K2W_TZ, y0 = tiy * K2W_TY, x0 = tix * K2W_TX;
+    if (z0 + K2W_TZ <= Dq && y0 + K2W_TY <= Hq && x0 + K2W_TX <= Wq) {  // whole tile inside the volume
+      const i64 pbase = ((((i64)n * Dp + 2 * z0) * Hp + 2 * y0) * Wp + 2 * x0) * CA;
+      const i64 qbase = ((((i64)n * Dq + z0) * Hq + y0) * Wq + x0) * CB;
+      const unsigned pm = pq_ok ? (1u << PE) - 1u : 0u, qm = qq_ok ? ((1u << QE) - 1u) << PE : 0u;
+#pragma unroll
+      for (int e = 0; e < PE; ++e) pst[e] = ld16(P, pq_ok ? pbase + prel[e] : (i64)0);
+#pragma unroll
+      for (int e = 0; e < QE; ++e) qst[e] = ld16(Q, qq_ok ? qbase + qrel[e] : (i64)0);
+      okmask = pm | qm;
+      return;
+    }
+    okmask = 0;
+#pragma unroll
+    for (int e = 0; e < PE; ++e) {
+      const int v = (tid + e * 256) >> 2;
+      const int hx = v % K2W_HX;
+      const int t = v / K2W_HX;
+      const int hy = t % K2W_HY;
+      const int hz = t / K2W_HY;
+      const int gz = 2 * z0 + hz, gy = 2 * y0 + hy, gx = 2 * x0 + hx;
+      const bool ok = pq_ok && gz < Dp && gy < Hp && gx < Wp;
+      pst[e] = ld16(P, ok ? ((((i64)n * Dp + gz) * Hp + gy) * Wp + gx) * CA + a0 + 8 * q8 : (i64)0);
+      okmask |= (ok ? 1u : 0u) << e;
+    }
+#pragma unroll
+    for (int e = 0; e < QE; ++e) {
+      const int v = (tid + e * 256) >> 2;
+      const int tx = v % K2W_TX;
+      const int t = v / K2W_TX;
+      const int ty = t % K2W_TY;
+      const int tz = t / K2W_TY;
+      const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
+      const bool ok = qq_ok && gz < Dq && gy < Hq && gx < Wq;
+      qst[e] = ld16(Q, ok ? ((((i64)n * Dq + gz) * Hq + gy) * Wq + gx) * CB + b0 + 8 * q8 : (i64)0);
+      okmask |= (ok ? 1u : 0u) << (PE + e);
+    }
+  };
+  auto store_tile = [&]() {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < PE; ++e)
+      *reinterpret_cast<f32x4*>(ps + ((tid + e * 256) >> 2) * 32 + 8 * q8) = ((okmask >> e) & 1u) ? pst[e] : zero;
+#pragma unroll
+    for (int e = 0; e < QE; ++e)
+      *reinterpret_cast<f32x4*>(qs + ((tid + e * 256) >> 2) * 32 + 8 * q8) = ((okmask >> (PE + e)) & 1u) ? qst[e] : zero;
+  };
+  // transposing-read addresses (bytes): lane 4q + p of a 16-lane group supplies row q, channels 4p..4p+3 of the group's 16
+  const int l16 = lane & 15, rq = l16 >> 2, rp = l16 & 3;
+  const int colb = (16 * ((lane >> 4) & 1) + 4 * rp) * 2;
+  const int r0 = 8 * lh + rq, r1 = r0 + 4;
+  const unsigned qbase_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)qs);
+  const unsigned pbase_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)ps);
+  const unsigned qa0 = qbase_lds + r0 * 64 + colb, qa1 = qbase_lds + r1 * 64 + colb;
+  // P row of Q voxel v = 16 s + r, tap (kz, ky, kx): ((2 tz + kz) HY + 2 ty + ky) HX + 2 tx + kx with tz = s >> 1,
+  // ty = 2 (s & 1) + (r >> 3), tx = r & 7  ->  per-lane part below, per-(step, tap) part as the asm offset
+  unsigned pa0[2], pa1[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int tap = wave * 2 + j;
+    const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
+    const int tapb = ((kz * K2W_HY + ky) * K2W_HX + kx) * 64;
+    pa0[j] = pbase_lds + tapb + ((2 * (r0 >> 3)) * K2W_HX + 2 * (r0 & 7)) * 64 + colb;
+    pa1[j] = pbase_lds + tapb + ((2 * (r1 >> 3)) * K2W_HX + 2 * (r1 & 7)) * 64 + colb;
+  }
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    k2_s16x4 blo[4], bhi[4], alo[4][2], ahi[4][2];
+    // step s: Q rows 16 s .. 16 s + 15; P offset of the step: ((2 (s >> 1)) HY + 4 (s & 1)) HX rows
+#define K2W3_POFF(S) ((((2 * ((S) >> 1)) * K2W_HY + 4 * ((S) & 1)) * K2W_HX) * 64)
+#define K2W3_STEP_READS(S)                                   \
+  K2_TR_READ(blo[S], qa0, (S) * 16 * 64);                    \
+  K2_TR_READ(bhi[S], qa1, (S) * 16 * 64);                    \
+  K2_TR_READ(alo[S][0], pa0[0], K2W3_POFF(S));               \
+  K2_TR_READ(ahi[S][0], pa1[0], K2W3_POFF(S));               \
+  K2_TR_READ(alo[S][1], pa0[1], K2W3_POFF(S));               \
+  K2_TR_READ(ahi[S][1], pa1[1], K2W3_POFF(S));
+    K2W3_STEP_READS(0) K2W3_STEP_READS(1) K2W3_STEP_READS(2) K2W3_STEP_READS(3)
+#undef K2W3_STEP_READS
+#undef K2W3_POFF
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]), "+v"(blo[3]),
+                   "+v"(bhi[3]), "+v"(alo[0][0]), "+v"(ahi[0][0]), "+v"(alo[0][1]), "+v"(ahi[0][1]), "+v"(alo[1][0]),
+                   "+v"(ahi[1][0]), "+v"(alo[1][1]), "+v"(ahi[1][1]));
+    asm volatile("" : "+v"(alo[2][0]), "+v"(ahi[2][0]), "+v"(alo[2][1]), "+v"(ahi[2][1]), "+v"(alo[3][0]), "+v"(ahi[3][0]),
+                      "+v"(alo[3][1]), "+v"(ahi[3][1]));
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const k2_bf16x8 bop = k2_tr_join(blo[st], bhi[st]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2_tr_join(alo[st][j], ahi[st][j]), bop, acc[j], 0, 0, 0);
+    }
+  }
+  float* dst = part + ((i64)blockIdx.x * gridDim.y + blockIdx.y) * 8 * 1024;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int tap = wave * 2 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[tap * 1024 + k2_row(r, lh) * 32 + li] = acc[j][r];
+  }
+}
+
 // dw[a*sa + b*sb + t] = sum_slab part[slab][a/32][b/32][t][a%32][b%32]   (a = reduction-side channel, b = output channel)
 // 64 outputs per workgroup, 4 slab groups per output (coalesced reads of every slab), combined in a fixed order.
 __global__ __launch_bounds__(256) void k2_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int slabs, int A,
@@ -717,7 +888,16 @@ static int k2_wgrad_launch(const void* P, const void* Q, int bf16, float* dw, fl
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "seg3d_k2_mfma_wgrad: more than 2^22 tiles");
   const int slabs = k2_wgrad_slabs(N, Dq, Hq, Wq, npairs);
   hipStream_t s = (hipStream_t)stream;
-  if (bf16)
+  static int mf16 = -1;
+  if (mf16 < 0) {
+    const char* e = getenv("SEG3D_K2_WGRAD_BF16_MFMA");   // 0: widen the bf16 operands and use the fp32 MFMA kernel
+    mf16 = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (bf16 && mf16 && (CA & 7) == 0 && (CB & 7) == 0)
+    hipLaunchKernelGGL(k2_wgrad_bf16_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s,
+                       reinterpret_cast<const seg3d_bf16*>(P), reinterpret_cast<const seg3d_bf16*>(Q), workspace, N, Dq, Hq,
+                       Wq, CA, CB, ntz, nty, ntx, ntiles, BB32);
+  else if (bf16)
     hipLaunchKernelGGL(k2_wgrad_mfma_kernel<true>, dim3(slabs, npairs), dim3(256), 0, s, P, Q, workspace, N, Dq, Hq, Wq, CA,
                        CB, ntz, nty, ntx, ntiles, BB32);
   else

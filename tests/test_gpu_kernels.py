@@ -173,6 +173,34 @@ def test_conv3d_k3_bf16_fwd(hip_device, shape, with_addend):
            err_vs_fp32_conv=float((got - (F.conv3d(x.double(), w.double(), b.double(), padding=1) + (a.double() if with_addend else 0))).abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 32, 4, 8, 8), (1, 64, 16, 3, 5, 6), (2, 128, 256, 2, 4, 8), (1, 32, 32, 6, 6, 6),
+                                   (1, 24, 40, 2, 4, 8)])
+@pytest.mark.parametrize('transposed', [False, True])
+def test_k2_bf16_wgrad(hip_device, shape, transposed):
+    """weight gradient of the stride-2 2x2x2 conv / transposed conv on bf16 operands (bf16-MFMA kernel with transposing
+    LDS reads; channel counts that are not multiples of 8 take the widening kernel): equals the exact gradient of the
+    bf16-rounded operands to fp32 accumulation error"""
+    from segmentation3d import _ops
+    N, Cin, Cout, Dq, Hq, Wq = shape          # conv: x [N,Cin,2Dq,..] -> y [N,Cout,Dq,..]; transposed: x [N,Cin,Dq,..] -> 2x
+    if transposed:
+        x = _t(61, 'k2x', (N, Cin, Dq, Hq, Wq)).bfloat16()
+        dy = _t(62, 'k2dy', (N, Cout, 2 * Dq, 2 * Hq, 2 * Wq)).bfloat16()
+        w0 = torch.zeros(Cin, Cout, 2, 2, 2, dtype=torch.double, requires_grad=True)
+        F.conv_transpose3d(x.double(), w0, None, stride=2).backward(dy.double())
+        kind, wshape = 'convT', (Cin, Cout, 2, 2, 2)
+    else:
+        x = _t(61, 'k2x', (N, Cin, 2 * Dq, 2 * Hq, 2 * Wq)).bfloat16()
+        dy = _t(62, 'k2dy', (N, Cout, Dq, Hq, Wq)).bfloat16()
+        w0 = torch.zeros(Cout, Cin, 2, 2, 2, dtype=torch.double, requires_grad=True)
+        F.conv3d(x.double(), w0, None, stride=2).backward(dy.double())
+        kind, wshape = 'k2s2', (Cout, Cin, 2, 2, 2)
+    nd = lambda t: t.to(hip_device).permute(0, 2, 3, 4, 1).contiguous()
+    dw = _ops.conv_wgrad(nd(x), nd(dy), wshape, kind)
+    err = float((dw.double().cpu() - w0.grad).abs().max()) / float(w0.grad.abs().max())
+    report('bf16_k2wgrad_{}_{}x{}x{}x{}_{}_{}'.format(kind, N, Dq, Hq, Wq, Cin, Cout), rel_max=err)
+    assert err < 2e-5, err
+
+
 def test_bf16_multi_pack_equals_single_pack(hip_device):
     """PackedWeightCache.repack_all() refreshes every bf16 weight image with ONE launch (pack_mfma_bf16_multi_kernel,
     coalesced read / LDS transpose); the images equal those of the per-tensor pack kernel bit for bit, both weight

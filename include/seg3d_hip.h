@@ -148,6 +148,9 @@ int seg3d_pack_weights_thin_in(const float* w, float* wp, int CT, int B, long lo
 long long seg3d_conv3d_k3_thin_stats_count(int D, int H, int W, int Cout_blocks);
 int seg3d_conv3d_k3_thin_in_fwd(const float* x, const float* wp_thin, const float* bias, float* y, float* stats_partial,
                                 int N, int D, int H, int W, int CT, int Cout, void* stream);
+/* bf16 mode: y is bf16 storage (the stem's conv output, the head's data-gradient); everything else as above */
+int seg3d_conv3d_k3_thin_in_bf16out_fwd(const float* x, const float* wp_thin, const float* bias, void* y_bf16,
+                                        float* stats_partial, int N, int D, int H, int W, int CT, int Cout, void* stream);
 int seg3d_pack_weights_thin_out(const float* w, float* wq, int A, int B, int CO, long long sa, long long sb, int flip,
                                 void* stream);
 long long seg3d_conv3d_k3_thin_out_stats_count(int D, int H, int W);

@@ -76,8 +76,9 @@ __device__ __forceinline__ int thin_koff(int k) {  // LDS float offset of GEMM-k
   return t < 27 ? ((kz * TH_HY + ky) * TH_HX + kx) * CT + a : 0;
 }
 
-template <int CT>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_kernel(const float* __restrict__ x,
+// OUT_BF (bf16 mode): y is bf16 storage -- the stem's conv output and the head's data-gradient; statistics from fp32 values
+template <int CT, bool OUT_BF>
+__device__ __forceinline__ void conv3d_k3_thin_in_body(const float* __restrict__ x,
                                                                      const float* __restrict__ wp,
                                                                      const float* __restrict__ bias,
                                                                      float* __restrict__ y, float* __restrict__ stats,
@@ -169,7 +170,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_kernel(const float* 
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      if (ooff[m][r] >= 0) y[(i64)ooff[m][r]] = acc[m][r];
+      if (ooff[m][r] >= 0) {
+        if (OUT_BF) reinterpret_cast<seg3d_bf16*>(y)[(i64)ooff[m][r]] = seg3d_f2bf(acc[m][r]);
+        else y[(i64)ooff[m][r]] = acc[m][r];
+      }
   if (stats) {
     __syncthreads();
     block_sum_256<2>(s, xs);
@@ -183,37 +187,75 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_kernel(const float* 
   }
 }
 
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ wp,
+                                                                     const float* __restrict__ bias,
+                                                                     float* __restrict__ y, float* __restrict__ stats,
+                                                                     int N, int D, int H, int W, int Cout, int ntz,
+                                                                     int nty, int ntx) {
+  conv3d_k3_thin_in_body<CT, false>(x, wp, bias, y, stats, N, D, H, W, Cout, ntz, nty, ntx);
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_bf16out_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ wp,
+                                                                     const float* __restrict__ bias,
+                                                                     float* __restrict__ y, float* __restrict__ stats,
+                                                                     int N, int D, int H, int W, int Cout, int ntz,
+                                                                     int nty, int ntx) {
+  conv3d_k3_thin_in_body<CT, true>(x, wp, bias, y, stats, N, D, H, W, Cout, ntz, nty, ntx);
+}
+
 extern "C" long long seg3d_conv3d_k3_thin_stats_count(int D, int H, int W, int Cout_blocks) {
   return (long long)seg3d_cdiv(D, TH_TZ) * seg3d_cdiv(H, TH_TY) * seg3d_cdiv(W, TH_TX) * Cout_blocks;
 }
 
 template <int CT>
 static void launch_thin_in(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
-                           int W, int Cout, hipStream_t s) {
+                           int W, int Cout, hipStream_t s, int out_bf16) {
   const int ntz = seg3d_cdiv(D, TH_TZ), nty = seg3d_cdiv(H, TH_TY), ntx = seg3d_cdiv(W, TH_TX);
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
-  hipLaunchKernelGGL((conv3d_k3_thin_in_kernel<CT>), grid, dim3(256), 0, s, x, wp, bias, y, stats, N, D, H, W, Cout, ntz, nty,
-                     ntx);
+  if (out_bf16)
+    hipLaunchKernelGGL((conv3d_k3_thin_in_bf16out_kernel<CT>), grid, dim3(256), 0, s, x, wp, bias, y, stats, N, D, H, W, Cout,
+                       ntz, nty, ntx);
+  else
+    hipLaunchKernelGGL((conv3d_k3_thin_in_kernel<CT>), grid, dim3(256), 0, s, x, wp, bias, y, stats, N, D, H, W, Cout, ntz,
+                       nty, ntx);
 }
 
 // x [N][D][H][W][CT] (CT <= 8), wp = seg3d_pack_weights_thin_in, y [N][D][H][W][Cout];
 // stats (optional): [N][seg3d_conv3d_k3_thin_stats_count(D,H,W,ceil(Cout/32))][2]
+static int thin_in_launch(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
+                          int W, int CT, int Cout, int out_bf16, void* stream);
+
 extern "C" int seg3d_conv3d_k3_thin_in_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N,
                                            int D, int H, int W, int CT, int Cout, void* stream) {
+  return thin_in_launch(x, wp, bias, y, stats, N, D, H, W, CT, Cout, 0, stream);
+}
+
+// bf16 mode: y is bf16 storage (stem conv output / head data-gradient); x, weights, bias and statistics fp32
+extern "C" int seg3d_conv3d_k3_thin_in_bf16out_fwd(const float* x, const float* wp, const float* bias, void* y_bf16,
+                                                   float* stats, int N, int D, int H, int W, int CT, int Cout, void* stream) {
+  return thin_in_launch(x, wp, bias, reinterpret_cast<float*>(y_bf16), stats, N, D, H, W, CT, Cout, 1, stream);
+}
+
+static int thin_in_launch(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
+                          int W, int CT, int Cout, int out_bf16, void* stream) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_thin_in_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "seg3d_conv3d_k3_thin_in_fwd: bad dims");
   SEG3D_REQUIRE(CT >= 1 && CT <= 8, "seg3d_conv3d_k3_thin_in_fwd: thin channel count %d not in [1, 8]", CT);
   SEG3D_REQUIRE((i64)N * D * H * W * Cout < (1ll << 31), "seg3d_conv3d_k3_thin_in_fwd: tensor exceeds 2^31 elements");
   hipStream_t s = (hipStream_t)stream;
   switch (CT) {
-    case 1: launch_thin_in<1>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
-    case 2: launch_thin_in<2>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
-    case 3: launch_thin_in<3>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
-    case 4: launch_thin_in<4>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
-    case 5: launch_thin_in<5>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
-    case 6: launch_thin_in<6>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
-    case 7: launch_thin_in<7>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
-    default: launch_thin_in<8>(x, wp, bias, y, stats, N, D, H, W, Cout, s); break;
+    case 1: launch_thin_in<1>(x, wp, bias, y, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 2: launch_thin_in<2>(x, wp, bias, y, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 3: launch_thin_in<3>(x, wp, bias, y, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 4: launch_thin_in<4>(x, wp, bias, y, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 5: launch_thin_in<5>(x, wp, bias, y, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 6: launch_thin_in<6>(x, wp, bias, y, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 7: launch_thin_in<7>(x, wp, bias, y, stats, N, D, H, W, Cout, s, out_bf16); break;
+    default: launch_thin_in<8>(x, wp, bias, y, stats, N, D, H, W, Cout, s, out_bf16); break;
   }
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_thin_in_fwd");
   return SEG3D_OK;

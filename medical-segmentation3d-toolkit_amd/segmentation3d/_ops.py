@@ -246,8 +246,9 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
     """y[v][b] = bias[b] + sum_{t,a} x[v + t - 1][a] W(a,b,t) [+ addend];  returns (y, stats_partial or None)"""
     N, D, H, W_, Cin = xn.shape
     assert Cin == A
-    if out_bf16 and not (_is_bf16(xn) and A % 16 == 0 and B % 4 == 0 and B >= 8 and not FORCE_DIRECT):
-        out_bf16 = False      # only the bf16 MFMA kernel writes bf16 (callers treat the flag as a request)
+    thin_in16 = out_bf16 and not _is_bf16(xn) and A <= 8 and not FORCE_DIRECT and addend is None and not _use_mfma(A, B)
+    if out_bf16 and not thin_in16 and not (_is_bf16(xn) and A % 16 == 0 and B % 4 == 0 and B >= 8 and not FORCE_DIRECT):
+        out_bf16 = False      # only the bf16 MFMA kernel and the thin-input kernel write bf16 (the flag is a request)
     y = _empty((N, D, H, W_, B), xn, torch.bfloat16 if out_bf16 else torch.float32)
     if _is_bf16(xn):
         if A % 16 == 0 and B % 4 == 0 and B >= 8 and not FORCE_DIRECT:
@@ -292,8 +293,8 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
         stats = None
         if want_stats:
             stats = _empty((N, E.query('seg3d_conv3d_k3_thin_stats_count', D, H, W_, (B + 31) // 32), 2), xn)
-        E.call('seg3d_conv3d_k3_thin_in_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B,
-               E.stream_ptr())
+        E.call('seg3d_conv3d_k3_thin_in_bf16out_fwd' if _is_bf16(y) else 'seg3d_conv3d_k3_thin_in_fwd', E.ptr(xn), E.ptr(wp),
+               E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B, E.stream_ptr())
         return y, stats
     if B <= 8 and A % 4 == 0 and not FORCE_DIRECT:
         # thin output (head forward): LDS-tiled VALU kernel, CO outputs per voxel
@@ -424,15 +425,18 @@ def _check_w(w, shape, kind):
         raise ValueError('conv weights must be contiguous')
 
 
-def conv_dgrad(dyn, w, kind, addend=None):
+def conv_dgrad(dyn, w, kind, addend=None, want_bf16=None):
     """gradient w.r.t. the conv input (+ addend, an extra gradient for the same tensor that is folded into the kernel
-    epilogue); dyn: [N,Do,Ho,Wo,Cout] contiguous"""
+    epilogue); dyn: [N,Do,Ho,Wo,Cout] contiguous.  want_bf16: the input is a bf16 activation, so its gradient should be
+    written as bf16 by the kernel where it can (default: follows dyn's dtype)"""
+    if want_bf16 is None:
+        want_bf16 = _is_bf16(dyn)
     N, D, H, W_, _ = dyn.shape
     if kind == 'k3':
         Cout, Cin = w.shape[0], w.shape[1]
         # dx[v][ci] = sum_{t',co} dy[v + t' - 1][co] w[co][ci][26 - t']
         # (a bf16 dy means the unit's input is a bf16 activation: its gradient is written as bf16 by the kernel itself)
-        dx, _ = _conv_k3_generic(dyn, w, None, Cout, Cin, Cin * 27, 27, 1, False, addend=addend, out_bf16=_is_bf16(dyn))
+        dx, _ = _conv_k3_generic(dyn, w, None, Cout, Cin, Cin * 27, 27, 1, False, addend=addend, out_bf16=want_bf16)
         return dx
     if addend is not None:
         return conv_dgrad(dyn, w, kind).add_(addend)
@@ -722,7 +726,8 @@ class ConvGnActFunction(torch.autograd.Function):
         E.require_device(x, weight, bias, gamma, beta, residual)
         xn = to_ndhwc(x)
         w = weight.detach()
-        want16 = BF16_CONV_OUTPUT and _is_bf16(xn) and _out_bf16(w.shape[1] if kind == 'convT' else w.shape[0])
+        cout = w.shape[1] if kind == 'convT' else w.shape[0]
+        want16 = BF16_CONV_OUTPUT and _out_bf16(cout) and (_is_bf16(xn) or (kind == 'k3' and xn.shape[4] <= 8))
         yn, partial = conv_forward(xn, w, None if bias is None else bias.detach(), kind, want_stats=True, out_bf16=want16)
         mean_rstd = gn_stats(yn, partial, eps)
         resn = None
@@ -767,7 +772,7 @@ class ConvGnActFunction(torch.autograd.Function):
                 raise RuntimeError('ResidualLink misuse: the linked unit must produce exactly one input gradient')
             addend, ctx.link_in.grad = ctx.link_in.grad, None
         if ctx.needs_input_grad[0]:
-            dx = from_ndhwc(conv_dgrad(dy, w, ctx.kind, addend=addend))
+            dx = from_ndhwc(conv_dgrad(dy, w, ctx.kind, addend=addend, want_bf16=_is_bf16(xn)))
         dw = None
         if ctx.needs_input_grad[1]:
             if sw is not None:

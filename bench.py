@@ -56,8 +56,11 @@ def parse():
                     help="fp32 = the headline metric (BASELINE configs 2-4); bf16 = BASELINE config 5's mode (bf16 "
                          "activations / packed weights, fp32 accumulate, statistics and master weights) -- reported "
                          "under its own dtype, never as the fp32 headline")
-    ap.add_argument('--graph', action='store_true',
-                    help='capture the whole train step in one hipGraph (single GPU only; see core/seg_train.TrainStep)')
+    ap.add_argument('--graph', action='store_true', help='(default for one GPU; kept for compatibility)')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='one GPU: issue the ~420 launches of a step eagerly instead of replaying the step from one '
+                         'hipGraph (core/seg_train.TrainStep use_graph; same kernels, bit-identical losses).  With several '
+                         'GPUs the step is always eager: the gradient all-reduce stays outside hipGraphs')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='enqueue weight-gradient kernels on the main stream (no second HIP stream): use this under '
                          'rocprofv3 --kernel-trace, which serialises concurrent dispatches and distorts their durations')
@@ -246,6 +249,7 @@ def main():
     if args.gpus != world and rank == 0:
         sys.stderr.write('note: --gpus {} but WORLD_SIZE {}\n'.format(args.gpus, world))
 
+    args.graph = (world == 1) and not args.no_graph
     from segmentation3d.core.seg_train import TrainStep
     from segmentation3d import _ops as _ops_mode
     _ops_mode.set_activation_dtype(args.dtype)

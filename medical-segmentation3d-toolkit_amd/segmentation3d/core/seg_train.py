@@ -83,11 +83,23 @@ class TrainStep(object):
             self._gx, self._gt = crops.clone(), masks.clone()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._gloss = self._eager(self._gx, self._gt)
-            for f in self.opt._flat:                          # capture ran the host side of opt.step() once, no kernels
+            host_steps = [None if f is None else f['step'] for f in self.opt._flat]
+            try:
+                with torch.cuda.graph(graph):
+                    self._gloss = self._eager(self._gx, self._gt)
+            except Exception as exc:                           # capture refused (driver / allocator state): stay eager
+                import warnings
+                warnings.warn('TrainStep: hipGraph capture of the train step failed ({}); continuing eagerly'.format(exc))
+                torch.cuda.synchronize()
+                for f, st in zip(self.opt._flat, host_steps):
+                    if f is not None:
+                        f['step'] = st
+                        f['step_dev'].fill_(int(st))
+                self.use_graph = False
+                return self._eager(crops, masks)
+            for f, st in zip(self.opt._flat, host_steps):     # capture ran the host side of opt.step() once, no kernels
                 if f is not None:
-                    f['step'] -= 1
+                    f['step'] = st
             self._graph = graph
         self._gx.copy_(crops)
         self._gt.copy_(masks)

@@ -142,7 +142,7 @@ def pmc_traffic_gb(kernel_name):
     (profiles/r01_pmc_fetch_write_per_kernel.json: FETCH_SIZE and WRITE_SIZE in KB, collected in separate --pmc
     passes).  gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE under-reports wide coalesced reads
     by 2x, WRITE_SIZE is exact.  Counters cannot be collected from inside bench.py; returns None when absent."""
-    path = os.path.join(REPO, 'profiles', 'r01_h_bf16_pmc_fetch_write_per_kernel.json' if 'bf16' in kernel_name
+    path = os.path.join(REPO, 'profiles', 'r01_i_bf16_pmc_fetch_write_per_kernel.json' if 'bf16' in kernel_name
                         else 'r01_pmc_fetch_write_per_kernel.json')
     if not os.path.isfile(path):
         return None

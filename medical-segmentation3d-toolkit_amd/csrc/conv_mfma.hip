@@ -289,6 +289,16 @@ __device__ long long* seg3d_stamp_buf;
 #define SEG3D_STAMP(slot, k) do { } while (0)
 #endif
 
+#ifndef SEG3D_LANE_SLOTS   // 0: tile-linear lane -> voxel order (measurement builds)
+#define SEG3D_LANE_SLOTS 1
+#endif
+#ifndef SEG3D_BF16_PD   // taps of LDS operands kept in flight by the bf16 forward kernel
+#define SEG3D_BF16_PD 3
+#endif
+#ifndef SEG3D_EXP_FWD_NODMA   // measurement builds: 1 = the forward kernels skip their steady-state LDS-DMA (results wrong)
+#define SEG3D_EXP_FWD_NODMA 0
+#endif
+
 __device__ __forceinline__ void seg3d_glds16(const float* src, float* lds_dst_wave_uniform) {
   __builtin_amdgcn_global_load_lds(src, lds_dst_wave_uniform, 16, 0, 0);
 }
@@ -351,11 +361,17 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
       hpos[j] = (hh << 30) | (hz << 20) | (hy << 10) | hx;
     }
   }
-  // this lane's MA voxels (one per accumulator row block): LDS base of the A rows and tile-local coordinates
+  // this lane's MA voxels (one per accumulator row block): LDS base of the A rows and tile-local coordinates.
+  // Which of the 32 voxels of a row block a lane takes is free (the lane feeds and owns MFMA column `li` either way); it
+  // is chosen so that each 16-lane group the hardware serves a ds_read_b128 in -- {0-3, 12-15, 20-27}, {4-11, 16-19,
+  // 28-31} and the same + 32 -- reads 16 CONSECUTIVE voxels of the tile: with tile rows of 16 voxels that is one contiguous
+  // 256-byte run = all 64 banks once.  (In tile-linear lane order a group gathered 4 + 4 + 8 voxels from four rows 160
+  // bytes apart: SQ_LDS_BANK_CONFLICT was 60 % of the LDS cycles of the bf16 kernel.)
+  const int lslot = li < 4 ? li : li < 12 ? li + 12 : li < 16 ? li - 8 : li < 20 ? li + 8 : li < 28 ? li - 12 : li;
   int abase[MA], vpos[MA];
 #pragma unroll
   for (int m = 0; m < MA; ++m) {
-    const int idx = (wave + 4 * m) * 32 + li;
+    const int idx = (wave + 4 * m) * 32 + (SEG3D_LANE_SLOTS ? lslot : li);
     int vb = 0;
     vpos[m] = -1;
     if (idx < MT) {
@@ -497,55 +513,107 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
       }
       const float* xs = cur;
       const float* ws = cur + XS;
-      f32x4 bw[NB], av[MA];
+      if constexpr (BF16) {
+        // bf16: a tap is 4 * MA * NB / 4 MFMAs of 32 cycles -- 8x shorter than in fp32 -- so operands read one tap ahead
+        // arrive too late (LDS latency > one tap).  A ring of SEG3D_BF16_PD taps of operands is kept in flight instead;
+        // the compiler places the counted lgkmcnt waits itself (plain LDS loads).
+        constexpr int PD = SEG3D_BF16_PD;
+        f32x4 bwq[PD][NB], avq[PD][MA];
+        auto tap_off = [&](int t) {
+          const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+          return ((kz * HY + ky) * HX + kx) * 4;
+        };
 #pragma unroll
-      for (int q = 0; q < NB; ++q) bw[q] = *reinterpret_cast<const f32x4*>(ws + q * SEG3D_W_CHUNK + bbase);
+        for (int p = 0; p < PD; ++p) {
 #pragma unroll
-      for (int m = 0; m < MA; ++m) av[m] = *reinterpret_cast<const f32x4*>(xs + abase[m]);
+          for (int q = 0; q < NB; ++q) bwq[p][q] = *reinterpret_cast<const f32x4*>(ws + q * SEG3D_W_CHUNK + p * 256 + bbase);
 #pragma unroll
-      for (int tap = 0; tap < 27; ++tap) {
-        f32x4 bwn[NB], avn[MA];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) bwn[q] = bw[q];
-#pragma unroll
-        for (int m = 0; m < MA; ++m) avn[m] = av[m];
-        if (tap + 1 < 27) {  // operands of tap t+1 are read while tap t is multiplied
-          const int t1 = tap + 1;
-          const int kz = t1 / 9, ky = (t1 / 3) % 3, kx = t1 % 3;
-          const int tapoff = ((kz * HY + ky) * HX + kx) * 4;
-#pragma unroll
-          for (int q = 0; q < NB; ++q) bwn[q] = *reinterpret_cast<const f32x4*>(ws + q * SEG3D_W_CHUNK + t1 * 256 + bbase);
-#pragma unroll
-          for (int m = 0; m < MA; ++m) avn[m] = *reinterpret_cast<const f32x4*>(xs + abase[m] + tapoff);
+          for (int m = 0; m < MA; ++m) avq[p][m] = *reinterpret_cast<const f32x4*>(xs + abase[m] + tap_off(p));
         }
-        if (do_dma) {  // one DMA piece of the next chunk per tap, behind the MFMAs
-          if (tap < SEG3D_V2_MAXPX) {
-            if (tap < nx) dma_x(tap, nxt);
-          } else if (tap - SEG3D_V2_MAXPX < MAXPW) {
-            dma_w(tap - SEG3D_V2_MAXPX, wnext, nxt);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+          const int slot = tap % PD;
+          f32x4 bwc[NB], avc[MA];
+#pragma unroll
+          for (int q = 0; q < NB; ++q) bwc[q] = bwq[slot][q];
+#pragma unroll
+          for (int m = 0; m < MA; ++m) avc[m] = avq[slot][m];
+          if (tap + PD < 27) {
+            const int t1 = tap + PD;
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+              bwq[slot][q] = *reinterpret_cast<const f32x4*>(ws + q * SEG3D_W_CHUNK + t1 * 256 + bbase);
+#pragma unroll
+            for (int m = 0; m < MA; ++m) avq[slot][m] = *reinterpret_cast<const f32x4*>(xs + abase[m] + tap_off(t1));
           }
-        }
-        // A = weights, B = voxels: D[co][voxel], a lane owns voxel (lane & 31) and channels 8 g + 4 (lane >> 5) + c
-        if constexpr (BF16) {
+          // keep the reads up here: left alone, the scheduler sinks every read to just in front of the MFMA that consumes
+          // it (register pressure heuristics) and puts an lgkmcnt(0) wait before nearly every MFMA
+          __builtin_amdgcn_sched_barrier(0);
+          if (do_dma && !SEG3D_EXP_FWD_NODMA) {  // one DMA piece of the next chunk per tap, behind the MFMAs
+            if (tap < SEG3D_V2_MAXPX) {
+              if (tap < nx) dma_x(tap, nxt);
+            } else if (tap - SEG3D_V2_MAXPX < MAXPW) {
+              dma_w(tap - SEG3D_V2_MAXPX, wnext, nxt);
+            }
+          }
 #pragma unroll
           for (int m = 0; m < MA; ++m)
 #pragma unroll
             for (int q = 0; q < NB; ++q)
-              acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[q]),
-                                                                  __builtin_bit_cast(bf16x8, av[m]), acc[m][q], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int m = 0; m < MA; ++m)
-#pragma unroll
-              for (int q = 0; q < NB; ++q)
-                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[q][r], av[m][r], acc[m][q], 0, 0, 0);
+              acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bwc[q]),
+                                                                  __builtin_bit_cast(bf16x8, avc[m]), acc[m][q], 0, 0, 0);
         }
-#pragma unroll
-        for (int q = 0; q < NB; ++q) bw[q] = bwn[q];
-#pragma unroll
-        for (int m = 0; m < MA; ++m) av[m] = avn[m];
+      } else {
+        f32x4 bw[NB], av[MA];
+  #pragma unroll
+        for (int q = 0; q < NB; ++q) bw[q] = *reinterpret_cast<const f32x4*>(ws + q * SEG3D_W_CHUNK + bbase);
+  #pragma unroll
+        for (int m = 0; m < MA; ++m) av[m] = *reinterpret_cast<const f32x4*>(xs + abase[m]);
+  #pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+          f32x4 bwn[NB], avn[MA];
+  #pragma unroll
+          for (int q = 0; q < NB; ++q) bwn[q] = bw[q];
+  #pragma unroll
+          for (int m = 0; m < MA; ++m) avn[m] = av[m];
+          if (tap + 1 < 27) {  // operands of tap t+1 are read while tap t is multiplied
+            const int t1 = tap + 1;
+            const int kz = t1 / 9, ky = (t1 / 3) % 3, kx = t1 % 3;
+            const int tapoff = ((kz * HY + ky) * HX + kx) * 4;
+  #pragma unroll
+            for (int q = 0; q < NB; ++q) bwn[q] = *reinterpret_cast<const f32x4*>(ws + q * SEG3D_W_CHUNK + t1 * 256 + bbase);
+  #pragma unroll
+            for (int m = 0; m < MA; ++m) avn[m] = *reinterpret_cast<const f32x4*>(xs + abase[m] + tapoff);
+          }
+          if (do_dma && !SEG3D_EXP_FWD_NODMA) {  // one DMA piece of the next chunk per tap, behind the MFMAs
+            if (tap < SEG3D_V2_MAXPX) {
+              if (tap < nx) dma_x(tap, nxt);
+            } else if (tap - SEG3D_V2_MAXPX < MAXPW) {
+              dma_w(tap - SEG3D_V2_MAXPX, wnext, nxt);
+            }
+          }
+          // A = weights, B = voxels: D[co][voxel], a lane owns voxel (lane & 31) and channels 8 g + 4 (lane >> 5) + c
+          if constexpr (BF16) {
+  #pragma unroll
+            for (int m = 0; m < MA; ++m)
+  #pragma unroll
+              for (int q = 0; q < NB; ++q)
+                acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[q]),
+                                                                    __builtin_bit_cast(bf16x8, av[m]), acc[m][q], 0, 0, 0);
+          } else {
+  #pragma unroll
+            for (int r = 0; r < 4; ++r)
+  #pragma unroll
+              for (int m = 0; m < MA; ++m)
+  #pragma unroll
+                for (int q = 0; q < NB; ++q)
+                  acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[q][r], av[m][r], acc[m][q], 0, 0, 0);
+          }
+  #pragma unroll
+          for (int q = 0; q < NB; ++q) bw[q] = bwn[q];
+  #pragma unroll
+          for (int m = 0; m < MA; ++m) av[m] = avn[m];
+        }
       }
       if (do_dma) __syncthreads();  // own DMAs landed (vmcnt(0)), everyone done with `cur`, `nxt` visible
       parity ^= 1;
@@ -893,7 +961,11 @@ static bool seg3d_pick_tile_v2(int N, int D, int H, int W, int Cin, int Cout, Se
             const double rounds = ceil(wgs * ks / 256.0);
             // bf16: the chunk is as long as the slower of its MFMAs and its DMA traffic (4 x pieces KiB per workgroup
             // at ~16 B/clk per CU out of L2)
-            const double body = bf16 ? fmax(mfma_chunk * ma * nb, 4.0 * pieces * 1024.0 / 16.0) : mfma_chunk * ma * nb;
+            // bf16: LDS-read bound unless the tile rows are 16 voxels long (bank-conflict-free operand reads, see the
+            // kernel): price the operand reads of a chunk (27 taps, 4 waves x (ma + nb) KiB) at 256 B/clk, x 2.5 with conflicts
+            const double lds_chunk = 27.0 * 4.0 * (ma + nb) * 1024.0 / 256.0 * ((tx % 16) ? 2.5 : 1.0);
+            const double body = bf16 ? fmax(fmax(mfma_chunk * ma * nb, lds_chunk), 4.0 * pieces * 1024.0 / 16.0)
+                                     : mfma_chunk * ma * nb;
             const double per_wg = cpk * (body + 60.0 * pieces + 400.0) + 9000.0;
             // finish pass: (ks + 2) x output bytes through ~4 TB/s (1700 B/cycle) + launch and pipeline latency
             const double finish = ks > 1 ? (ks + 2) * out_bytes / 1700.0 + 16000.0 : 0.0;

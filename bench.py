@@ -129,6 +129,10 @@ class KernelTimer(object):
 
 def variant_kernel_name(v):
     """seg3d_conv3d_k3_mfma_variant code -> kernel symbol as rocprofv3 prints it"""
+    if v >= 400:
+        return 'conv3d_k3_mfma2w8_bf16_kernel<{}, {}, true>'.format((v - 400) // 10, v % 10)
+    if v >= 300:   # two waves per SIMD, MA row blocks per wave
+        return 'conv3d_k3_mfma2w8_kernel<{}, {}>'.format((v - 300) // 10, v % 10)
     if v >= 200:
         # third template argument: bf16 output -- every data-gradient, and every forward launch unless SEG3D_BF16_Y=0
         return 'conv3d_k3_mfma2_bf16_kernel<{}, {}, true>'.format((v - 200) // 10, v % 10)

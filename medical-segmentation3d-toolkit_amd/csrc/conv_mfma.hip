@@ -309,7 +309,10 @@ __device__ __forceinline__ void seg3d_glds16(const float* src, float* lds_dst_wa
 // four 32x32x2 fp32 MFMAs per tap.  Accumulators, bias, addend, output and statistics stay fp32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int MA, int NB, bool SPLITK, bool BF16 = false, bool OUT_BF = false>
+// NW = waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD, each with half the row blocks: while one wave is stuck
+// issuing an LDS-DMA piece -- ~150 cycles, during which its single in-flight MFMA runs out -- the other one keeps the
+// matrix pipe fed; needs <= 256 registers per wave, i.e. MA * NB <= 2).  The tile has 32 * NW * MA voxels either way.
+template <int MA, int NB, bool SPLITK, bool BF16 = false, bool OUT_BF = false, int NW = 4>
 __device__ __forceinline__ void conv3d_k3_mfma2_body(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ stats, int N, int D, int H, int W, int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
@@ -345,11 +348,11 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
   // input-tile DMA pieces of this wave: piece p = wave + 4 j covers float4 entries e = 64 p + lane of [2][NV];
   // hpos[j] = halo coordinates (hz << 20 | hy << 10 | hx), bit 30 = upper channel half, -1 = padding entry
   const int NPX = XS >> 8;
-  const int nx = NPX > wave ? (NPX - wave + 3) >> 2 : 0;
+  const int nx = NPX > wave ? (NPX - wave + NW - 1) / NW : 0;
   int hpos[SEG3D_V2_MAXPX];
 #pragma unroll
   for (int j = 0; j < SEG3D_V2_MAXPX; ++j) {
-    const int e = (wave + 4 * j) * 64 + lane;
+    const int e = (wave + NW * j) * 64 + lane;
     hpos[j] = -1;
     if (e < 2 * NV) {
       const int hh = e >= NV;
@@ -371,7 +374,7 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
   int abase[MA], vpos[MA];
 #pragma unroll
   for (int m = 0; m < MA; ++m) {
-    const int idx = (wave + 4 * m) * 32 + (SEG3D_LANE_SLOTS ? lslot : li);
+    const int idx = (wave + NW * m) * 32 + (SEG3D_LANE_SLOTS ? lslot : li);
     int vb = 0;
     vpos[m] = -1;
     if (idx < MT) {
@@ -426,13 +429,13 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
     }
   };
   auto dma_x = [&](int j, float* buf) {  // j compile-time after unrolling; issues the piece, then steps to the next chunk
-    seg3d_glds16(xsrc[j], buf + (wave + 4 * j) * 256);
+    seg3d_glds16(xsrc[j], buf + (wave + NW * j) * 256);
     xsrc[j] += ((xadv >> j) & 1) * 8;
   };
   constexpr int NPW = 27 * NB;  // weight pieces (1 KiB = one tap of one column block)
-  constexpr int MAXPW = (NPW + 3) / 4;
+  constexpr int MAXPW = (NPW + NW - 1) / NW;
   auto dma_w = [&](int j, const float* wchunk, float* buf) {  // wchunk: packed weights of (first column block, chunk)
-    const int piece = wave + 4 * j;
+    const int piece = wave + NW * j;
     if (piece < NPW) {
       const int nb = piece / 27, tap = piece - nb * 27;
       seg3d_glds16(wchunk + (i64)nb * CIB * SEG3D_W_CHUNK + tap * 256 + lane * 4, buf + XS + piece * 256);
@@ -517,7 +520,7 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
         // bf16: a tap is 4 * MA * NB / 4 MFMAs of 32 cycles -- 8x shorter than in fp32 -- so operands read one tap ahead
         // arrive too late (LDS latency > one tap).  A ring of SEG3D_BF16_PD taps of operands is kept in flight instead;
         // the compiler places the counted lgkmcnt waits itself (plain LDS loads).
-        constexpr int PD = SEG3D_BF16_PD;
+        constexpr int PD = NW == 8 ? 1 : SEG3D_BF16_PD;   // (two waves per SIMD: 256 registers, and the other wave covers)
         f32x4 bwq[PD][NB], avq[PD][MA];
         auto tap_off = [&](int t) {
           const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
@@ -671,7 +674,7 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
     }
     // interior items (whole tile inside the volume, all 32-channel blocks complete) store unconditionally: straight-
     // line code, 4 * MA * NB dwordx4 stores back to back; the per-lane test of edge items costs exec-mask branches
-    const bool whole = MT == 128 * MA && cur_z0 + TZ <= D && cur_y0 + TY <= H && cur_x0 + TX <= W &&
+    const bool whole = MT == 32 * NW * MA && cur_z0 + TZ <= D && cur_y0 + TY <= H && cur_x0 + TX <= W &&
                        (cur_cog + 1) * NB * 32 <= Cout;
     if (whole) {
 #pragma unroll
@@ -716,7 +719,7 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
       s1 = wave_sum(s1);
       if (lane == 0) {
         const int tiles_per_sample = ntz * nty * ntx;
-        float* dst = stats + ((((i64)cur_n * tiles_per_sample + cur_tile) * ncog + cur_cog) * 4 + wave) * 2;
+        float* dst = stats + ((((i64)cur_n * tiles_per_sample + cur_tile) * ncog + cur_cog) * NW + wave) * 2;
         dst[0] = s0;
         dst[1] = s1;
       }
@@ -742,6 +745,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_kernel(
                                       addend, nullptr, 1, 0);
 }
 
+// two waves per SIMD (NW = 8): MA counts the row blocks PER WAVE, the tile has 256 * MA voxels
+template <int MA, int NB>
+__global__ __launch_bounds__(512, 1) void conv3d_k3_mfma2w8_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ stats, int N, int D, int H, int W, int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
+    int ntx, int ncog, int nitems, const float* __restrict__ addend) {
+  conv3d_k3_mfma2_body<MA, NB, false, false, false, 8>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, TZ, TY, TX, ntz, nty,
+                                                       ntx, ncog, nitems, addend, nullptr, 1, 0);
+}
+
 // same loop over (tile, column group, K range) items; writes raw partial slabs for conv3d_splitk_finish_kernel
 template <int MA, int NB>
 __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_splitk_kernel(
@@ -761,6 +774,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma2_bf16_kernel(
     int ntx, int ncog, int nitems, const float* __restrict__ addend) {
   conv3d_k3_mfma2_body<MA, NB, false, true, OUT_BF>(x, wp, bias, y, stats, N, D, H, W, Cw, Cout, TZ, TY, TX, ntz, nty, ntx,
                                                     ncog, nitems, addend, nullptr, 1, 0);
+}
+
+template <int MA, int NB, bool OUT_BF>
+__global__ __launch_bounds__(512, 1) void conv3d_k3_mfma2w8_bf16_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y,
+    float* __restrict__ stats, int N, int D, int H, int W, int Cw, int Cout, int TZ, int TY, int TX, int ntz, int nty,
+    int ntx, int ncog, int nitems, const float* __restrict__ addend) {
+  conv3d_k3_mfma2_body<MA, NB, false, true, OUT_BF, 8>(x, wp, bias, y, stats, N, D, H, W, Cw, Cout, TZ, TY, TX, ntz, nty,
+                                                       ntx, ncog, nitems, addend, nullptr, 1, 0);
 }
 
 template <int MA, int NB>
@@ -892,7 +914,17 @@ struct Seg3dFwdPlan {
   int version;  // 1: two workgroups per CU, register-staged (also the split-K path); 2: one per CU, LDS-DMA
   Seg3dTile t;
   int ma, nb, ks;
+  int nw;       // waves per workgroup of the version-2 kernel: 4, or 8 (two per SIMD, ma / 2 row blocks each)
 };
+
+static int seg3d_fwd_w8_enabled() {   // SEG3D_FWD_W8=0: always one wave per SIMD (measurement switch)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEG3D_FWD_W8");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
 
 static int seg3d_fwd_v2_enabled() {
   static int v = -1;
@@ -988,6 +1020,7 @@ static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout
   Seg3dFwdPlan p;
   p.ks = seg3d_fwd_ksplit(N, D, H, W, Cin, Cout);
   p.version = 1;
+  p.nw = 4;
   p.nb = 1;
   p.t = seg3d_pick_tile(N, D, H, W, (Cout + 31) / 32);
   p.ma = ((p.t.tz * p.t.ty * p.t.tx + 31) / 32 + 3) / 4;
@@ -1002,6 +1035,7 @@ static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout
       p.ma = ma2;
       p.nb = nb2;
       p.ks = ks2;
+      if (seg3d_fwd_w8_enabled() && ks2 == 1 && nb2 == 1 && (ma2 == 2 || ma2 == 4)) p.nw = 8;
     }
   }
   return p;
@@ -1011,6 +1045,7 @@ static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout
 static Seg3dFwdPlan seg3d_fwd_plan_bf16(int N, int D, int H, int W, int Cin, int Cout) {
   Seg3dFwdPlan p;
   p.version = 0;
+  p.nw = 4;
   p.ks = 1;
   p.ma = p.nb = 1;
   p.t = {1, 1, 1};
@@ -1024,6 +1059,7 @@ static Seg3dFwdPlan seg3d_fwd_plan_bf16(int N, int D, int H, int W, int Cin, int
     p.ma = ma2;
     p.nb = nb2;
     p.ks = ks2;
+    if (seg3d_fwd_w8_enabled() && ks2 == 1 && nb2 == 1 && (ma2 == 2 || ma2 == 4)) p.nw = 8;
   }
   return p;
 }
@@ -1038,12 +1074,13 @@ extern "C" long long seg3d_conv3d_k3_bf16_stats_count(int N, int D, int H, int W
   if (p.version != 2) return 0;
   if (p.ks > 1) return ((long long)D * H * W * Cout + SPLITK_CHUNK - 1) / SPLITK_CHUNK;
   const long long tiles = (long long)seg3d_cdiv(D, p.t.tz) * seg3d_cdiv(H, p.t.ty) * seg3d_cdiv(W, p.t.tx);
-  return tiles * ((Cout + 31) / 32 / p.nb) * 4;
+  return tiles * ((Cout + 31) / 32 / p.nb) * p.nw;
 }
 
 // 200 + 10 MA + NB of conv3d_k3_mfma2_bf16_kernel<MA, NB> (0: shape not supported)
 extern "C" int seg3d_conv3d_k3_bf16_variant(int N, int D, int H, int W, int Cin, int Cout) {
   const Seg3dFwdPlan p = seg3d_fwd_plan_bf16(N, D, H, W, Cin, Cout);
+  if (p.version == 2 && p.nw == 8) return 400 + 10 * (p.ma / 2) + p.nb;   // conv3d_k3_mfma2w8_bf16_kernel<MA / 2, NB, .>
   return p.version == 2 ? 200 + 10 * p.ma + p.nb : 0;
 }
 
@@ -1058,13 +1095,14 @@ extern "C" long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W
   if (p.ks > 1) return ((long long)D * H * W * Cout + SPLITK_CHUNK - 1) / SPLITK_CHUNK;
   const int cob = (Cout + 31) / 32;
   const long long tiles = (long long)seg3d_cdiv(D, p.t.tz) * seg3d_cdiv(H, p.t.ty) * seg3d_cdiv(W, p.t.tx);
-  return p.version == 2 ? tiles * (cob / p.nb) * 4 /* one slot per wave */ : tiles * cob;
+  return p.version == 2 ? tiles * (cob / p.nb) * p.nw /* one slot per wave */ : tiles * cob;
 }
 
 // which template instantiation a given problem runs (lets profilers attribute time): MA (row blocks per wave, 1..4)
 // for the first-generation kernel conv3d_k3_mfma_kernel<MA>; 100 + 10 MA + NB for conv3d_k3_mfma2_kernel<MA, NB>
 extern "C" int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cin, int Cout) {
   const Seg3dFwdPlan p = seg3d_fwd_plan(N, D, H, W, Cin, Cout);
+  if (p.version == 2 && p.nw == 8) return 300 + 10 * (p.ma / 2) + p.nb;   // conv3d_k3_mfma2w8_kernel<MA / 2, NB>
   return p.version == 2 ? 100 + 10 * p.ma + p.nb : p.ma;
 }
 
@@ -1152,6 +1190,52 @@ static int launch_fwd2(const float* x, const float* wp, const float* bias, float
   return SEG3D_OK;
 }
 
+template <int MA, bool OUT_BF>
+static int launch_fwd2_w8_bf16(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
+                               int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, const float* addend) {
+  const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
+  const size_t lds = seg3d_fwd2_lds_bytes(t, 1);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2w8_bf16_kernel<MA, 1, OUT_BF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) {
+      seg3d_set_error("conv3d_k3_mfma2w8_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SEG3D_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  const int ncog = (Cout + 31) / 32;
+  const int nitems = N * ntz * nty * ntx * ncog;
+  dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
+  hipLaunchKernelGGL((conv3d_k3_mfma2w8_bf16_kernel<MA, 1, OUT_BF>), grid, dim3(512), lds, s, x, wp, bias, y, stats, N, D, H,
+                     W, Cin / 2, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, addend);
+  return SEG3D_OK;
+}
+
+template <int MA>
+static int launch_fwd2_w8(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D, int H,
+                          int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, const float* addend) {
+  const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
+  const size_t lds = seg3d_fwd2_lds_bytes(t, 1);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2w8_kernel<MA, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) {
+      seg3d_set_error("conv3d_k3_mfma2w8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SEG3D_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  const int ncog = (Cout + 31) / 32;
+  const int nitems = N * ntz * nty * ntx * ncog;
+  dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
+  hipLaunchKernelGGL((conv3d_k3_mfma2w8_kernel<MA, 1>), grid, dim3(512), lds, s, x, wp, bias, y, stats, N, D, H, W, Cin,
+                     Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, addend);
+  return SEG3D_OK;
+}
+
 // x [N][D][H][W][Cin], wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 27), y [N][D][H][W][Cout];
 // stats (optional): [N][seg3d_conv3d_k3_mfma_stats_count][2] partial (sum, sumsq) of y per sample.
 // addend (optional, same shape as y): y = conv(x) + bias + addend -- used by the data-gradient of the first conv of a
@@ -1171,6 +1255,13 @@ extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const f
   const int ks = plan.ks;
   SEG3D_REQUIRE(ks == 1 || workspace, "seg3d_conv3d_k3_mfma_fwd: this shape runs split-K and needs the workspace "
                 "(seg3d_conv3d_k3_mfma_fwd_workspace_floats)");
+  if (plan.version == 2 && plan.nw == 8) {
+    const int rc8 = plan.ma == 4 ? launch_fwd2_w8<2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend)
+                                 : launch_fwd2_w8<1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend);
+    if (rc8 != SEG3D_OK) return rc8;
+    SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_fwd(v2, 8 waves)");
+    return SEG3D_OK;
+  }
   if (plan.version == 2) {
     int rc2;
     switch (plan.ma * 10 + plan.nb) {
@@ -1238,6 +1329,18 @@ extern "C" int seg3d_conv3d_k3_bf16_fwd(const void* x, const void* wp, const flo
   const Seg3dTile t = plan.t;
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  if (plan.nw == 8) {
+    int rc8;
+    if (plan.ma == 4)
+      rc8 = out_bf16 ? launch_fwd2_w8_bf16<2, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend)
+                     : launch_fwd2_w8_bf16<2, false>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend);
+    else
+      rc8 = out_bf16 ? launch_fwd2_w8_bf16<1, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend)
+                     : launch_fwd2_w8_bf16<1, false>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend);
+    if (rc8 != SEG3D_OK) return rc8;
+    SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_bf16_fwd(8 waves)");
+    return SEG3D_OK;
+  }
 #define SEG3D_BF16_LAUNCH(MA_, NB_)                                                                                    \
   rc = out_bf16 ? launch_fwd2<MA_, NB_, true, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend, workspace, \
                                                     ks)                                                               \

@@ -370,6 +370,9 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
   // 28-31} and the same + 32 -- reads 16 CONSECUTIVE voxels of the tile: with tile rows of 16 voxels that is one contiguous
   // 256-byte run = all 64 banks once.  (In tile-linear lane order a group gathered 4 + 4 + 8 voxels from four rows 160
   // bytes apart: SQ_LDS_BANK_CONFLICT was 60 % of the LDS cycles of the bf16 kernel.)
+  // NW = 8 with a 384-voxel tile: waves 4..7 own only one of their two row blocks (12 blocks over 8 waves = 3 per SIMD);
+  // the MFMAs of the missing block are skipped (wave-uniform)
+  const bool act1 = NW != 8 || MA < 2 || (wave + NW) * 32 < MT;
   const int lslot = li < 4 ? li : li < 12 ? li + 12 : li < 16 ? li - 8 : li < 20 ? li + 8 : li < 28 ? li - 12 : li;
   int abase[MA], vpos[MA];
 #pragma unroll
@@ -560,11 +563,13 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
             }
           }
 #pragma unroll
-          for (int m = 0; m < MA; ++m)
+          for (int m = 0; m < MA; ++m) {
+            if (NW == 8 && m == 1 && !act1) continue;
 #pragma unroll
             for (int q = 0; q < NB; ++q)
               acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bwc[q]),
                                                                   __builtin_bit_cast(bf16x8, avc[m]), acc[m][q], 0, 0, 0);
+          }
         }
       } else {
         f32x4 bw[NB], av[MA];
@@ -607,10 +612,12 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
   #pragma unroll
             for (int r = 0; r < 4; ++r)
   #pragma unroll
-              for (int m = 0; m < MA; ++m)
+              for (int m = 0; m < MA; ++m) {
+                if (NW == 8 && m == 1 && !act1) continue;
   #pragma unroll
                 for (int q = 0; q < NB; ++q)
                   acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[q][r], av[m][r], acc[m][q], 0, 0, 0);
+              }
           }
   #pragma unroll
           for (int q = 0; q < NB; ++q) bw[q] = bwn[q];
@@ -1035,7 +1042,7 @@ static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout
       p.ma = ma2;
       p.nb = nb2;
       p.ks = ks2;
-      if (seg3d_fwd_w8_enabled() && ks2 == 1 && nb2 == 1 && (ma2 == 2 || ma2 == 4)) p.nw = 8;
+      if (seg3d_fwd_w8_enabled() && ks2 == 1 && nb2 == 1 && ma2 >= 2) p.nw = 8;   // ma 3: 12 row blocks over 8 waves
     }
   }
   return p;
@@ -1059,7 +1066,7 @@ static Seg3dFwdPlan seg3d_fwd_plan_bf16(int N, int D, int H, int W, int Cin, int
     p.ma = ma2;
     p.nb = nb2;
     p.ks = ks2;
-    if (seg3d_fwd_w8_enabled() && ks2 == 1 && nb2 == 1 && (ma2 == 2 || ma2 == 4)) p.nw = 8;
+    if (seg3d_fwd_w8_enabled() && ks2 == 1 && nb2 == 1 && ma2 >= 2) p.nw = 8;
   }
   return p;
 }
@@ -1080,7 +1087,7 @@ extern "C" long long seg3d_conv3d_k3_bf16_stats_count(int N, int D, int H, int W
 // 200 + 10 MA + NB of conv3d_k3_mfma2_bf16_kernel<MA, NB> (0: shape not supported)
 extern "C" int seg3d_conv3d_k3_bf16_variant(int N, int D, int H, int W, int Cin, int Cout) {
   const Seg3dFwdPlan p = seg3d_fwd_plan_bf16(N, D, H, W, Cin, Cout);
-  if (p.version == 2 && p.nw == 8) return 400 + 10 * (p.ma / 2) + p.nb;   // conv3d_k3_mfma2w8_bf16_kernel<MA / 2, NB, .>
+  if (p.version == 2 && p.nw == 8) return 400 + 10 * ((p.ma + 1) / 2) + p.nb;   // conv3d_k3_mfma2w8_bf16_kernel<ceil(MA / 2), NB, .>
   return p.version == 2 ? 200 + 10 * p.ma + p.nb : 0;
 }
 
@@ -1102,7 +1109,7 @@ extern "C" long long seg3d_conv3d_k3_mfma_stats_count(int N, int D, int H, int W
 // for the first-generation kernel conv3d_k3_mfma_kernel<MA>; 100 + 10 MA + NB for conv3d_k3_mfma2_kernel<MA, NB>
 extern "C" int seg3d_conv3d_k3_mfma_variant(int N, int D, int H, int W, int Cin, int Cout) {
   const Seg3dFwdPlan p = seg3d_fwd_plan(N, D, H, W, Cin, Cout);
-  if (p.version == 2 && p.nw == 8) return 300 + 10 * (p.ma / 2) + p.nb;   // conv3d_k3_mfma2w8_kernel<MA / 2, NB>
+  if (p.version == 2 && p.nw == 8) return 300 + 10 * ((p.ma + 1) / 2) + p.nb;   // conv3d_k3_mfma2w8_kernel<ceil(MA / 2), NB>
   return p.version == 2 ? 100 + 10 * p.ma + p.nb : p.ma;
 }
 
@@ -1256,7 +1263,7 @@ extern "C" int seg3d_conv3d_k3_mfma_fwd(const float* x, const float* wp, const f
   SEG3D_REQUIRE(ks == 1 || workspace, "seg3d_conv3d_k3_mfma_fwd: this shape runs split-K and needs the workspace "
                 "(seg3d_conv3d_k3_mfma_fwd_workspace_floats)");
   if (plan.version == 2 && plan.nw == 8) {
-    const int rc8 = plan.ma == 4 ? launch_fwd2_w8<2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend)
+    const int rc8 = plan.ma >= 3 ? launch_fwd2_w8<2>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend)
                                  : launch_fwd2_w8<1>(x, wp, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend);
     if (rc8 != SEG3D_OK) return rc8;
     SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_fwd(v2, 8 waves)");
@@ -1331,7 +1338,7 @@ extern "C" int seg3d_conv3d_k3_bf16_fwd(const void* x, const void* wp, const flo
   int rc;
   if (plan.nw == 8) {
     int rc8;
-    if (plan.ma == 4)
+    if (plan.ma >= 3)
       rc8 = out_bf16 ? launch_fwd2_w8_bf16<2, true>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend)
                      : launch_fwd2_w8_bf16<2, false>(xw, ww, bias, y, stats, N, D, H, W, Cin, Cout, t, s, addend);
     else

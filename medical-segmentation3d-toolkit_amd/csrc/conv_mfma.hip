@@ -1042,7 +1042,8 @@ static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout
       p.ma = ma2;
       p.nb = nb2;
       p.ks = ks2;
-      if (seg3d_fwd_w8_enabled() && ks2 == 1 && nb2 == 1 && ma2 >= 2) p.nw = 8;   // ma 3: 12 row blocks over 8 waves
+      // (fp32: the 384-voxel tiles -- 12 row blocks over 8 waves -- measured 0..2 % slower with 8 waves, bf16 4 % faster)
+      if (seg3d_fwd_w8_enabled() && ks2 == 1 && nb2 == 1 && (ma2 == 2 || ma2 == 4)) p.nw = 8;
     }
   }
   return p;

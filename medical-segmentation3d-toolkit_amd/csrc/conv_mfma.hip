@@ -289,6 +289,9 @@ __device__ long long* seg3d_stamp_buf;
 #define SEG3D_STAMP(slot, k) do { } while (0)
 #endif
 
+#ifndef SEG3D_XCD_WALK   // XCD-contiguous item walk of the persistent forward kernels
+#define SEG3D_XCD_WALK 1
+#endif
 #ifndef SEG3D_LANE_SLOTS   // 0: tile-linear lane -> voxel order (measurement builds)
 #define SEG3D_LANE_SLOTS 1
 #endif
@@ -445,8 +448,17 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
     }
   };
 
-  int item = blockIdx.x;
-  if (item >= nitems) return;
+  // Item walk.  SEG3D_XCD_WALK: workgroups go to the 8 XCDs round-robin (blockIdx % 8); XCD j then owns the contiguous
+  // eighth j of the item list and its G / 8 workgroups walk it side by side, so that neighbouring tiles (overlapping halos)
+  // are fetched through the same L2 at about the same time.
+  int item = blockIdx.x, istride = G, ilimit = nitems;
+  if (SEG3D_XCD_WALK && (G & 7) == 0) {
+    const int per_xcd = (nitems + 7) >> 3, xcd = blockIdx.x & 7;
+    item = xcd * per_xcd + (blockIdx.x >> 3);
+    istride = G >> 3;
+    ilimit = (xcd + 1) * per_xcd < nitems ? (xcd + 1) * per_xcd : nitems;
+  }
+  if (item >= ilimit) return;
   setup_item(item);
   SEG3D_STAMP(blockIdx.x, 0);
   {  // the only exposed DMA prologue of this workgroup: chunk 0 of its first item into buffer 0
@@ -465,8 +477,8 @@ __device__ __forceinline__ void conv3d_k3_mfma2_body(
     // the item being multiplied (its identity is needed again in the epilogue, after setup_item moved on)
     const int cur_n = it_n, cur_z0 = it_z0, cur_y0 = it_y0, cur_x0 = it_x0, cur_cog = it_cog, cur_tile = it_tile;
     const int cur_ks = it_ks, cur_c0 = SPLITK ? it_c0 : 0, cur_c1 = SPLITK ? it_c1 : CIB;
-    const int next_item = item + G;
-    const bool more_items = next_item < nitems;
+    const int next_item = item + istride;
+    const bool more_items = next_item < ilimit;
 
     f32x16 acc[MA][NB];
 #pragma unroll

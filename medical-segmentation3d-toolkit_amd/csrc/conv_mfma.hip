@@ -1675,8 +1675,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
     }
   };
 
-  int tile = slab;
-  if (tile < ntiles) {
+  // tile walk: plain stride, or (SEG3D_XCD_WALK, slabs % 8 == 0) XCD-contiguous as in the forward kernels
+  int tile = slab, tstride = slabs, tlimit = ntiles;
+  if (SEG3D_XCD_WALK && (slabs & 7) == 0) {
+    const int per_xcd = (ntiles + 7) >> 3, xcd = slab & 7;
+    tile = xcd * per_xcd + (slab >> 3);
+    tstride = slabs >> 3;
+    tlimit = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+  }
+  if (tile < tlimit) {
     set_tile(tile);
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) issue_piece(g, lds);
@@ -1686,14 +1693,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad2_kernel(const float* _
 #ifdef SEG3D_STAMPS
   int stamp_k = 0;
 #endif
-  for (; tile < ntiles; tile += slabs) {
+  for (; tile < tlimit; tile += tstride) {
 #ifdef SEG3D_STAMPS
     if (stamp_k < 5) SEG3D_STAMP(blockIdx.x, 3 * stamp_k);
 #endif
     const float* cur = lds + parity * BUF;
     float* nxt = lds + (parity ^ 1) * BUF;
-    const bool more = tile + slabs < ntiles;
-    if (more) set_tile(tile + slabs);
+    const bool more = tile + tstride < tlimit;
+    if (more) set_tile(tile + tstride);
     // the tile being fetched: inside the volume?  which of its halo faces stick out?
     const bool regular = tz0 + TZ <= D && ty0 + TY <= H && tx0 + TX <= W;
     const int faces = 64 | (tz0 == 0 ? 1 : 0) | (tz0 + TZ >= D ? 2 : 0) | (ty0 == 0 ? 4 : 0) |

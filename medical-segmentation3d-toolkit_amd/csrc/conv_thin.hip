@@ -320,7 +320,8 @@ __device__ __forceinline__ void conv3d_k3_thin_out_body(const void* __restrict__
                                                         int Cout, int ntz, int nty, int ntx) {
   __shared__ __attribute__((aligned(16))) float xs[8 * TO_NVP];      // [2][NVP][4]  (60.8 KB)
   const int tid = threadIdx.x;
-  int b = blockIdx.x;
+  int b = seg3d_xcd_tile(blockIdx.x, N * ntz * nty * ntx);   // neighbouring tiles (shared halo rows) on one XCD
+  if (b < 0) return;
   int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
   const int tix = b - qd * ntx; b = qd;
   qd = seg3d_fdiv(b, 1.0f / (float)nty);
@@ -492,7 +493,7 @@ static int thin_out_launch(const void* xv, int x_bf16, const float* wq, const fl
   SEG3D_REQUIRE((i64)N * D * H * W * Cin < (1ll << 31), "seg3d_conv3d_k3_thin_out_fwd: tensor exceeds 2^31 elements");
   const int ntz = seg3d_cdiv(D, TO_TZ), nty = seg3d_cdiv(H, TO_TY), ntx = seg3d_cdiv(W, TO_TX);
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "seg3d_conv3d_k3_thin_out_fwd: more than 2^22 tiles");
-  dim3 grid((unsigned)(N * ntz * nty * ntx));
+  dim3 grid((unsigned)seg3d_xcd_grid(N * ntz * nty * ntx));
   hipStream_t s = (hipStream_t)stream;
   if (x_bf16) {
     if (CO == 2)

@@ -115,6 +115,21 @@ template <> struct Seg3dQuad<true> {
   }
 };
 
+// XCD-contiguous block order for one-tile-per-workgroup kernels whose neighbouring tiles share halo voxels: workgroup b
+// runs on XCD b % 8 (round-robin dispatch), so it takes tile (b % 8) * ceil(n / 8) + b / 8 -- XCD j covers the contiguous
+// eighth j of the tile list and the halos of neighbours come through one L2.  Returns -1 for the padding blocks of the
+// last eighth (n not a multiple of 8: launch seg3d_xcd_grid(n) blocks).
+#ifndef SEG3D_XCD_TILES
+#define SEG3D_XCD_TILES 1
+#endif
+static inline int seg3d_xcd_grid(int n) { return SEG3D_XCD_TILES ? ((n + 7) / 8) * 8 : n; }
+__device__ __forceinline__ int seg3d_xcd_tile(int b, int n) {
+  if (!SEG3D_XCD_TILES) return b;
+  const int per = (n + 7) >> 3;
+  const int t = (b & 7) * per + (b >> 3);
+  return ((b >> 3) < per && t < n) ? t : -1;
+}
+
 // Sum NV values over a 256-thread workgroup. Result valid in thread 0. `red` must hold 4*NV floats.
 template <int NV>
 __device__ __forceinline__ void block_sum_256(float (&v)[NV], float* red) {

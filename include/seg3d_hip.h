@@ -128,6 +128,15 @@ int seg3d_k2_bf16_wgrad(const void* P_bf16, const void* Q_bf16, float* dw, float
 int seg3d_conv3d_k3_thin_out_bf16_fwd(const void* x_bf16, const float* wq, const float* bias, float* y,
                                       float* stats_partial, int N, int D, int H, int W, int Cin, int Cout, int CO,
                                       void* stream);
+/* the same head conv on the matrix cores (Cin in {16, 32}, Cout <= 3): x taps in the reduction dimension, (kz, ky)
+ * taps in the output dimension, weights as a bf16 hi + lo pair (fp32-grade); statistics slots as the thin_out kernel.
+ * replaces OutputBlock.conv1 = nn.Conv3d(in, out, 3, padding=1), network/module/vnet_outblock.py:13 */
+int seg3d_conv3d_k3_thin_out_mfma_supported(int Cin, int Cout);
+long long seg3d_thin_out_mfma_packed_elems(int Cin);
+int seg3d_pack_weights_thin_out_mfma(const float* w, void* wp_bf16, int A, int B, long long sa, long long sb, int flip,
+                                     void* stream);
+int seg3d_conv3d_k3_thin_out_mfma_fwd(const void* x_bf16, const void* wp_bf16, const float* bias, float* y,
+                                      float* stats_partial, int N, int D, int H, int W, int Cin, int Cout, void* stream);
 
 /* fp32 MFMA path for the stride-2 2x2x2 layers (Cin % 4 == 0): gather = Conv3d k2s2 forward / ConvTranspose3d dgrad,
  * scatter = ConvTranspose3d k2s2 forward / Conv3d k2s2 dgrad, pair-reduce = weight gradient of both */

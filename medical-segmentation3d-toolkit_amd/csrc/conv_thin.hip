@@ -524,6 +524,234 @@ static int thin_out_launch(const void* xv, int x_bf16, const float* wq, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Thin-output head on the matrix cores (bf16 activations).  The VALU kernel above spends 27 * Cin * Cout FMAs per voxel
+// and is VALU bound (215 us for the 96^3 32 -> 2 head on bf16 input, its HBM time is ~50 us).  Here the x taps go into
+// the reduction dimension and the (kz, ky) taps into the output dimension of ONE small GEMM per row block:
+//     P[v][(kz, ky, co)] = sum_{kx, ci} x[v + (kx - 1)][ci] * w[kz][ky][kx][ci][co]          (K = 3 Cin, 9 Cout <= 32 columns)
+//     y[z][y][x][co]     = sum_{kz, ky} P[(z + kz - 1, y + ky - 1, x)][(kz, ky, co)]           (9 Cout adds per voxel)
+// NDHWC makes x[v - 1 .. v + 1][0 .. Cin) ONE contiguous run, so a lane's 8-channel operand chunk of any K-step is a single
+// 16-byte global load -- the activations never pass through LDS.  The weights are the other MFMA operand, resident in
+// registers for the whole kernel, as a bf16 hi + lo pair (two MFMAs per K-step) so the head keeps fp32-grade weights
+// (2^-17) like the rest of the 2..5-channel tail.  Only P goes through LDS, wave-private and one halo plane at a time:
+// wave w owns output planes 2w, 2w+1 of the 8 x 8 x 16 tile, walks its 4 halo planes (5 row blocks of 2 rows x 16 x each)
+// and adds the 3 x 3 shifted P entries of each plane into 4 x Cout register accumulators per lane.  No __syncthreads in the
+// main loop.  The tile and the per-tile statistics slot are those of the VALU kernel.
+typedef __bf16 to_bf16x8 __attribute__((ext_vector_type(8)));
+
+// wp[2 (hi, lo)][KS][64 lanes][8]: lane l supplies row n = l & 31 = (kz * 3 + ky) * COUT + co, k = 16 ks + 8 (l >> 5) + j
+__global__ __launch_bounds__(256) void pack_thin_out_mfma_kernel(const float* __restrict__ w, seg3d_bf16* __restrict__ wp,
+                                                                   int A, int B, int COUT, i64 sa, i64 sb, int flip) {
+  const int KS = 3 * A / 16;
+  const int total = KS * 64 * 8;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int j = idx & 7, l = (idx >> 3) & 63, ks = idx >> 9;
+    const int nrow = l & 31, k = ks * 16 + 8 * (l >> 5) + j;
+    const int kx = k / A, ci = k - kx * A;
+    const int t9 = nrow / COUT, co = nrow - t9 * COUT;
+    float v = 0.f;
+    if (t9 < 9 && co < B) {
+      const int t = t9 * 3 + kx;
+      v = w[ci * sa + co * sb + (flip ? 26 - t : t)];
+    }
+    const seg3d_bf16 hi = seg3d_f2bf(v);
+    wp[idx] = hi;
+    wp[total + idx] = seg3d_f2bf(v - seg3d_bf2f(hi));
+  }
+}
+
+extern "C" int seg3d_conv3d_k3_thin_out_mfma_supported(int Cin, int Cout) {
+  return (Cin == 16 || Cin == 32) && Cout >= 1 && Cout <= 3;
+}
+
+extern "C" long long seg3d_thin_out_mfma_packed_elems(int Cin) { return 2ll * (3 * Cin / 16) * 64 * 8; }
+
+extern "C" int seg3d_pack_weights_thin_out_mfma(const float* w, void* wp_bf16, int A, int B, long long sa, long long sb,
+                                                int flip, void* stream) {
+  SEG3D_REQUIRE(w && wp_bf16 && seg3d_conv3d_k3_thin_out_mfma_supported(A, B),
+                "seg3d_pack_weights_thin_out_mfma: need Cin in {16, 32} and Cout <= 3");
+  const int total = (3 * A / 16) * 64 * 8;
+  hipLaunchKernelGGL(pack_thin_out_mfma_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     reinterpret_cast<seg3d_bf16*>(wp_bf16), A, B, B <= 2 ? 2 : 3, (i64)sa, (i64)sb, flip);
+  SEG3D_LAUNCH_CHECK("seg3d_pack_weights_thin_out_mfma");
+  return SEG3D_OK;
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, COUT == 2 ? 3 : 2) void conv3d_k3_thin_out_mfma_kernel(const seg3d_bf16* __restrict__ x,
+                                                                          const seg3d_bf16* __restrict__ wp,
+                                                                          const float* __restrict__ bias,
+                                                                          float* __restrict__ y, float* __restrict__ stats,
+                                                                          int N, int D, int H, int W, int Cout, int ntz,
+                                                                          int nty, int ntx) {
+  constexpr int KS = 3 * CIN / 16;             // K-steps of 16: kx = 16 ks / CIN, channels (16 ks) % CIN + 8 half ..
+  constexpr int NCOL = 9 * COUT;               // used rows of the 32-row MFMA result
+  constexpr int STR = (NCOL + 3) & ~3;         // floats per voxel of a P plane (20 / 28)
+  constexpr int ROW = TO_TX * STR + 4;         // floats per halo row (pad: the 8 ty rows of a read start 4 banks apart)
+  constexpr int PLANE = TO_HY * ROW;           // one halo plane of one wave (12.7 / 17.7 KB)
+  __shared__ __attribute__((aligned(16))) float pl[4 * PLANE];
+  const int tid = threadIdx.x;
+  int b = seg3d_xcd_tile(blockIdx.x, N * ntz * nty * ntx);
+  if (b < 0) return;
+  int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
+  const int tix = b - qd * ntx; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)nty);
+  const int tiy = b - qd * nty; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)ntz);
+  const int tiz = b - qd * ntz;
+  const int n = qd;
+  const int z0 = tiz * TO_TZ, y0 = tiy * TO_TY, x0 = tix * TO_TX;
+  const int wave = tid >> 6, lane = tid & 63, lh = lane >> 5, r = lane & 31;
+  float* __restrict__ pw = pl + wave * PLANE;
+
+  f32x4 whi[KS], wlo[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    whi[ks] = *reinterpret_cast<const f32x4*>(wp + ((i64)ks * 64 + lane) * 8);
+    wlo[ks] = *reinterpret_cast<const f32x4*>(wp + ((i64)(KS + ks) * 64 + lane) * 8);
+  }
+
+  // row block i = 5 p + mb of this wave: halo plane p (gz = z0 + 2 wave + p - 1), halo rows 2 mb, 2 mb + 1; lane row r is
+  // voxel (row 2 mb + (r >> 4), x = r & 15); K-step ks reads the 8 channels (16 ks) % CIN + 8 lh of the voxel at x + kx - 1
+  const int gx = x0 + (r & 15);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto block_voxel = [&](int i, bool& rowok) {
+    const int p = i / 5, mb = i - 5 * p;
+    const int gz = z0 + 2 * wave + p - 1;
+    const int gy = y0 + 2 * mb + (r >> 4) - 1;
+    rowok = gz >= 0 && gz < D && gy >= 0 && gy < H;
+    return ((n * D + gz) * H + gy) * W + gx;
+  };
+  auto load_chunk = [&](int vox, bool rowok, int ks) {
+    const int kx = (ks * 16) / CIN, ci = (ks * 16) % CIN + 8 * lh;
+    const int gxx = gx + kx - 1;
+    const bool ok = rowok && gxx >= 0 && gxx < W;
+    return ok ? *reinterpret_cast<const f32x4*>(x + (i64)(vox + kx - 1) * CIN + ci) : zero4;
+  };
+
+  const int tzl = lane >> 5, ty = (lane >> 2) & 7, xg = lane & 3;
+  float acc[4][COUT];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[o][c] = 0.f;
+
+  f32x4 a[KS];
+  {
+    bool ok0;
+    const int v0 = block_voxel(0, ok0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = load_chunk(v0, ok0, ks);
+  }
+#pragma unroll 1
+  for (int i = 0; i < 20; ++i) {
+    const int p = i / 5, mb = i - 5 * p;
+    bool nok;
+    const int nvox = block_voxel(i + 1 < 20 ? i + 1 : i, nok);
+    f32x16 c;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) c[v] = 0.f;
+    // one operand buffer: the chunk of the next row block is requested as soon as its two MFMAs have read the register
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, whi[ks]), __builtin_bit_cast(to_bf16x8, a[ks]),
+                                                  c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, wlo[ks]), __builtin_bit_cast(to_bf16x8, a[ks]),
+                                                  c, 0, 0, 0);
+      if (i + 1 < 20) a[ks] = load_chunk(nvox, nok, ks);
+    }
+    // result register 4 g + j is row 8 g + 4 lh + j (the (kz, ky, co) column of P) of voxel r
+    float* dst = pw + (2 * mb + (r >> 4)) * ROW + (r & 15) * STR;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (8 * g < NCOL) {
+        const int row0 = 8 * g + 4 * lh;
+        if (row0 < NCOL) {
+          const f32x4 v = {c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+          *reinterpret_cast<f32x4*>(dst + row0) = v;
+        }
+      }
+    }
+    if (mb == 4) {   // plane p complete: add its taps to the outputs of plane tzl (kz = p - tzl)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int kz = p - tzl;
+      if (kz >= 0 && kz <= 2) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* src = pw + (ty + ky) * ROW + (4 * xg) * STR + (kz * 3 + ky) * COUT;
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int cc = 0; cc < COUT; ++cc) acc[o][cc] += src[o * STR + cc];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+
+  float s[2] = {0.f, 0.f};
+  const int gz = z0 + 2 * wave + tzl, gy = y0 + ty;
+  if (gz < D && gy < H) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int gxo = x0 + 4 * xg + o;
+      if (gxo < W) {
+        float* yp = y + ((((i64)n * D + gz) * H + gy) * W + gxo) * Cout;
+#pragma unroll
+        for (int cc = 0; cc < COUT; ++cc) {
+          if (cc < Cout) {
+            const float val = acc[o][cc] + (bias ? bias[cc] : 0.f);
+            yp[cc] = val;
+            s[0] += val;
+            s[1] += val * val;
+          }
+        }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    block_sum_256<2>(s, pl);
+    if (tid == 0) {
+      const int tiles_per_sample = ntz * nty * ntx;
+      const int tile = (tiz * nty + tiy) * ntx + tix;
+      float* dst = stats + ((i64)n * tiles_per_sample + tile) * 2;
+      dst[0] = s[0];
+      dst[1] = s[1];
+    }
+  }
+}
+
+// x bf16 [N][D][H][W][Cin], wp = seg3d_pack_weights_thin_out_mfma, y fp32 [N][D][H][W][Cout]; stats as the VALU kernel
+extern "C" int seg3d_conv3d_k3_thin_out_mfma_fwd(const void* x_bf16, const void* wp_bf16, const float* bias, float* y,
+                                                 float* stats, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+  SEG3D_REQUIRE(x_bf16 && wp_bf16 && y, "seg3d_conv3d_k3_thin_out_mfma_fwd: null pointer");
+  SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "seg3d_conv3d_k3_thin_out_mfma_fwd: bad dims");
+  SEG3D_REQUIRE(seg3d_conv3d_k3_thin_out_mfma_supported(Cin, Cout),
+                "seg3d_conv3d_k3_thin_out_mfma_fwd: need Cin in {16, 32} and Cout <= 3");
+  SEG3D_REQUIRE((i64)N * D * H * W * Cin < (1ll << 31), "seg3d_conv3d_k3_thin_out_mfma_fwd: tensor exceeds 2^31 elements");
+  const int ntz = seg3d_cdiv(D, TO_TZ), nty = seg3d_cdiv(H, TO_TY), ntx = seg3d_cdiv(W, TO_TX);
+  SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "seg3d_conv3d_k3_thin_out_mfma_fwd: more than 2^22 tiles");
+  dim3 grid((unsigned)seg3d_xcd_grid(N * ntz * nty * ntx));
+  hipStream_t s = (hipStream_t)stream;
+  const seg3d_bf16* xp = reinterpret_cast<const seg3d_bf16*>(x_bf16);
+  const seg3d_bf16* wq = reinterpret_cast<const seg3d_bf16*>(wp_bf16);
+#define SEG3D_TO_MFMA(CI, CO)                                                                                              \
+  hipLaunchKernelGGL((conv3d_k3_thin_out_mfma_kernel<CI, CO>), grid, dim3(256), 0, s, xp, wq, bias, y, stats, N, D, H, W, \
+                     Cout, ntz, nty, ntx)
+  if (Cin == 32 && Cout <= 2) SEG3D_TO_MFMA(32, 2);
+  else if (Cin == 32) SEG3D_TO_MFMA(32, 3);
+  else if (Cout <= 2) SEG3D_TO_MFMA(16, 2);
+  else SEG3D_TO_MFMA(16, 3);
+#undef SEG3D_TO_MFMA
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_thin_out_mfma_fwd");
+  return SEG3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // thin weight gradient: G[t][ct][cf] = sum_u fat[u][cf] * thin[u + off(t)][ct]
 // ---------------------------------------------------------------------------------------------------------------
 // FAT_BF (bf16 mode, head weight gradient): the fat operand (the unit's bf16 input) is widened at the LDS store

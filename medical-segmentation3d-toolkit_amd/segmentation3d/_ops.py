@@ -33,6 +33,8 @@ _ACT_BF16 = [False]
 BF16_CONV_OUTPUT = os.environ.get('SEG3D_BF16_Y', '1') != '0'
 # bf16 mode, stride-2 layers: bf16 weight images + bf16 MFMA (SEG3D_K2_BF16_MFMA=0: fp32 images, input widened while staging)
 K2_BF16_MFMA = os.environ.get('SEG3D_K2_BF16_MFMA', '1') != '0'
+# bf16 mode, head conv (Cin 16/32 -> <= 3): small GEMM per row block on the matrix cores (SEG3D_THIN_OUT_MFMA=0: VALU kernel)
+THIN_OUT_MFMA = os.environ.get('SEG3D_THIN_OUT_MFMA', '1') != '0'
 
 
 def set_activation_dtype(name):
@@ -262,12 +264,18 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
                    E.ptr(ws), N, D, H, W_, A, B, int(out_bf16), E.stream_ptr())
             return y, stats
         if B <= 8 and A % 4 == 0 and addend is None and not FORCE_DIRECT:   # head forward on bf16 activations
-            CO = 2 if B <= 2 else (4 if B <= 4 else 8)
-            wq = _empty(((A + 7) // 8 * 27 * 8 * CO,), w)
-            E.call('seg3d_pack_weights_thin_out', E.ptr(w), E.ptr(wq), A, B, CO, sa, sb, flip, E.stream_ptr())
             stats = None
             if want_stats:
                 stats = _empty((N, E.query('seg3d_conv3d_k3_thin_out_stats_count', D, H, W_), 2), xn)
+            if THIN_OUT_MFMA and E.query('seg3d_conv3d_k3_thin_out_mfma_supported', A, B):
+                wq = torch.empty(E.query('seg3d_thin_out_mfma_packed_elems', A), dtype=torch.bfloat16, device=w.device)
+                E.call('seg3d_pack_weights_thin_out_mfma', E.ptr(w), E.ptr(wq), A, B, sa, sb, flip, E.stream_ptr())
+                E.call('seg3d_conv3d_k3_thin_out_mfma_fwd', E.ptr(xn), E.ptr(wq), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D,
+                       H, W_, A, B, E.stream_ptr())
+                return y, stats
+            CO = 2 if B <= 2 else (4 if B <= 4 else 8)
+            wq = _empty(((A + 7) // 8 * 27 * 8 * CO,), w)
+            E.call('seg3d_pack_weights_thin_out', E.ptr(w), E.ptr(wq), A, B, CO, sa, sb, flip, E.stream_ptr())
             E.call('seg3d_conv3d_k3_thin_out_bf16_fwd', E.ptr(xn), E.ptr(wq), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H,
                    W_, A, B, CO, E.stream_ptr())
             return y, stats

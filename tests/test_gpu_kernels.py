@@ -173,6 +173,46 @@ def test_conv3d_k3_bf16_fwd(hip_device, shape, with_addend):
            err_vs_fp32_conv=float((got - (F.conv3d(x.double(), w.double(), b.double(), padding=1) + (a.double() if with_addend else 0))).abs().max()))
 
 
+@pytest.mark.parametrize('shape', [(1, 32, 2, 8, 8, 16), (2, 32, 2, 16, 16, 32), (1, 32, 3, 5, 9, 11), (2, 16, 1, 6, 10, 18),
+                                   (1, 16, 3, 9, 7, 33), (1, 32, 2, 3, 2, 1), (1, 32, 2, 24, 24, 48)])
+@pytest.mark.parametrize('flip', [0, 1])
+def test_conv3d_k3_thin_out_mfma(hip_device, shape, flip):
+    """head conv on the matrix cores (bf16 activations, x taps in K, (kz, ky) taps in the output rows, weights as bf16
+    hi + lo): equals the conv of the bf16-rounded input with the fp32 weights (weight error 2^-17, tolerance 2e-5 of the
+    output scale -- the bound of the bf16 kernels whose weights are rounded), ragged tiles, flipped taps (the adjoint
+    form), no-bias / no-stats calls, and per-tile statistics equal to those of its own output"""
+    from segmentation3d import _ops, _engine as E
+    N, Cin, Cout, D, H, W = shape
+    assert E.query('seg3d_conv3d_k3_thin_out_mfma_supported', Cin, Cout) == 1
+    assert E.query('seg3d_conv3d_k3_thin_out_mfma_supported', 24, 2) == 0 and E.query('seg3d_conv3d_k3_thin_out_mfma_supported', 32, 4) == 0
+    x = _t(51, 'hx', (N, Cin, D, H, W))
+    w = _t(52, 'hw', (Cout, Cin, 3, 3, 3), std=0.05)
+    b = _t(53, 'hb', (Cout,), std=0.5)
+    xb = _ops.to_ndhwc(x.to(hip_device)).bfloat16()
+    wd = w.to(hip_device)
+    wp = torch.empty(E.query('seg3d_thin_out_mfma_packed_elems', Cin), dtype=torch.bfloat16, device=hip_device)
+    E.call('seg3d_pack_weights_thin_out_mfma', E.ptr(wd), E.ptr(wp), Cin, Cout, 27, Cin * 27, flip, E.stream_ptr())
+    y = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
+    cnt = E.query('seg3d_conv3d_k3_thin_out_stats_count', D, H, W)
+    st = torch.full((N, cnt, 2), float('nan'), device=hip_device)
+    bd = b.to(hip_device)
+    E.call('seg3d_conv3d_k3_thin_out_mfma_fwd', E.ptr(xb), E.ptr(wp), E.ptr(bd), E.ptr(y), E.ptr(st), N, D, H, W, Cin, Cout,
+           E.stream_ptr())
+    wref = w.flip(2, 3, 4) if flip else w
+    ref = F.conv3d(x.bfloat16().double(), wref.double(), b.double(), padding=1)
+    got = _ops.from_ndhwc(y).double().cpu()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 2e-5 * scale
+    s = st.double().sum(1).cpu()
+    rr = got.reshape(N, -1)
+    assert float(((s[:, 0] - rr.sum(1)).abs() / rr.abs().sum(1)).max()) < 1e-5 and rel_err(s[:, 1], (rr * rr).sum(1)) < 1e-5
+    y2 = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
+    E.call('seg3d_conv3d_k3_thin_out_mfma_fwd', E.ptr(xb), E.ptr(wp), None, E.ptr(y2), None, N, D, H, W, Cin, Cout, E.stream_ptr())
+    assert torch.equal(y2 + bd, y) or float((y2 + bd - y).abs().max()) < 1e-6 * scale
+    report('thin_out_mfma_{}x{}x{}x{}_{}_{}_flip{}'.format(N, D, H, W, Cin, Cout, flip), max_abs_err=float((got - ref).abs().max()),
+           out_scale=scale)
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 32, 4, 8, 8), (1, 64, 16, 3, 5, 6), (2, 128, 256, 2, 4, 8), (1, 32, 32, 6, 6, 6),
                                    (1, 24, 40, 2, 4, 8)])
 @pytest.mark.parametrize('transposed', [False, True])

@@ -1,5 +1,5 @@
 """micro-benchmark of single conv launches (events on the launch stream); used for kernel A/B work and PMC runs.
-usage: python tools/bench_conv.py [fwd|fwd16|wgrad|wgrad16|all] [N D H W Cin Cout] [--iters K]   (fwd16 / wgrad16 = bf16-input kernels)"""
+usage: python tools/bench_conv.py [fwd|fwd16|head16|wgrad|wgrad16|all] [N D H W Cin Cout] [--iters K]   (fwd16 / wgrad16 = bf16-input kernels)"""
 import os, sys, time
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,6 +33,19 @@ def run(kind, N, D, H, W, Cin, Cout, iters=10):
         st = torch.empty(N, cnt, 2, device=dev)
         print('variant', E.query('seg3d_conv3d_k3_bf16_variant', N, D, H, W, Cin, Cout), 'ks', nws // (N * D * H * W * Cout))
         fn = lambda: E.call('seg3d_conv3d_k3_bf16_fwd', E.ptr(xb), E.ptr(wp), E.ptr(b), None, E.ptr(y), E.ptr(st), E.ptr(wsp), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
+    elif kind == 'head16':   # thin-output head on bf16 activations: MFMA kernel, or the VALU kernel with --valu
+        xb = x.bfloat16()
+        y = torch.empty(N, D, H, W, Cout, device=dev)
+        st = torch.empty(N, E.query('seg3d_conv3d_k3_thin_out_stats_count', D, H, W), 2, device=dev)
+        if '--valu' in sys.argv:
+            CO = 2 if Cout <= 2 else (4 if Cout <= 4 else 8)
+            wq = torch.empty((Cin + 7) // 8 * 27 * 8 * CO, device=dev)
+            E.call('seg3d_pack_weights_thin_out', E.ptr(w), E.ptr(wq), Cin, Cout, CO, 27, Cin * 27, 0, E.stream_ptr())
+            fn = lambda: E.call('seg3d_conv3d_k3_thin_out_bf16_fwd', E.ptr(xb), E.ptr(wq), E.ptr(b), E.ptr(y), E.ptr(st), N, D, H, W, Cin, Cout, CO, E.stream_ptr())
+        else:
+            wq = torch.empty(E.query('seg3d_thin_out_mfma_packed_elems', Cin), dtype=torch.bfloat16, device=dev)
+            E.call('seg3d_pack_weights_thin_out_mfma', E.ptr(w), E.ptr(wq), Cin, Cout, 27, Cin * 27, 0, E.stream_ptr())
+            fn = lambda: E.call('seg3d_conv3d_k3_thin_out_mfma_fwd', E.ptr(xb), E.ptr(wq), E.ptr(b), E.ptr(y), E.ptr(st), N, D, H, W, Cin, Cout, E.stream_ptr())
     elif kind == 'wgrad16':
         xb, dyb = x.bfloat16(), dy.bfloat16()
         ws = torch.empty(E.query('seg3d_conv3d_k3_bf16_wgrad_workspace_floats', N, D, H, W, Cin, Cout), device=dev)

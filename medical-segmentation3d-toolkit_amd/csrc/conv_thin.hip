@@ -529,13 +529,16 @@ static int thin_out_launch(const void* xv, int x_bf16, const float* wq, const fl
 // the reduction dimension and the (kz, ky) taps into the output dimension of ONE small GEMM per row block:
 //     P[v][(kz, ky, co)] = sum_{kx, ci} x[v + (kx - 1)][ci] * w[kz][ky][kx][ci][co]          (K = 3 Cin, 9 Cout <= 32 columns)
 //     y[z][y][x][co]     = sum_{kz, ky} P[(z + kz - 1, y + ky - 1, x)][(kz, ky, co)]           (9 Cout adds per voxel)
-// NDHWC makes x[v - 1 .. v + 1][0 .. Cin) ONE contiguous run, so a lane's 8-channel operand chunk of any K-step is a single
-// 16-byte global load -- the activations never pass through LDS.  The weights are the other MFMA operand, resident in
-// registers for the whole kernel, as a bf16 hi + lo pair (two MFMAs per K-step) so the head keeps fp32-grade weights
-// (2^-17) like the rest of the 2..5-channel tail.  Only P goes through LDS, wave-private and one halo plane at a time:
-// wave w owns output planes 2w, 2w+1 of the 8 x 8 x 16 tile, walks its 4 halo planes (5 row blocks of 2 rows x 16 x each)
-// and adds the 3 x 3 shifted P entries of each plane into 4 x Cout register accumulators per lane.  No __syncthreads in the
-// main loop.  The tile and the per-tile statistics slot are those of the VALU kernel.
+// NDHWC makes x[v - 1 .. v + 1][0 .. Cin) ONE contiguous run, so a lane's 8-channel operand chunk of any K-step is a
+// 16-byte piece of global memory: the kernel loads the voxel itself once and takes its x neighbours from the
+// neighbouring lanes (DPP row shifts) -- the activations never pass through LDS.  The weights are the other MFMA
+// operand, resident in registers for the whole kernel, as a bf16 hi + lo pair (two MFMAs per K-step) so the head keeps
+// fp32-grade weights (2^-17) like the rest of the 2..5-channel tail.  Only P goes through LDS, wave-private and one halo
+// plane at a time.  ONE WAVE owns one 8 x 8 x 16 tile (the tile and statistics slot of the VALU kernel; a workgroup is
+// four independent waves, no barrier anywhere): it walks the 10 halo planes in z, 5 row blocks (2 rows x 16 x) each,
+// and after each plane adds the plane's 3 x 3 shifted P entries into three rolling accumulator sets -- output planes
+// p, p - 1, p - 2 take the plane's kz = 0, 1, 2 taps -- then stores the finished plane p - 2 (16 bytes per lane) and
+// rotates.  Per output voxel: 50 / 1024 row blocks (z halo 10 / 8, y halo 10 / 8), 18 LDS floats read, 18 adds.
 typedef __bf16 to_bf16x8 __attribute__((ext_vector_type(8)));
 
 // wp[2 (hi, lo)][KS][64 lanes][8]: lane l supplies row n = l & 31 = (kz * 3 + ky) * COUT + co, k = 16 ks + 8 (l >> 5) + j
@@ -576,22 +579,34 @@ extern "C" int seg3d_pack_weights_thin_out_mfma(const float* w, void* wp_bf16, i
   return SEG3D_OK;
 }
 
+#ifndef SEG3D_HEAD_RING
+#define SEG3D_HEAD_RING 2
+#endif
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, COUT == 2 ? 3 : 2) void conv3d_k3_thin_out_mfma_kernel(const seg3d_bf16* __restrict__ x,
-                                                                          const seg3d_bf16* __restrict__ wp,
-                                                                          const float* __restrict__ bias,
-                                                                          float* __restrict__ y, float* __restrict__ stats,
-                                                                          int N, int D, int H, int W, int Cout, int ntz,
-                                                                          int nty, int ntx) {
-  constexpr int KS = 3 * CIN / 16;             // K-steps of 16: kx = 16 ks / CIN, channels (16 ks) % CIN + 8 half ..
+                                                                                         const seg3d_bf16* __restrict__ wp,
+                                                                                         const float* __restrict__ bias,
+                                                                                         float* __restrict__ y,
+                                                                                         float* __restrict__ stats, int N,
+                                                                                         int D, int H, int W, int Cout,
+                                                                                         int ntz, int nty, int ntx) {
+  constexpr int KS = 3 * CIN / 16;             // K-steps of 16: ks = kx * KC + j, channels 16 j + 8 half ..
+  constexpr int KC = CIN / 16;
   constexpr int NCOL = 9 * COUT;               // used rows of the 32-row MFMA result
   constexpr int STR = (NCOL + 3) & ~3;         // floats per voxel of a P plane (20 / 28)
   constexpr int ROW = TO_TX * STR + 4;         // floats per halo row (pad: the 8 ty rows of a read start 4 banks apart)
   constexpr int PLANE = TO_HY * ROW;           // one halo plane of one wave (12.7 / 17.7 KB)
+  constexpr int NBLK = 5 * (TO_TZ + 2);        // row blocks of a tile
+  constexpr int RING = SEG3D_HEAD_RING;        // row blocks in flight (registers)
+  static_assert(NBLK % RING == 0, "the row blocks of a tile are walked in groups of RING");
   __shared__ __attribute__((aligned(16))) float pl[4 * PLANE];
   const int tid = threadIdx.x;
-  int b = seg3d_xcd_tile(blockIdx.x, N * ntz * nty * ntx);
-  if (b < 0) return;
+  const int wave = tid >> 6, lane = tid & 63, lh = lane >> 5, r = lane & 31;
+  const int ntiles = N * ntz * nty * ntx;
+  const int wg = seg3d_xcd_tile(blockIdx.x, (ntiles + 3) >> 2);   // neighbouring tiles on one XCD
+  if (wg < 0) return;
+  int b = wg * 4 + wave;                       // the wave's tile (x fastest)
+  if (b >= ntiles) return;
   int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
   const int tix = b - qd * ntx; b = qd;
   qd = seg3d_fdiv(b, 1.0f / (float)nty);
@@ -600,7 +615,6 @@ __global__ __launch_bounds__(256, COUT == 2 ? 3 : 2) void conv3d_k3_thin_out_mfm
   const int tiz = b - qd * ntz;
   const int n = qd;
   const int z0 = tiz * TO_TZ, y0 = tiy * TO_TY, x0 = tix * TO_TX;
-  const int wave = tid >> 6, lane = tid & 63, lh = lane >> 5, r = lane & 31;
   float* __restrict__ pw = pl + wave * PLANE;
 
   f32x4 whi[KS], wlo[KS];
@@ -610,112 +624,181 @@ __global__ __launch_bounds__(256, COUT == 2 ? 3 : 2) void conv3d_k3_thin_out_mfm
     wlo[ks] = *reinterpret_cast<const f32x4*>(wp + ((i64)(KS + ks) * 64 + lane) * 8);
   }
 
-  // row block i = 5 p + mb of this wave: halo plane p (gz = z0 + 2 wave + p - 1), halo rows 2 mb, 2 mb + 1; lane row r is
-  // voxel (row 2 mb + (r >> 4), x = r & 15); K-step ks reads the 8 channels (16 ks) % CIN + 8 lh of the voxel at x + kx - 1
+  // row block i = 5 p + mb: halo plane p (gz = z0 + p - 1), halo rows 2 mb, 2 mb + 1; lane row r is the voxel
+  // (row 2 mb + (r >> 4), x = r & 15), lane half lh its channels 16 j + 8 lh ..
   const int gx = x0 + (r & 15);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto block_voxel = [&](int i, bool& rowok) {
     const int p = i / 5, mb = i - 5 * p;
-    const int gz = z0 + 2 * wave + p - 1;
+    const int gz = z0 + p - 1;
     const int gy = y0 + 2 * mb + (r >> 4) - 1;
     rowok = gz >= 0 && gz < D && gy >= 0 && gy < H;
     return ((n * D + gz) * H + gy) * W + gx;
   };
-  auto load_chunk = [&](int vox, bool rowok, int ks) {
-    const int kx = (ks * 16) / CIN, ci = (ks * 16) % CIN + 8 * lh;
-    const int gxx = gx + kx - 1;
-    const bool ok = rowok && gxx >= 0 && gxx < W;
-    return ok ? *reinterpret_cast<const f32x4*>(x + (i64)(vox + kx - 1) * CIN + ci) : zero4;
+  // operands of a row block: ONE load of the voxel's own channels (the kx = 1 K-steps); the kx = 0 / kx = 2 operands are
+  // the same registers of the neighbouring lane (DPP row shift inside the 16-lane x row), and only the two end lanes of
+  // a row need their outside neighbour (x0 - 1 / x0 + 16).  Loads are unconditional (an invalid voxel reads the tensor's
+  // first bytes and is zeroed when it is consumed): with no branch around them the compiler can count them, so the wait
+  // in front of a row block is a counted vmcnt that leaves the later blocks of the ring in flight.
+  const int edge_dx = (r & 15) == 0 ? -1 : ((r & 15) == 15 ? 1 : 0);
+  const int edge_gx = gx + edge_dx;
+  const bool centre_in = gx < W, edge_in = edge_dx != 0 && edge_gx >= 0 && edge_gx < W;
+  auto load_centre = [&](int vox, bool rowok, int j) {
+    return *reinterpret_cast<const f32x4*>(x + ((rowok && centre_in) ? (i64)vox * CIN : (i64)0) + j * 16 + 8 * lh);
+  };
+  auto load_edge = [&](int vox, bool rowok, int j) {
+    return *reinterpret_cast<const f32x4*>(x + ((rowok && edge_in) ? (i64)(vox + edge_dx) * CIN : (i64)0) + j * 16 + 8 * lh);
+  };
+  auto shift_x = [&](const f32x4& cen, const f32x4& edge, f32x4& left, f32x4& right) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int cv = __float_as_int(cen[d]), ev = __float_as_int(edge[d]);
+      left[d] = __int_as_float(__builtin_amdgcn_update_dpp(ev, cv, 0x111, 0xf, 0xf, false));    // row_shr:1: lane i <- i - 1
+      right[d] = __int_as_float(__builtin_amdgcn_update_dpp(ev, cv, 0x101, 0xf, 0xf, false));   // row_shl:1: lane i <- i + 1
+    }
   };
 
-  const int tzl = lane >> 5, ty = (lane >> 2) & 7, xg = lane & 3;
-  float acc[4][COUT];
+  // outputs of a lane: (ty, x = 2 xp, 2 xp + 1) of the planes in flight; acc[k] is output plane p - k (taps kz = k)
+  const int ty = lane >> 3, xp = lane & 7;
+  float acc[3][2][COUT];
 #pragma unroll
-  for (int o = 0; o < 4; ++o)
+  for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[o][c] = 0.f;
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) acc[k][o][c] = 0.f;
+  float bv[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) bv[c] = (bias && c < Cout) ? bias[c] : 0.f;
+  float s[2] = {0.f, 0.f};
+  const int oy = y0 + ty, ox = x0 + 2 * xp;
 
-  f32x4 a[KS];
-  {
-    bool ok0;
-    const int v0 = block_voxel(0, ok0);
+  f32x4 cc[RING][KC], ee[RING][KC];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a[ks] = load_chunk(v0, ok0, ks);
+  for (int sl = 0; sl < RING; ++sl) {
+    bool ok0;
+    const int v0 = block_voxel(sl, ok0);
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      cc[sl][j] = load_centre(v0, ok0, j);
+      ee[sl][j] = load_edge(v0, ok0, j);
+    }
   }
 #pragma unroll 1
-  for (int i = 0; i < 20; ++i) {
-    const int p = i / 5, mb = i - 5 * p;
-    bool nok;
-    const int nvox = block_voxel(i + 1 < 20 ? i + 1 : i, nok);
-    f32x16 c;
+  for (int i0 = 0; i0 < NBLK; i0 += RING) {
 #pragma unroll
-    for (int v = 0; v < 16; ++v) c[v] = 0.f;
-    // one operand buffer: the chunk of the next row block is requested as soon as its two MFMAs have read the register
+    for (int sl = 0; sl < RING; ++sl) {
+      const int i = i0 + sl;
+      const int p = i / 5, mb = i - 5 * p;
+      bool cok, nok;
+      block_voxel(i, cok);
+      const int nvox = block_voxel(i + RING < NBLK ? i + RING : i, nok);
+      f32x4 a[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, whi[ks]), __builtin_bit_cast(to_bf16x8, a[ks]),
-                                                  c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, wlo[ks]), __builtin_bit_cast(to_bf16x8, a[ks]),
-                                                  c, 0, 0, 0);
-      if (i + 1 < 20) a[ks] = load_chunk(nvox, nok, ks);
-    }
-    // result register 4 g + j is row 8 g + 4 lh + j (the (kz, ky, co) column of P) of voxel r
-    float* dst = pw + (2 * mb + (r >> 4)) * ROW + (r & 15) * STR;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (8 * g < NCOL) {
-        const int row0 = 8 * g + 4 * lh;
-        if (row0 < NCOL) {
-          const f32x4 v = {c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
-          *reinterpret_cast<f32x4*>(dst + row0) = v;
-        }
+      for (int j = 0; j < KC; ++j) {
+        const f32x4 cen = (cok && centre_in) ? cc[sl][j] : zero4;
+        const f32x4 edg = (cok && edge_in) ? ee[sl][j] : zero4;
+        shift_x(cen, edg, a[j], a[2 * KC + j]);
+        a[KC + j] = cen;
       }
-    }
-    if (mb == 4) {   // plane p complete: add its taps to the outputs of plane tzl (kz = p - tzl)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int kz = p - tzl;
-      if (kz >= 0 && kz <= 2) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const float* src = pw + (ty + ky) * ROW + (4 * xg) * STR + (kz * 3 + ky) * COUT;
-#pragma unroll
-          for (int o = 0; o < 4; ++o)
-#pragma unroll
-            for (int cc = 0; cc < COUT; ++cc) acc[o][cc] += src[o * STR + cc];
-        }
+      for (int j = 0; j < KC; ++j) {   // block i + RING (the last RING blocks re-request themselves: no branch around a load)
+        cc[sl][j] = load_centre(nvox, nok, j);
+        ee[sl][j] = load_edge(nvox, nok, j);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-  }
-
-  float s[2] = {0.f, 0.f};
-  const int gz = z0 + 2 * wave + tzl, gy = y0 + ty;
-  if (gz < D && gy < H) {
+      f32x16 c;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int gxo = x0 + 4 * xg + o;
-      if (gxo < W) {
-        float* yp = y + ((((i64)n * D + gz) * H + gy) * W + gxo) * Cout;
+      for (int v = 0; v < 16; ++v) c[v] = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < COUT; ++cc) {
-          if (cc < Cout) {
-            const float val = acc[o][cc] + (bias ? bias[cc] : 0.f);
-            yp[cc] = val;
-            s[0] += val;
-            s[1] += val * val;
+      for (int ks = 0; ks < KS; ++ks) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, whi[ks]),
+                                                    __builtin_bit_cast(to_bf16x8, a[ks]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, wlo[ks]),
+                                                    __builtin_bit_cast(to_bf16x8, a[ks]), c, 0, 0, 0);
+      }
+      // result register 4 g + j is row 8 g + 4 lh + j (the (kz, ky, co) column of P) of voxel r
+      float* dst = pw + (2 * mb + (r >> 4)) * ROW + (r & 15) * STR;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (8 * g < NCOL) {
+          const int row0 = 8 * g + 4 * lh;
+          if (row0 < NCOL) {
+            const f32x4 v = {c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(dst + row0) = v;
           }
         }
       }
+      if (mb == 4) {   // halo plane p is complete in LDS (wave-private: ordering inside the wave is all that is needed)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz) {
+          if (p - kz >= 0 && p - kz < TO_TZ) {   // wave-uniform
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              const float* src = pw + (ty + ky) * ROW + (2 * xp) * STR + (kz * 3 + ky) * COUT;
+#pragma unroll
+              for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int cq = 0; cq < COUT; ++cq) acc[kz][o][cq] += src[o * STR + cq];
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int oz = z0 + p - 2;   // output plane p - 2 has all three kz taps now
+        if (p >= 2 && oz < D && oy < H) {
+          float* yp = y + ((((i64)n * D + oz) * H + oy) * W + ox) * Cout;
+          float val[2][COUT];
+#pragma unroll
+          for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int cq = 0; cq < COUT; ++cq) val[o][cq] = acc[2][o][cq] + bv[cq];
+          if (COUT == 2 && Cout == 2 && ox + 1 < W && (W & 1) == 0) {   // 16 bytes, aligned (even row length, even x)
+            const f32x4 v = {val[0][0], val[0][COUT - 1], val[1][0], val[1][COUT - 1]};
+            *reinterpret_cast<f32x4*>(yp) = v;
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+              for (int cq = 0; cq < COUT; ++cq) {
+                s[0] += val[o][cq];
+                s[1] += val[o][cq] * val[o][cq];
+              }
+          } else {
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+              if (ox + o < W) {
+#pragma unroll
+                for (int cq = 0; cq < COUT; ++cq)
+                  if (cq < Cout) {
+                    yp[o * Cout + cq] = val[o][cq];
+                    s[0] += val[o][cq];
+                    s[1] += val[o][cq] * val[o][cq];
+                  }
+              }
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int cq = 0; cq < COUT; ++cq) {
+            acc[2][o][cq] = acc[1][o][cq];
+            acc[1][o][cq] = acc[0][o][cq];
+            acc[0][o][cq] = 0.f;
+          }
+      }
     }
   }
-  if (stats) {
-    __syncthreads();
-    block_sum_256<2>(s, pl);
-    if (tid == 0) {
+
+  if (stats) {   // one slot per tile = per wave
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      s[0] += __shfl_xor(s[0], m, 64);
+      s[1] += __shfl_xor(s[1], m, 64);
+    }
+    if (lane == 0) {
       const int tiles_per_sample = ntz * nty * ntx;
       const int tile = (tiz * nty + tiy) * ntx + tix;
       float* dst = stats + ((i64)n * tiles_per_sample + tile) * 2;
@@ -735,7 +818,7 @@ extern "C" int seg3d_conv3d_k3_thin_out_mfma_fwd(const void* x_bf16, const void*
   SEG3D_REQUIRE((i64)N * D * H * W * Cin < (1ll << 31), "seg3d_conv3d_k3_thin_out_mfma_fwd: tensor exceeds 2^31 elements");
   const int ntz = seg3d_cdiv(D, TO_TZ), nty = seg3d_cdiv(H, TO_TY), ntx = seg3d_cdiv(W, TO_TX);
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "seg3d_conv3d_k3_thin_out_mfma_fwd: more than 2^22 tiles");
-  dim3 grid((unsigned)seg3d_xcd_grid(N * ntz * nty * ntx));
+  dim3 grid((unsigned)seg3d_xcd_grid((N * ntz * nty * ntx + 3) / 4));   // one tile per wave, four waves per workgroup
   hipStream_t s = (hipStream_t)stream;
   const seg3d_bf16* xp = reinterpret_cast<const seg3d_bf16*>(x_bf16);
   const seg3d_bf16* wq = reinterpret_cast<const seg3d_bf16*>(wp_bf16);

@@ -958,6 +958,175 @@ __device__ __forceinline__ void k3_thin_wgrad_body(const float* __restrict__ thi
   }
 }
 
+// bf16 mode, head weight gradient on the bf16 matrix cores: same tiles, slabs and reduce as above, but the voxel (K)
+// dimension is fed 16 per v_mfma_f32_32x32x16_bf16 instead of 2 per fp32 MFMA (the fp32 version is bound by its 64
+// MFMAs + 96 scalar LDS reads per wave and tile).  A lane's operand is 8 consecutive voxels = one x row of the 4 x 8 x 8
+// tile, so both tiles sit in LDS with x fastest:
+//   fat  (bf16 input):   fsT[cf][256 voxels], transposed in registers -- a thread loads the 8 voxels of one row for its 4
+//                        channels and writes four 16-byte rows;
+//   thin (fp32 dy):      three x-shifted planar copies tsP[kx][ct][halo row][8] so that every tap's row starts 16-byte
+//                        aligned, as a bf16 hi + lo pair (two MFMAs into the same accumulator): the 2..5-channel tail
+//                        keeps fp32-grade operands (2^-17), the fat operand is bf16 in memory already.
+// Rows of the last row block beyond 27 CT read tap 0 again; the reduce kernel never looks at them.
+#define THB_FS (TH_MT + 8)   // fsT row stride in bf16 (528 bytes: 16-byte reads of 16 lanes cover all banks)
+template <int CT>
+__global__ __launch_bounds__(256, 2) void k3_thin_wgrad_bf16_mfma_kernel(const float* __restrict__ thin,
+                                                                          const seg3d_bf16* __restrict__ fat,
+                                                                          float* __restrict__ part, int N, int D, int H, int W,
+                                                                          int CF, int ntz, int nty, int ntx, int ntiles) {
+  constexpr int ROWS = 27 * CT;
+  constexpr int RB = (ROWS + 31) / 32;
+  constexpr int HR = (TH_TZ + 2) * TH_HY;           // 60 halo rows
+  constexpr int TSP = 3 * CT * HR * 8;              // bf16 elements of one (hi or lo) set of shifted planar copies
+  constexpr int LDS_A = 32 * THB_FS * 2 + 2 * TSP * 2;   // bytes: fsT + tsP(hi, lo)
+  constexpr int LDS_B = 4 * 1024 * 4;                    // bytes: the final 4-wave reduce
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_A > LDS_B ? LDS_A : LDS_B];
+  seg3d_bf16* fsT = reinterpret_cast<seg3d_bf16*>(lds_raw);
+  seg3d_bf16* tsP = fsT + 32 * THB_FS;
+  float* red = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int cf0 = blockIdx.y * 32;
+  int roff[RB];   // start of the row's x row 0 in tsP (bf16 elements)
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    int i = rb * 32 + li;
+    if (i >= ROWS) i = 0;
+    const int t = i / CT, a = i % CT;
+    const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+    roff[rb] = ((kx * CT + a) * HR + kz * TH_HY + ky) * 8;
+  }
+  f32x16 acc[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+  const int q = tid & 7, frow = tid >> 3;           // fat: channels cf0 + 4 q .., x row frow = tz * 8 + ty, voxels tx = k
+  const bool fq_ok = cf0 + 4 * q < CF;
+
+  constexpr int TE = (TH_NV * CT + 255) / 256, FE = TH_TX;
+  float tst[TE];
+  uint2 fst[FE];
+  static_assert(TE + FE <= 32, "okmask is 32 bits");
+  unsigned okmask = 0;
+  auto load_tile = [&](int tile) {
+    int b = tile;
+    const int tix = b % ntx; b /= ntx;
+    const int tiy = b % nty; b /= nty;
+    const int tiz = b % ntz;
+    const int n = b / ntz;
+    const int z0 = tiz * TH_TZ, y0 = tiy * TH_TY, x0 = tix * TH_TX;
+    okmask = 0;
+#pragma unroll
+    for (int k = 0; k < TE; ++k) {
+      const int e = tid + k * 256;
+      const int v = e / CT, a = e % CT;
+      const int hx = v % TH_HX;
+      const int t = v / TH_HX;
+      const int hy = t % TH_HY;
+      const int hz = t / TH_HY;
+      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const bool ok = e < TH_NV * CT && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      tst[k] = thin[ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * CT + a : (i64)0];
+      okmask |= (ok ? 1u : 0u) << k;
+    }
+    const int gz = z0 + (frow >> 3), gy = y0 + (frow & 7);
+    const bool rok = fq_ok && gz < D && gy < H;
+    const i64 rbase = ((((i64)n * D + gz) * H + gy) * W + x0) * CF + cf0 + 4 * q;
+#pragma unroll
+    for (int k = 0; k < FE; ++k) {
+      const bool ok = rok && x0 + k < W;
+      fst[k] = *reinterpret_cast<const uint2*>(fat + (ok ? rbase + (i64)k * CF : (i64)0));
+      okmask |= (ok ? 1u : 0u) << (TE + k);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < TE; ++k) {
+      const int e = tid + k * 256;
+      if (e < TH_NV * CT) {
+        const int v = e / CT, a = e % CT;
+        const int hx = v % TH_HX, hrow = v / TH_HX;
+        const float val = ((okmask >> k) & 1u) ? tst[k] : 0.f;
+        const seg3d_bf16 hi = seg3d_f2bf(val);
+        const seg3d_bf16 lo = seg3d_f2bf(val - seg3d_bf2f(hi));
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int txp = hx - kx;
+          if (txp >= 0 && txp < TH_TX) {
+            const int idx = ((kx * CT + a) * HR + hrow) * 8 + txp;
+            tsP[idx] = hi;
+            tsP[TSP + idx] = lo;
+          }
+        }
+      }
+    }
+    // 8 voxels x 4 channels -> 4 channels x 8 voxels (bf16 pairs): out[c] dword j = voxel 2j | voxel 2j + 1 << 16
+    unsigned d0[FE], d1[FE];
+#pragma unroll
+    for (int k = 0; k < FE; ++k) {
+      const bool ok = (okmask >> (TE + k)) & 1u;
+      d0[k] = ok ? fst[k].x : 0u;
+      d1[k] = ok ? fst[k].y : 0u;
+    }
+    uint4 o[4];
+    unsigned* ow = reinterpret_cast<unsigned*>(o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ow[0 * 4 + j] = (d0[2 * j] & 0xffffu) | (d0[2 * j + 1] << 16);
+      ow[1 * 4 + j] = (d0[2 * j] >> 16) | (d0[2 * j + 1] & 0xffff0000u);
+      ow[2 * 4 + j] = (d1[2 * j] & 0xffffu) | (d1[2 * j + 1] << 16);
+      ow[3 * 4 + j] = (d1[2 * j] >> 16) | (d1[2 * j + 1] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(fsT + (4 * q + c) * THB_FS + frow * 8) = o[c];
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    // K (voxels) is split over the waves: wave w takes plane tz = w, K-step s its x rows ty = 2 s + lh
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int ty = 2 * st + lh;
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(fsT + li * THB_FS + (wave * 8 + ty) * 8);
+      const int ub = (wave * TH_HY + ty) * 8;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const f32x4 ah = *reinterpret_cast<const f32x4*>(tsP + roff[rb] + ub);
+        const f32x4 al = *reinterpret_cast<const f32x4*>(tsP + TSP + roff[rb] + ub);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, ah), __builtin_bit_cast(to_bf16x8, bq),
+                                                          acc[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, al), __builtin_bit_cast(to_bf16x8, bq),
+                                                          acc[rb], 0, 0, 0);
+      }
+    }
+  }
+  // reduce the 4 waves' accumulators through LDS (fixed order) and write this workgroup's slab [RB*32][32]
+  float* dst = part + ((i64)blockIdx.x * gridDim.y + blockIdx.y) * RB * 1024;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave * 1024 + thin_row(r, lh) * 32 + li] = acc[rb][r];
+    __syncthreads();
+    for (int k = tid; k < 1024; k += 256) dst[rb * 1024 + k] = (red[k] + red[1024 + k]) + (red[2048 + k] + red[3072 + k]);
+  }
+}
+
+static int seg3d_thin_wgrad_bf16_mfma_enabled() {   // SEG3D_THIN_WGRAD_BF16_MFMA=0: fp32-MFMA kernel on the widened operand
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEG3D_THIN_WGRAD_BF16_MFMA");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 // dw[ct*s_ct + cf*s_cf + (flip ? 26 - t : t)] = sum_slab part[slab][cfb][row = t*CT + ct][cf % 32]
 // 16 outputs x 16 slab groups per workgroup (the output is tiny: the reduction over <= 512 slabs is the work),
 // combined through LDS in a fixed order.
@@ -1019,7 +1188,10 @@ template <int CT>
 static void launch_thin_wgrad(const float* thin, const void* fat, int fat_bf16, float* part, int N, int D, int H, int W,
                               int CF, int slabs, hipStream_t s) {
   const int ntz = seg3d_cdiv(D, TH_TZ), nty = seg3d_cdiv(H, TH_TY), ntx = seg3d_cdiv(W, TH_TX);
-  if (fat_bf16)
+  if (fat_bf16 && seg3d_thin_wgrad_bf16_mfma_enabled())
+    hipLaunchKernelGGL((k3_thin_wgrad_bf16_mfma_kernel<CT>), dim3(slabs, (CF + 31) / 32), dim3(256), 0, s, thin,
+                       reinterpret_cast<const seg3d_bf16*>(fat), part, N, D, H, W, CF, ntz, nty, ntx, N * ntz * nty * ntx);
+  else if (fat_bf16)
     hipLaunchKernelGGL((k3_thin_wgrad_fatbf16_kernel<CT>), dim3(slabs, (CF + 31) / 32), dim3(256), 0, s, thin, fat, part, N,
                        D, H, W, CF, ntz, nty, ntx, N * ntz * nty * ntx);
   else

@@ -213,6 +213,34 @@ def test_conv3d_k3_thin_out_mfma(hip_device, shape, flip):
            out_scale=scale)
 
 
+@pytest.mark.parametrize('shape', [(1, 32, 2, 4, 8, 8), (2, 32, 2, 12, 16, 24), (1, 32, 3, 5, 9, 11), (2, 16, 1, 6, 10, 18),
+                                   (1, 16, 5, 3, 7, 9), (1, 64, 8, 4, 8, 16), (1, 32, 2, 2, 1, 3)])
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_k3_thin_wgrad_fatbf16(hip_device, shape, accumulate):
+    """head weight gradient in bf16 mode (thin = fp32 dy with <= 8 channels, fat = the bf16 input) on the bf16 matrix
+    cores with dy as a bf16 hi + lo pair: equals the exact weight gradient of the bf16 input and the fp32 dy to 2e-5 of
+    the gradient scale; ragged tiles, accumulate flag"""
+    from segmentation3d import _ops, _engine as E
+    N, Cin, Cout, D, H, W = shape
+    x = _t(61, 'gx', (N, Cin, D, H, W))
+    dy = _t(62, 'gdy', (N, Cout, D, H, W))
+    base = _t(63, 'gbase', (Cout, Cin, 3, 3, 3))
+    xb = _ops.to_ndhwc(x.to(hip_device)).bfloat16()
+    dyn = _ops.to_ndhwc(dy.to(hip_device))
+    dw = base.to(hip_device).clone() if accumulate else torch.full((Cout, Cin, 3, 3, 3), float('nan'), device=hip_device)
+    ws = torch.empty(E.query('seg3d_k3_thin_wgrad_workspace_floats', N, D, H, W, Cout, Cin), device=hip_device)
+    E.call('seg3d_k3_thin_wgrad_fatbf16', E.ptr(dyn), E.ptr(xb), E.ptr(dw), E.ptr(ws), N, D, H, W, Cout, Cin, Cin * 27, 27, 1,
+           int(accumulate), E.stream_ptr())
+    wz = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.double, requires_grad=True)
+    (F.conv3d(x.bfloat16().double(), wz, None, padding=1) * dy.double()).sum().backward()
+    ref = wz.grad + (base.double() if accumulate else 0)
+    got = dw.double().cpu()
+    scale = float(wz.grad.abs().max())
+    assert float((got - ref).abs().max()) < 2e-5 * scale
+    report('thin_wgrad_fatbf16_{}x{}x{}x{}_{}_{}{}'.format(N, D, H, W, Cin, Cout, '_acc' if accumulate else ''),
+           max_abs_err=float((got - ref).abs().max()), grad_scale=scale)
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 32, 4, 8, 8), (1, 64, 16, 3, 5, 6), (2, 128, 256, 2, 4, 8), (1, 32, 32, 6, 6, 6),
                                    (1, 24, 40, 2, 4, 8)])
 @pytest.mark.parametrize('transposed', [False, True])

@@ -1,5 +1,5 @@
 """micro-benchmark of single conv launches (events on the launch stream); used for kernel A/B work and PMC runs.
-usage: python tools/bench_conv.py [fwd|fwd16|head16|wgrad|wgrad16|all] [N D H W Cin Cout] [--iters K]   (fwd16 / wgrad16 = bf16-input kernels)"""
+usage: python tools/bench_conv.py [fwd|fwd16|head16|headwgrad16|wgrad|wgrad16|all] [N D H W Cin Cout] [--iters K]   (fwd16 / wgrad16 = bf16-input kernels)"""
 import os, sys, time
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,6 +46,11 @@ def run(kind, N, D, H, W, Cin, Cout, iters=10):
             wq = torch.empty(E.query('seg3d_thin_out_mfma_packed_elems', Cin), dtype=torch.bfloat16, device=dev)
             E.call('seg3d_pack_weights_thin_out_mfma', E.ptr(w), E.ptr(wq), Cin, Cout, 27, Cin * 27, 0, E.stream_ptr())
             fn = lambda: E.call('seg3d_conv3d_k3_thin_out_mfma_fwd', E.ptr(xb), E.ptr(wq), E.ptr(b), E.ptr(y), E.ptr(st), N, D, H, W, Cin, Cout, E.stream_ptr())
+    elif kind == 'headwgrad16':   # head weight gradient in bf16 mode: thin = fp32 dy (Cout), fat = bf16 x (Cin)
+        xb = x.bfloat16()
+        ws = torch.empty(E.query('seg3d_k3_thin_wgrad_workspace_floats', N, D, H, W, Cout, Cin), device=dev)
+        dw = torch.empty(Cout, Cin, 3, 3, 3, device=dev)
+        fn = lambda: E.call('seg3d_k3_thin_wgrad_fatbf16', E.ptr(dy), E.ptr(xb), E.ptr(dw), E.ptr(ws), N, D, H, W, Cout, Cin, Cin * 27, 27, 1, 0, E.stream_ptr())
     elif kind == 'wgrad16':
         xb, dyb = x.bfloat16(), dy.bfloat16()
         ws = torch.empty(E.query('seg3d_conv3d_k3_bf16_wgrad_workspace_floats', N, D, H, W, Cin, Cout), device=dev)

@@ -516,6 +516,9 @@ def conv_wgrad(xn, dyn, w_shape, kind, out=None):
                 not (_use_mfma(Cin, Cout) and Cout % 4 == 0):
             # bf16-mode head: thin = fp32 dy, fat = the unit's bf16 input, widened inside the kernel
             return _thin_wgrad(dyn, xn, Cout, Cin, w_shape, Cin * 27, 27, 1, out)
+        if not _is_bf16(xn) and _is_bf16(dyn) and not FORCE_DIRECT and Cin <= 8 and Cout % 4 == 0:
+            # bf16-mode stem: thin = the fp32 image, fat = the bf16 gradient of the unit's conv output
+            return _thin_wgrad(xn, dyn, Cin, Cout, w_shape, 27, Cin * 27, 0, out)
         xn, dyn = _to_f32(xn), _to_f32(dyn)     # remaining mixed cases: widen, then the fp32 kernels
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             nfl = E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W_, Cin, Cout)
@@ -749,6 +752,9 @@ class ConvGnActFunction(torch.autograd.Function):
         # the gradient w.r.t. the conv output goes to the dgrad / wgrad kernels as bf16 when they take bf16 (same
         # condition as in forward: bf16 input activations and MFMA-shaped channel counts on both sides)
         ctx.dy_bf16 = _is_bf16(xn) and _is_bf16(outn) and xn.shape[4] % 16 == 0
+        if kind == 'k3' and not _is_bf16(xn) and _is_bf16(outn) and xn.shape[4] <= 8 and not ctx.needs_input_grad[0] \
+                and not FORCE_DIRECT:
+            ctx.dy_bf16 = True     # stem (fp32 image in, bf16 out, no input gradient): its weight gradient takes a bf16 dy
         ctx.kind, ctx.relu = kind, bool(relu)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.w_shape = tuple(weight.shape)

@@ -241,6 +241,24 @@ def test_k3_thin_wgrad_fatbf16(hip_device, shape, accumulate):
            max_abs_err=float((got - ref).abs().max()), grad_scale=scale)
 
 
+@pytest.mark.parametrize('shape', [(2, 1, 16, 8, 8, 16), (1, 4, 16, 5, 9, 11), (1, 2, 32, 6, 10, 18)])
+def test_k3_thin_wgrad_stem_bf16_dy(hip_device, shape):
+    """stem weight gradient in bf16 mode: thin = the fp32 image (hi + lo inside the kernel), fat = the bf16 dy"""
+    from segmentation3d import _ops, _engine as E
+    N, Cin, Cout, D, H, W = shape
+    x = _t(64, 'sx', (N, Cin, D, H, W))
+    dy = _t(65, 'sdy', (N, Cout, D, H, W))
+    xn = _ops.to_ndhwc(x.to(hip_device))
+    dyb = _ops.to_ndhwc(dy.to(hip_device)).bfloat16()
+    dw = _ops.conv_wgrad(xn, dyb, (Cout, Cin, 3, 3, 3), 'k3')
+    wz = torch.zeros(Cout, Cin, 3, 3, 3, dtype=torch.double, requires_grad=True)
+    (F.conv3d(x.double(), wz, None, padding=1) * dy.bfloat16().double()).sum().backward()
+    scale = float(wz.grad.abs().max())
+    err = float((dw.double().cpu() - wz.grad).abs().max())
+    assert err < 2e-5 * scale
+    report('thin_wgrad_stem_bf16dy_{}x{}x{}x{}_{}_{}'.format(N, D, H, W, Cin, Cout), max_abs_err=err, grad_scale=scale)
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 32, 4, 8, 8), (1, 64, 16, 3, 5, 6), (2, 128, 256, 2, 4, 8), (1, 32, 32, 6, 6, 6),
                                    (1, 24, 40, 2, 4, 8)])
 @pytest.mark.parametrize('transposed', [False, True])

@@ -144,36 +144,52 @@ __device__ __forceinline__ void conv3d_k3_thin_in_body(const float* __restrict__
 #pragma unroll
   for (int p = 0; p < KP; ++p) {
     const int koff = lh ? thin_koff<CT>(2 * p + 1) : thin_koff<CT>(2 * p);
+    // weights are the ROW operand: the result puts a voxel in every lane (column li) and four consecutive output
+    // channels in every register quad (rows 8 g + 4 lh ..), so the epilogue stores 16 (fp32) / 8 (bf16) contiguous bytes
+    // per quad instead of one element per lane -- with 16 output channels the element stores also left half the lanes idle
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[abase[m] + koff], bw[p], acc[m], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[p], xs[abase[m] + koff], acc[m], 0, 0, 0);
   }
 
-  const int co = cob * 32 + li;
-  const bool co_ok = co < Cout;
-  const float bv = (bias && co_ok) ? bias[co] : 0.f;
   float s[2] = {0.f, 0.f};
-  int ooff[2][16];
+  const bool quad_ok = (Cout & 3) == 0;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
+    const int vo = voff[(wave + 4 * m) * 32 + li];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int vo = voff[(wave + 4 * m) * 32 + thin_row(r, lh)];
-      const bool ok = vo >= 0 && co_ok;
-      ooff[m][r] = ok ? vo * Cout + co : -1;
-      acc[m][r] += bv;
-      const float val = ok ? acc[m][r] : 0.f;
-      s[0] += val;
-      s[1] += val * val;
+    for (int g = 0; g < 4; ++g) {
+      const int co0 = cob * 32 + 8 * g + 4 * lh;
+      float val[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = vo >= 0 && co0 + j < Cout;
+        val[j] = acc[m][4 * g + j] + ((bias && co0 + j < Cout) ? bias[co0 + j] : 0.f);
+        const float sv = ok ? val[j] : 0.f;
+        s[0] += sv;
+        s[1] += sv * sv;
+      }
+      if (vo < 0 || co0 >= Cout) continue;
+      const i64 o = (i64)vo * Cout + co0;
+      if (quad_ok) {
+        if (OUT_BF) {
+          uint2 pk;
+          pk.x = seg3d_pack2bf(val[0], val[1]);
+          pk.y = seg3d_pack2bf(val[2], val[3]);
+          *reinterpret_cast<uint2*>(reinterpret_cast<seg3d_bf16*>(y) + o) = pk;
+        } else {
+          const f32x4 v4 = {val[0], val[1], val[2], val[3]};
+          *reinterpret_cast<f32x4*>(y + o) = v4;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (co0 + j < Cout) {
+            if (OUT_BF) reinterpret_cast<seg3d_bf16*>(y)[o + j] = seg3d_f2bf(val[j]);
+            else y[o + j] = val[j];
+          }
+      }
     }
   }
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (ooff[m][r] >= 0) {
-        if (OUT_BF) reinterpret_cast<seg3d_bf16*>(y)[(i64)ooff[m][r]] = seg3d_f2bf(acc[m][r]);
-        else y[(i64)ooff[m][r]] = acc[m][r];
-      }
   if (stats) {
     __syncthreads();
     block_sum_256<2>(s, xs);

@@ -224,13 +224,79 @@ extern "C" int seg3d_bf16_to_f32(const void* src, float* dst, long long n, void*
 // and for the data-gradient orientation: 52 tiny launches per V-Net step otherwise).  `jobs` is a device array;
 // job k owns the workgroups [first_block[k], first_block[k+1]), one per packed (32 x 8 x T) chunk.
 // AW = reduction channels per chunk: 8 (fp32 image) or 16 (bf16 image, 8 per half)
+// TC = compile-time tap count (27 / 8; 0 = run-time T): the index arithmetic below is one division per element and
+// loop, and with a run-time divisor those divisions WERE the kernel (about 60 VALU instructions per element, 134 us for
+// the 2 x 45 M packed elements of a V-Net step; divisions by constants are a multiply and a shift)
+// LDS tile element of the multi-pack kernel: the value as it will be stored (fp32 image: float, bf16 image: bf16 bits)
+template <bool BF> struct Seg3dPackTile;
+template <> struct Seg3dPackTile<false> {
+  typedef float type;
+  static __device__ __forceinline__ float put(float v) { return v; }
+  static __device__ __forceinline__ void store(float* wp, i64 i, float v) { wp[i] = v; }
+};
+template <> struct Seg3dPackTile<true> {
+  typedef seg3d_bf16 type;
+  static __device__ __forceinline__ seg3d_bf16 put(float v) { return seg3d_f2bf(v); }
+  static __device__ __forceinline__ void store(float* wp, i64 i, seg3d_bf16 v) { reinterpret_cast<seg3d_bf16*>(wp)[i] = v; }
+};
+
+template <int AW, bool BF, int TC>
+__device__ __forceinline__ void pack_mfma_chunk(const Seg3dPackJob& jb, int chunk,
+                                                typename Seg3dPackTile<BF>::type* __restrict__ tile) {
+  typedef Seg3dPackTile<BF> TL;
+  const int T = TC ? TC : jb.T;
+  const int AB = (jb.A + AW - 1) / AW;
+  const int ab = chunk % AB, bb = chunk / AB;
+  const int a0 = ab * AW, b0 = bb * 32;
+  const int n = AW * 32 * T;                                     // elements of this chunk, tile[(a * 32 + b) * T + t]
+  if (T <= 27 && jb.sa == T) {
+    // w[b][a][t]: for a fixed output channel b the 8 x T values of this chunk are contiguous
+    const int run = AW * T;
+#pragma unroll 6
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+      const int b = i / run, r = i - b * run;
+      const int a = r / T, t = r - a * T;
+      float v = 0.f;
+      if (a0 + a < jb.A && b0 + b < jb.B) v = jb.w[(i64)(b0 + b) * jb.sb + (i64)a0 * T + r];
+      tile[(a * 32 + b) * T + t] = TL::put(v);
+    }
+  } else if (T <= 27 && jb.sb == T) {
+    // w[a][b][t]: for a fixed reduction channel a the 32 x T values are contiguous
+    const int run = 32 * T;
+#pragma unroll 6
+    for (int i = threadIdx.x; i < AW * run; i += 256) {
+      const int a = i / run, r = i - a * run;
+      float v = 0.f;
+      if (a0 + a < jb.A && b0 + r / T < jb.B) v = jb.w[(i64)(a0 + a) * jb.sa + (i64)b0 * T + r];
+      tile[a * run + r] = TL::put(v);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n && T <= 27; i += 256) {
+      const int t = i % T, ab_ = i / T;
+      const int b = ab_ % 32, a = ab_ / 32;
+      float v = 0.f;
+      if (a0 + a < jb.A && b0 + b < jb.B) v = jb.w[(a0 + a) * jb.sa + (b0 + b) * jb.sb + t];
+      tile[i] = TL::put(v);
+    }
+  }
+  __syncthreads();
+  // packed order inside the chunk: [t][h][j][r]  with a = 4 h + r, b = j
+  constexpr int HW = AW / 2;   // channels per half
+#pragma unroll 6
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, t = i / (HW * 64);
+    const typename TL::type v = tile[((HW * h + r) * 32 + j) * T + (jb.flip ? T - 1 - t : t)];
+    TL::store(jb.wp, (i64)chunk * n + i, v);
+  }
+}
+
 template <int AW, bool BF>
 __device__ __forceinline__ void pack_mfma_multi_body(const Seg3dPackJob* __restrict__ jobs, int njobs) {
   // One workgroup per packed chunk (8 reduction channels x 32 output channels x T taps = exactly one LDS image of the
   // conv kernels).  In both reference layouts one of the two channel strides equals T, so the chunk's source elements
   // form long contiguous runs: they are read in memory order (coalesced), transposed through LDS and written in packed
   // order (coalesced).  The first version gathered single floats straight from global memory and moved 5x the bytes.
-  __shared__ float tile[AW * 32 * 27];
+  __shared__ typename Seg3dPackTile<BF>::type tile[AW * 32 * 27];   // bf16 images keep the tile in bf16: 27 KB, 5 workgroups per CU
   __shared__ int sjob;
   if (threadIdx.x == 0) {
     int lo = 0, hi = njobs - 1;  // last job whose first_block <= blockIdx.x
@@ -242,48 +308,10 @@ __device__ __forceinline__ void pack_mfma_multi_body(const Seg3dPackJob* __restr
   }
   __syncthreads();
   const Seg3dPackJob jb = jobs[sjob];
-  const int AB = (jb.A + AW - 1) / AW, T = jb.T;
   const int chunk = (int)((i64)blockIdx.x - jb.first_block);   // = bb * AB + ab
-  const int ab = chunk % AB, bb = chunk / AB;
-  const int a0 = ab * AW, b0 = bb * 32;
-  const int n = AW * 32 * T;                                     // elements of this chunk, tile[(a * 32 + b) * T + t]
-  if (T <= 27 && jb.sa == T) {
-    // w[b][a][t]: for a fixed output channel b the 8 x T values of this chunk are contiguous
-    const int run = AW * T;
-    for (int i = threadIdx.x; i < 32 * run; i += 256) {
-      const int b = i / run, r = i - b * run;
-      const int a = r / T, t = r - a * T;
-      float v = 0.f;
-      if (a0 + a < jb.A && b0 + b < jb.B) v = jb.w[(i64)(b0 + b) * jb.sb + (i64)a0 * T + r];
-      tile[(a * 32 + b) * T + t] = v;
-    }
-  } else if (T <= 27 && jb.sb == T) {
-    // w[a][b][t]: for a fixed reduction channel a the 32 x T values are contiguous
-    const int run = 32 * T;
-    for (int i = threadIdx.x; i < AW * run; i += 256) {
-      const int a = i / run, r = i - a * run;
-      float v = 0.f;
-      if (a0 + a < jb.A && b0 + r / T < jb.B) v = jb.w[(i64)(a0 + a) * jb.sa + (i64)b0 * T + r];
-      tile[a * run + r] = v;
-    }
-  } else {
-    for (int i = threadIdx.x; i < n && T <= 27; i += 256) {
-      const int t = i % T, ab_ = i / T;
-      const int b = ab_ % 32, a = ab_ / 32;
-      float v = 0.f;
-      if (a0 + a < jb.A && b0 + b < jb.B) v = jb.w[(a0 + a) * jb.sa + (b0 + b) * jb.sb + t];
-      tile[i] = v;
-    }
-  }
-  __syncthreads();
-  // packed order inside the chunk: [t][h][j][r]  with a = 4 h + r, b = j
-  constexpr int HW = AW / 2;   // channels per half
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, t = i / (HW * 64);
-    const float v = tile[((HW * h + r) * 32 + j) * T + (jb.flip ? T - 1 - t : t)];
-    if (BF) reinterpret_cast<seg3d_bf16*>(jb.wp)[(i64)chunk * n + i] = seg3d_f2bf(v);
-    else jb.wp[(i64)chunk * n + i] = v;
-  }
+  if (jb.T == 27) pack_mfma_chunk<AW, BF, 27>(jb, chunk, tile);
+  else if (jb.T == 8) pack_mfma_chunk<AW, BF, 8>(jb, chunk, tile);
+  else pack_mfma_chunk<AW, BF, 0>(jb, chunk, tile);
 }
 
 __global__ __launch_bounds__(256) void pack_mfma_multi_kernel(const Seg3dPackJob* __restrict__ jobs, int njobs) {

@@ -128,6 +128,16 @@ int seg3d_k2_bf16_wgrad(const void* P_bf16, const void* Q_bf16, float* dw, float
 int seg3d_conv3d_k3_thin_out_bf16_fwd(const void* x_bf16, const float* wq, const float* bias, float* y,
                                       float* stats_partial, int N, int D, int H, int W, int Cin, int Cout, int CO,
                                       void* stream);
+/* thin-input conv on the bf16 matrix cores (bf16 mode: stem forward CT = 1, head data-gradient CT = 2; Cout % 4 == 0):
+ * x fp32 and the weights enter as bf16 hi + lo pairs (three MFMAs per K-step, exact to 2^-16), y is bf16, statistics
+ * slots as seg3d_conv3d_k3_thin_in_fwd.  replaces InputBlock.conv = nn.Conv3d(in, 16, 3, padding=1),
+ * network/module/vnet_inblock.py:9, and the input gradient of OutputBlock.conv1, vnet_outblock.py:13 */
+int seg3d_conv3d_k3_thin_in_mfma16_supported(int CT, int Cout);
+long long seg3d_packed_thin_in16_elems(int CT, int B);
+int seg3d_pack_weights_thin_in16(const float* w, void* wq_bf16, int CT, int B, long long sa, long long sb, int flip,
+                                 void* stream);
+int seg3d_conv3d_k3_thin_in_mfma16_fwd(const float* x, const void* wq_bf16, const float* bias, void* y_bf16,
+                                       float* stats_partial, int N, int D, int H, int W, int CT, int Cout, void* stream);
 /* the same head conv on the matrix cores (Cin in {16, 32}, Cout <= 3): x taps in the reduction dimension, (kz, ky)
  * taps in the output dimension, weights as a bf16 hi + lo pair (fp32-grade); statistics slots as the thin_out kernel.
  * replaces OutputBlock.conv1 = nn.Conv3d(in, out, 3, padding=1), network/module/vnet_outblock.py:13 */

@@ -20,6 +20,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 to_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int thin_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -221,6 +222,263 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_bf16out_kernel(const
                                                                      int N, int D, int H, int W, int Cout, int ntz,
                                                                      int nty, int ntx) {
   conv3d_k3_thin_in_body<CT, true>(x, wp, bias, y, stats, N, D, H, W, Cout, ntz, nty, ntx);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// thin-in forward on the bf16 matrix cores (bf16 mode: stem forward CT = 1, head data-gradient CT = 2; bf16 output)
+// ---------------------------------------------------------------------------------------------------------------
+// The fp32 kernel above issues 14 / 27 fp32 MFMAs of 64 cycles per row block and is bound by instruction issue.  Here
+// a K-step is 16 reduction entries of one v_mfma_f32_32x32x16_bf16, and both operands are bf16 hi + lo pairs (three
+// MFMAs per K-step: hi.hi + hi.lo + lo.hi, exact to 2^-16): the stem and the head stay fp32-grade.  A lane's operand
+// is 8 reduction entries of ITS voxel = four dwords, each ONE aligned LDS read:
+//   CT = 2: k = 2 tap + channel; the halo tile holds one dword (ch0 | ch1 << 16) per voxel; K = 54 -> 4 K-steps;
+//   CT = 1: k = 4 (kz 3 + ky) + slot, slot = kx 0, 1, 2 and one zero-weight filler; a dword is the x pair (hx, hx + 1),
+//           kept in two copies (pairs starting at even / odd hx) so that either parity of the lane's x is an aligned
+//           read; K = 36 -> 3 K-steps.
+// Weights: the ROW operand, in registers (wq[hi, lo][K-step][lane][8]); result and epilogue as in the fp32 kernel.
+template <int CT> struct ThinIn16 {
+  static constexpr int KS = CT == 1 ? 3 : 4;
+  static constexpr int ROWD = 6;                                        // CT = 1: dwords per halo row (12 elements)
+  static constexpr int PLANE = CT == 1 ? (TH_TZ + 2) * TH_HY * ROWD : TH_NV;   // dwords of one LDS image
+  static constexpr int IMAGES = CT == 1 ? 4 : 2;                        // CT = 1: even hi, odd hi, even lo, odd lo
+};
+
+// k of K-step ks, lane half h, entry j -> (tap, channel) or (-1) for a zero weight
+template <int CT>
+__host__ __device__ __forceinline__ int thin16_tap(int ks, int h, int j, int* ch) {
+  const int k = 16 * ks + 8 * h + j;
+  if (CT == 2) {
+    *ch = k & 1;
+    return (k >> 1) < 27 ? (k >> 1) : -1;
+  }
+  *ch = 0;
+  const int row = k >> 2, slot = k & 3;
+  return (row < 9 && slot < 3) ? row * 3 + slot : -1;
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void pack_thin_in16_kernel(const float* __restrict__ w, seg3d_bf16* __restrict__ wq, int B,
+                                                               int BB, i64 sa, i64 sb, int flip) {
+  constexpr int KS = ThinIn16<CT>::KS;
+  const int total = BB * KS * 512;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int j = idx & 7, l = (idx >> 3) & 63, r = idx >> 9;
+    const int ks = r % KS, bb = r / KS;
+    int a;
+    const int t = thin16_tap<CT>(ks, l >> 5, j, &a);
+    const int b = bb * 32 + (l & 31);
+    float v = 0.f;
+    if (t >= 0 && b < B) v = w[a * sa + b * sb + (flip ? 26 - t : t)];
+    const seg3d_bf16 hi = seg3d_f2bf(v);
+    wq[idx] = hi;
+    wq[total + idx] = seg3d_f2bf(v - seg3d_bf2f(hi));
+  }
+}
+
+extern "C" int seg3d_conv3d_k3_thin_in_mfma16_supported(int CT, int Cout) { return (CT == 1 || CT == 2) && Cout > 0 && (Cout % 4) == 0; }
+
+extern "C" long long seg3d_packed_thin_in16_elems(int CT, int B) {
+  return 2ll * ((B + 31) / 32) * (CT == 1 ? 3 : 4) * 512;
+}
+
+extern "C" int seg3d_pack_weights_thin_in16(const float* w, void* wq_bf16, int CT, int B, long long sa, long long sb, int flip,
+                                            void* stream) {
+  SEG3D_REQUIRE(w && wq_bf16 && (CT == 1 || CT == 2) && B > 0, "seg3d_pack_weights_thin_in16: bad arguments (CT in {1, 2})");
+  const int BB = (B + 31) / 32;
+  const int total = BB * (CT == 1 ? 3 : 4) * 512;
+  seg3d_bf16* wq = reinterpret_cast<seg3d_bf16*>(wq_bf16);
+  if (CT == 1)
+    hipLaunchKernelGGL(pack_thin_in16_kernel<1>, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wq, B, BB,
+                       (i64)sa, (i64)sb, flip);
+  else
+    hipLaunchKernelGGL(pack_thin_in16_kernel<2>, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wq, B, BB,
+                       (i64)sa, (i64)sb, flip);
+  SEG3D_LAUNCH_CHECK("seg3d_pack_weights_thin_in16");
+  return SEG3D_OK;
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_mfma16_kernel(const float* __restrict__ x,
+                                                                           const seg3d_bf16* __restrict__ wq,
+                                                                           const float* __restrict__ bias,
+                                                                           seg3d_bf16* __restrict__ y, float* __restrict__ stats,
+                                                                           int N, int D, int H, int W, int Cout, int ntz,
+                                                                           int nty, int ntx) {
+  typedef ThinIn16<CT> TI;
+  constexpr int KS = TI::KS, PL = TI::PLANE;
+  __shared__ __attribute__((aligned(16))) unsigned img[TI::IMAGES * PL + 64];   // (+ the block_sum scratch fits as well)
+  __shared__ int voff[TH_MT];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cob = blockIdx.y;
+  int b = blockIdx.x;
+  const int tix = b % ntx; b /= ntx;
+  const int tiy = b % nty; b /= nty;
+  const int tiz = b % ntz;
+  const int n = b / ntz;
+  const int z0 = tiz * TH_TZ, y0 = tiy * TH_TY, x0 = tix * TH_TX;
+
+  f32x4 whi[KS], wlo[KS];
+  {
+    const seg3d_bf16* wsrc = wq + ((i64)cob * KS * 64 + lane) * 8;
+    const i64 lo_off = (i64)gridDim.y * KS * 512;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      whi[ks] = *reinterpret_cast<const f32x4*>(wsrc + ks * 512);
+      wlo[ks] = *reinterpret_cast<const f32x4*>(wsrc + lo_off + ks * 512);
+    }
+  }
+  seg3d_bf16* img16 = reinterpret_cast<seg3d_bf16*>(img);
+  if (CT == 1) {   // the filler elements (hx 10, 11) are read with zero weights: they must be finite
+    for (int e = tid; e < TI::IMAGES * PL; e += 256) img[e] = 0u;
+    __syncthreads();
+  }
+  for (int e = tid; e < TH_NV * CT; e += 256) {
+    const int v = e / CT, a = e % CT;
+    const int hx = v % TH_HX;
+    const int row = v / TH_HX;           // hz * TH_HY + hy
+    const int hy = row % TH_HY;
+    const int hz = row / TH_HY;
+    const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+    float val = 0.f;
+    if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+      val = x[((((i64)n * D + gz) * H + gy) * W + gx) * CT + a];
+    const seg3d_bf16 hi = seg3d_f2bf(val);
+    const seg3d_bf16 lo = seg3d_f2bf(val - seg3d_bf2f(hi));
+    if (CT == 2) {
+      img16[2 * v + a] = hi;
+      img16[2 * (PL + v) + a] = lo;
+    } else {
+      // even image: pair (2 i, 2 i + 1) in dword i; odd image: pair (2 i + 1, 2 i + 2) in dword i
+      const int ev = 2 * (row * TI::ROWD) + hx;
+      img16[ev] = hi;
+      img16[2 * 2 * PL + ev] = lo;
+      if (hx >= 1) {
+        const int od = 2 * (PL + row * TI::ROWD) + hx - 1;
+        img16[od] = hi;
+        img16[2 * 2 * PL + od] = lo;
+      }
+    }
+  }
+  {
+    const int tx = tid % TH_TX;
+    const int t = tid / TH_TX;
+    const int ty = t % TH_TY;
+    const int tz = t / TH_TY;
+    const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
+    voff[tid] = (gz < D && gy < H && gx < W) ? ((n * D + gz) * H + gy) * W + gx : -1;
+  }
+  // dword offset of this lane's voxel (tap 0) in the hi image, per row block
+  int abase[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int idx = (wave + 4 * m) * 32 + li;
+    const int tx = idx % TH_TX;
+    const int t = idx / TH_TX;
+    const int ty = t % TH_TY;
+    const int tz = t / TH_TY;
+    if (CT == 2) abase[m] = (tz * TH_HY + ty) * TH_HX + tx;
+    else abase[m] = (tx & 1) * PL + (tz * TH_HY + ty) * TI::ROWD + (tx >> 1);
+  }
+  __syncthreads();
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  constexpr int LO = CT == 1 ? 2 * PL : PL;   // dword distance hi image -> lo image
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      unsigned xh[4], xl[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        int off0, off1;   // dword offsets for lane half 0 / 1 (compile-time)
+        if (CT == 2) {
+          const int t0 = 8 * ks + d, t1 = 8 * ks + 4 + d;
+          off0 = t0 < 27 ? ((t0 / 9) * TH_HY + (t0 / 3) % 3) * TH_HX + t0 % 3 : 0;
+          off1 = t1 < 27 ? ((t1 / 9) * TH_HY + (t1 / 3) % 3) * TH_HX + t1 % 3 : 0;
+        } else {
+          const int r0 = 4 * ks + (d >> 1), r1 = 4 * ks + 2 + (d >> 1);
+          off0 = r0 < 9 ? ((r0 / 3) * TH_HY + r0 % 3) * TI::ROWD + (d & 1) : 0;
+          off1 = r1 < 9 ? ((r1 / 3) * TH_HY + r1 % 3) * TI::ROWD + (d & 1) : 0;
+        }
+        const int off = abase[m] + (lh ? off1 : off0);
+        xh[d] = img[off];
+        xl[d] = img[LO + off];
+      }
+      const f32x4 bh = {__uint_as_float(xh[0]), __uint_as_float(xh[1]), __uint_as_float(xh[2]), __uint_as_float(xh[3])};
+      const f32x4 bl = {__uint_as_float(xl[0]), __uint_as_float(xl[1]), __uint_as_float(xl[2]), __uint_as_float(xl[3])};
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, whi[ks]), __builtin_bit_cast(to_bf16x8, bh),
+                                                       acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, whi[ks]), __builtin_bit_cast(to_bf16x8, bl),
+                                                       acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(to_bf16x8, wlo[ks]), __builtin_bit_cast(to_bf16x8, bh),
+                                                       acc[m], 0, 0, 0);
+    }
+  }
+
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int vo = voff[(wave + 4 * m) * 32 + li];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co0 = cob * 32 + 8 * g + 4 * lh;    // Cout % 4 == 0: a quad is inside or outside
+      if (co0 >= Cout) continue;
+      float val[4];
+      const f32x4 bq = bias ? *reinterpret_cast<const f32x4*>(bias + co0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        val[j] = acc[m][4 * g + j] + bq[j];
+        const float sv = vo >= 0 ? val[j] : 0.f;
+        s[0] += sv;
+        s[1] += sv * sv;
+      }
+      if (vo < 0) continue;
+      uint2 pk;
+      pk.x = seg3d_pack2bf(val[0], val[1]);
+      pk.y = seg3d_pack2bf(val[2], val[3]);
+      *reinterpret_cast<uint2*>(y + (i64)vo * Cout + co0) = pk;
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    block_sum_256<2>(s, reinterpret_cast<float*>(img));
+    if (tid == 0) {
+      const int tiles_per_sample = ntz * nty * ntx;
+      const int tile = (tiz * nty + tiy) * ntx + tix;
+      float* dst = stats + (((i64)n * tiles_per_sample + tile) * gridDim.y + cob) * 2;
+      dst[0] = s[0];
+      dst[1] = s[1];
+    }
+  }
+}
+
+// x fp32 [N][D][H][W][CT] (CT in {1, 2}), wq = seg3d_pack_weights_thin_in16, y bf16 [N][D][H][W][Cout] (Cout % 4 == 0);
+// stats as seg3d_conv3d_k3_thin_in_fwd
+extern "C" int seg3d_conv3d_k3_thin_in_mfma16_fwd(const float* x, const void* wq_bf16, const float* bias, void* y_bf16,
+                                                  float* stats, int N, int D, int H, int W, int CT, int Cout, void* stream) {
+  SEG3D_REQUIRE(x && wq_bf16 && y_bf16, "seg3d_conv3d_k3_thin_in_mfma16_fwd: null pointer");
+  SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "seg3d_conv3d_k3_thin_in_mfma16_fwd: bad dims");
+  SEG3D_REQUIRE(seg3d_conv3d_k3_thin_in_mfma16_supported(CT, Cout),
+                "seg3d_conv3d_k3_thin_in_mfma16_fwd: need CT in {1, 2} and Cout %% 4 == 0");
+  SEG3D_REQUIRE((i64)N * D * H * W * Cout < (1ll << 31), "seg3d_conv3d_k3_thin_in_mfma16_fwd: tensor exceeds 2^31 elements");
+  const int ntz = seg3d_cdiv(D, TH_TZ), nty = seg3d_cdiv(H, TH_TY), ntx = seg3d_cdiv(W, TH_TX);
+  dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
+  hipStream_t s = (hipStream_t)stream;
+  const seg3d_bf16* wq = reinterpret_cast<const seg3d_bf16*>(wq_bf16);
+  seg3d_bf16* y = reinterpret_cast<seg3d_bf16*>(y_bf16);
+  if (CT == 1)
+    hipLaunchKernelGGL((conv3d_k3_thin_in_mfma16_kernel<1>), grid, dim3(256), 0, s, x, wq, bias, y, stats, N, D, H, W, Cout, ntz,
+                       nty, ntx);
+  else
+    hipLaunchKernelGGL((conv3d_k3_thin_in_mfma16_kernel<2>), grid, dim3(256), 0, s, x, wq, bias, y, stats, N, D, H, W, Cout, ntz,
+                       nty, ntx);
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_thin_in_mfma16_fwd");
+  return SEG3D_OK;
 }
 
 extern "C" long long seg3d_conv3d_k3_thin_stats_count(int D, int H, int W, int Cout_blocks) {
@@ -555,7 +813,6 @@ static int thin_out_launch(const void* xv, int x_bf16, const float* wq, const fl
 // and after each plane adds the plane's 3 x 3 shifted P entries into three rolling accumulator sets -- output planes
 // p, p - 1, p - 2 take the plane's kz = 0, 1, 2 taps -- then stores the finished plane p - 2 (16 bytes per lane) and
 // rotates.  Per output voxel: 50 / 1024 row blocks (z halo 10 / 8, y halo 10 / 8), 18 LDS floats read, 18 adds.
-typedef __bf16 to_bf16x8 __attribute__((ext_vector_type(8)));
 
 // wp[2 (hi, lo)][KS][64 lanes][8]: lane l supplies row n = l & 31 = (kz * 3 + ky) * COUT + co, k = 16 ks + 8 (l >> 5) + j
 __global__ __launch_bounds__(256) void pack_thin_out_mfma_kernel(const float* __restrict__ w, seg3d_bf16* __restrict__ wp,

@@ -35,6 +35,8 @@ BF16_CONV_OUTPUT = os.environ.get('SEG3D_BF16_Y', '1') != '0'
 K2_BF16_MFMA = os.environ.get('SEG3D_K2_BF16_MFMA', '1') != '0'
 # bf16 mode, head conv (Cin 16/32 -> <= 3): small GEMM per row block on the matrix cores (SEG3D_THIN_OUT_MFMA=0: VALU kernel)
 THIN_OUT_MFMA = os.environ.get('SEG3D_THIN_OUT_MFMA', '1') != '0'
+# bf16 mode, stem forward / head data-gradient (1-2 input channels, bf16 output): bf16 MFMA with hi + lo operands
+THIN_IN_MFMA16 = os.environ.get('SEG3D_THIN_IN_MFMA16', '1') != '0'
 
 
 def set_activation_dtype(name):
@@ -296,11 +298,17 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
         return y2.add_(addend), st
     if A <= 8 and not FORCE_DIRECT:
         # thin input (stem forward, head data-gradient): all 27*A taps folded into one MFMA K dimension
-        wp = _empty((E.query('seg3d_packed_thin_in_floats', A, B),), w)
-        E.call('seg3d_pack_weights_thin_in', E.ptr(w), E.ptr(wp), A, B, sa, sb, flip, E.stream_ptr())
         stats = None
         if want_stats:
             stats = _empty((N, E.query('seg3d_conv3d_k3_thin_stats_count', D, H, W_, (B + 31) // 32), 2), xn)
+        if _is_bf16(y) and THIN_IN_MFMA16 and E.query('seg3d_conv3d_k3_thin_in_mfma16_supported', A, B):
+            wq = torch.empty(E.query('seg3d_packed_thin_in16_elems', A, B), dtype=torch.bfloat16, device=w.device)
+            E.call('seg3d_pack_weights_thin_in16', E.ptr(w), E.ptr(wq), A, B, sa, sb, flip, E.stream_ptr())
+            E.call('seg3d_conv3d_k3_thin_in_mfma16_fwd', E.ptr(xn), E.ptr(wq), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H,
+                   W_, A, B, E.stream_ptr())
+            return y, stats
+        wp = _empty((E.query('seg3d_packed_thin_in_floats', A, B),), w)
+        E.call('seg3d_pack_weights_thin_in', E.ptr(w), E.ptr(wp), A, B, sa, sb, flip, E.stream_ptr())
         E.call('seg3d_conv3d_k3_thin_in_bf16out_fwd' if _is_bf16(y) else 'seg3d_conv3d_k3_thin_in_fwd', E.ptr(xn), E.ptr(wp),
                E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B, E.stream_ptr())
         return y, stats

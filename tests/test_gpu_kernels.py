@@ -241,6 +241,41 @@ def test_k3_thin_wgrad_fatbf16(hip_device, shape, accumulate):
            max_abs_err=float((got - ref).abs().max()), grad_scale=scale)
 
 
+@pytest.mark.parametrize('shape', [(2, 1, 16, 8, 8, 16), (1, 1, 16, 5, 9, 11), (1, 2, 32, 6, 10, 18), (2, 2, 32, 4, 8, 8),
+                                   (1, 1, 64, 3, 7, 9), (1, 2, 20, 9, 5, 13), (1, 1, 16, 1, 2, 3)])
+@pytest.mark.parametrize('flip', [0, 1])
+def test_conv3d_k3_thin_in_mfma16(hip_device, shape, flip):
+    """thin-input conv on the bf16 matrix cores (stem forward / head data-gradient in bf16 mode): fp32 input and
+    weights as bf16 hi + lo pairs, bf16 output = one rounding of the fp32-grade result (tolerance: half a bf16 ulp at
+    the output scale = 2^-8 of it, + 2e-5); statistics are taken from the unrounded values"""
+    from segmentation3d import _ops, _engine as E
+    N, CT, Cout, D, H, W = shape
+    assert E.query('seg3d_conv3d_k3_thin_in_mfma16_supported', CT, Cout) == 1
+    assert E.query('seg3d_conv3d_k3_thin_in_mfma16_supported', 3, 16) == 0
+    x = _t(71, 'tx', (N, CT, D, H, W))
+    w = _t(72, 'tw', (Cout, CT, 3, 3, 3), std=0.2)
+    b = _t(73, 'tb', (Cout,), std=0.5)
+    xn = _ops.to_ndhwc(x.to(hip_device))
+    wd, bd = w.to(hip_device), b.to(hip_device)
+    wq = torch.empty(E.query('seg3d_packed_thin_in16_elems', CT, Cout), dtype=torch.bfloat16, device=hip_device)
+    E.call('seg3d_pack_weights_thin_in16', E.ptr(wd), E.ptr(wq), CT, Cout, 27, CT * 27, flip, E.stream_ptr())
+    y = torch.full((N, D, H, W, Cout), float('nan'), dtype=torch.bfloat16, device=hip_device)
+    cnt = E.query('seg3d_conv3d_k3_thin_stats_count', D, H, W, (Cout + 31) // 32)
+    st = torch.full((N, cnt, 2), float('nan'), device=hip_device)
+    E.call('seg3d_conv3d_k3_thin_in_mfma16_fwd', E.ptr(xn), E.ptr(wq), E.ptr(bd), E.ptr(y), E.ptr(st), N, D, H, W, CT, Cout,
+           E.stream_ptr())
+    wref = w.flip(2, 3, 4) if flip else w
+    ref = F.conv3d(x.double(), wref.double(), b.double(), padding=1)
+    got = _ops.from_ndhwc(y.float()).double().cpu()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < (2.0 ** -8 + 2e-5) * scale
+    s = st.double().sum(1).cpu()
+    rr = ref.reshape(N, -1)
+    assert float(((s[:, 0] - rr.sum(1)).abs() / rr.abs().sum(1)).max()) < 2e-5 and rel_err(s[:, 1], (rr * rr).sum(1)) < 2e-5
+    report('thin_in_mfma16_{}x{}x{}x{}_{}_{}_flip{}'.format(N, D, H, W, CT, Cout, flip), max_abs_err=float((got - ref).abs().max()),
+           out_scale=scale, stats_rel_err=rel_err(s[:, 1], (rr * rr).sum(1)))
+
+
 @pytest.mark.parametrize('shape', [(2, 1, 16, 8, 8, 16), (1, 4, 16, 5, 9, 11), (1, 2, 32, 6, 10, 18)])
 def test_k3_thin_wgrad_stem_bf16_dy(hip_device, shape):
     """stem weight gradient in bf16 mode: thin = the fp32 image (hi + lo inside the kernel), fat = the bf16 dy"""

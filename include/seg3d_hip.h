@@ -198,6 +198,11 @@ int seg3d_gn_bwd_reduce(const float* dout, const float* out /* NULL: recompute t
 int seg3d_gn_bwd_finalize(const float* part, const float* gamma, const float* mean_rstd, float* abx, float* s12,
                           float* dgamma, float* dbeta, float* dbias, int N, long long S, int C,
                           int acc_mask /* bit 0/1/2: accumulate into dgamma/dbeta/dbias */, void* stream);
+/* both stages in one launch (last-ticket workgroup runs the parameter stage); ticket: one device int, zero before the
+ * first call and left zero by every call */
+int seg3d_gn_bwd_finalize_fused(const float* part, const float* gamma, const float* mean_rstd, float* abx, float* s12,
+                                float* dgamma, float* dbeta, float* dbias, int* ticket, int N, long long S, int C,
+                                int acc_mask, void* stream);
 int seg3d_gn_bwd_apply(const float* dout, const float* out /* NULL: recompute */, const float* y, const float* mean_rstd,
                        const float* s12, const float* gamma, const float* beta, float* dy, float* dres, int N, long long S,
                        int C, int relu, int ld_dout /* row stride of dout in floats, 0 = C */, void* stream);

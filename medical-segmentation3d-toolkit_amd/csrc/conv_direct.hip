@@ -355,13 +355,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// few outputs, many chunks (the head's 1x1x1 conv: 4 outputs x ~14 k chunks took 134 us with one serial thread per
+// output): one workgroup per output, threads stride over the chunks, fixed-shape LDS tree -- still deterministic
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                  int chunks, int T, int A, int B, int BP, i64 sa, i64 sb,
+                                                                  int accumulate) {
+  __shared__ float red[256];
+  const i64 idx = blockIdx.x;
+  const i64 slab = (i64)T * A * BP;
+  const int b = (int)(idx % B);
+  const i64 r = idx / B;
+  const int a = (int)(r % A);
+  const int t = (int)(r / A);
+  const float* p = part + ((i64)t * A + a) * BP + b;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < chunks; c += 256) s += p[(i64)c * slab];
+  red[threadIdx.x] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* d = dw + a * sa + b * sb + t;
+    *d = accumulate ? *d + red[0] : red[0];
+  }
+}
+
 extern "C" int seg3d_wgrad_reduce(const float* part, float* dw, int chunks, int T, int A, int B, long long sa,
                                   long long sb, int accumulate, void* stream) {
   SEG3D_REQUIRE(part && dw && chunks > 0 && T > 0 && A > 0 && B > 0, "seg3d_wgrad_reduce: bad arguments");
   const int BP = seg3d_round_up(B, 4);
   i64 total = (i64)T * A * B;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, part, dw,
-                     chunks, T, A, B, BP, (i64)sa, (i64)sb, accumulate);
+  if (chunks >= 512 && total <= 2048)
+    hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, part, dw, chunks, T, A,
+                       B, BP, (i64)sa, (i64)sb, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, part, dw,
+                       chunks, T, A, B, BP, (i64)sa, (i64)sb, accumulate);
   SEG3D_LAUNCH_CHECK("seg3d_wgrad_reduce");
   return SEG3D_OK;
 }

@@ -485,10 +485,10 @@ extern "C" int seg3d_gn_bwd_reduce_bf16(const void* dout, const void* out, const
 }
 
 // finalize: one workgroup per sample sums the partial slabs (fp64), writes abx[n][c][3] and s12[n][2]
-__global__ __launch_bounds__(256) void gn_bwd_finalize_sample_kernel(const float* __restrict__ part,
-                                                                       const float* __restrict__ gamma,
-                                                                       float* __restrict__ abx, float* __restrict__ s12,
-                                                                       int C, int nblk, double M) {
+__device__ __forceinline__ void gn_bwd_finalize_sample_body(const float* __restrict__ part,
+                                                            const float* __restrict__ gamma,
+                                                            float* __restrict__ abx, float* __restrict__ s12,
+                                                            int C, int nblk, double M) {
   // thread = (channel c, slab group p): PARTS groups split the nblk partial slabs; combined in fixed order through LDS
   __shared__ double red[256 * 3];
   __shared__ double red2[2 * 4];
@@ -544,6 +544,50 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_sample_kernel(const float
   }
 }
 
+__global__ __launch_bounds__(256) void gn_bwd_finalize_sample_kernel(const float* __restrict__ part,
+                                                                       const float* __restrict__ gamma,
+                                                                       float* __restrict__ abx, float* __restrict__ s12,
+                                                                       int C, int nblk, double M) {
+  gn_bwd_finalize_sample_body(part, gamma, abx, s12, C, nblk, M);
+}
+
+// Both finalize stages in ONE launch (the two tiny kernels cost 9 + 6 us of a 7 ms bf16 step 29 times): every sample's
+// workgroup takes a ticket when its abx / s12 are written; the workgroup that draws the last ticket runs the parameter
+// stage over all samples (fixed order: same result as the two-kernel path) and puts the ticket counter back to zero,
+// so the counter (one device int, zero before the first call) is reusable by the next call and by graph replays.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_fused_kernel(const float* __restrict__ part,
+                                                                      const float* __restrict__ gamma,
+                                                                      const float* __restrict__ mean_rstd,
+                                                                      float* __restrict__ abx, float* __restrict__ s12,
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                      float* __restrict__ dbias, int* __restrict__ ticket, int N,
+                                                                      int C, int nblk, double S, int acc_mask) {
+  gn_bwd_finalize_sample_body(part, gamma, abx, s12, C, nblk, S * (double)C);
+  __shared__ int is_last;
+  __threadfence();          // this workgroup's abx / s12 are visible device-wide before its ticket is
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = (atomicAdd(ticket, 1) == N - 1);
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) *ticket = 0;
+  const volatile float* vabx = abx;    // written by other workgroups of this launch: read past the L1
+  const volatile float* vs12 = s12;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double dg = 0.0, db = 0.0, dc = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const volatile float* d = vabx + ((i64)n * C + c) * 3;
+      const double A = d[0], B = d[1], X = d[2];
+      dg += B;
+      db += A;
+      dc += (double)mean_rstd[2 * n + 1] * ((double)gamma[c] * A - S * (double)vs12[2 * n] - (double)vs12[2 * n + 1] * X);
+    }
+    dgamma[c] = (acc_mask & 1) ? dgamma[c] + (float)dg : (float)dg;
+    dbeta[c] = (acc_mask & 2) ? dbeta[c] + (float)db : (float)db;
+    if (dbias) dbias[c] = (acc_mask & 4) ? dbias[c] + (float)dc : (float)dc;
+  }
+}
+
 // dgamma[c] = sum_n B, dbeta[c] = sum_n A, dbias[c] = sum_n rstd_n (gamma_c A - S s1_n - s2_n X)
 __global__ __launch_bounds__(256) void gn_bwd_finalize_param_kernel(const float* __restrict__ abx,
                                                                       const float* __restrict__ s12,
@@ -581,6 +625,19 @@ extern "C" int seg3d_gn_bwd_finalize(const float* part, const float* gamma, cons
   hipLaunchKernelGGL(gn_bwd_finalize_param_kernel, dim3(seg3d_cdiv(C, 256)), dim3(256), 0, s, abx, s12, mean_rstd, gamma,
                      dgamma, dbeta, dbias, N, C, (double)S, acc_mask);
   SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_finalize(param)");
+  return SEG3D_OK;
+}
+
+// the same with one launch; ticket: one device int that is zero before the first call (left zero by every call)
+extern "C" int seg3d_gn_bwd_finalize_fused(const float* part, const float* gamma, const float* mean_rstd, float* abx,
+                                           float* s12, float* dgamma, float* dbeta, float* dbias, int* ticket, int N,
+                                           long long S, int C, int acc_mask, void* stream) {
+  SEG3D_REQUIRE(part && gamma && mean_rstd && abx && s12 && dgamma && dbeta && ticket && N > 0 && S > 0 && C > 0,
+                "seg3d_gn_bwd_finalize_fused: bad arguments");
+  const int nblk = (int)seg3d_gn_bwd_blocks(S);
+  hipLaunchKernelGGL(gn_bwd_finalize_fused_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, part, gamma, mean_rstd, abx, s12,
+                     dgamma, dbeta, dbias, ticket, N, C, nblk, (double)S, acc_mask);
+  SEG3D_LAUNCH_CHECK("seg3d_gn_bwd_finalize_fused");
   return SEG3D_OK;
 }
 

@@ -96,6 +96,7 @@ _SIGNATURES = {
     'seg3d_gn_bwd_blocks': (_c_ll, [_c_ll]),
     'seg3d_gn_bwd_reduce': (_c_int, [_c_p] * 7 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_p]),
     'seg3d_gn_bwd_finalize': (_c_int, [_c_p] * 8 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
+    'seg3d_gn_bwd_finalize_fused': (_c_int, [_c_p] * 9 + [_c_int, _c_ll, _c_int, _c_int, _c_p]),
     'seg3d_gn_bwd_apply': (_c_int, [_c_p] * 9 + [_c_int, _c_ll, _c_int, _c_int, _c_int, _c_p]),
     'seg3d_softmax_fwd': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),
     'seg3d_softmax_bwd': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_ll, _c_p]),

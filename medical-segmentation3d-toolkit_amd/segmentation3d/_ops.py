@@ -611,6 +611,20 @@ def _row_stride(t, C):
     return ld
 
 
+# GroupNorm backward: both finalize stages in one launch (SEG3D_GN_FUSED_FINALIZE=0: two kernels).  The fused kernel takes
+# a ticket counter that is zero between calls; one per device, shared by all GroupNorm backward calls -- they are issued
+# on one stream (the weight-gradient side stream never runs GroupNorm), so two launches never hold tickets at once.
+GN_FUSED_FINALIZE = os.environ.get('SEG3D_GN_FUSED_FINALIZE', '1') != '0'
+_GN_TICKETS = {}
+
+
+def _gn_ticket(device):
+    t = _GN_TICKETS.get(device)
+    if t is None:
+        t = _GN_TICKETS[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
 def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_dbias=True, sinks=(None, None, None),
                 dy_bf16=False):
     """returns (dy, dres or None, dgamma, dbeta, dbias or None).  `outn` (the unit's forward output) is only read when
@@ -647,8 +661,12 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
     dbeta = _empty((C,), yn) if sb_ is None else sb_
     dbias = (_empty((C,), yn) if sc is None else sc) if want_dbias else None
     acc_mask = (1 if sg is not None else 0) | (2 if sb_ is not None else 0) | (4 if (want_dbias and sc is not None) else 0)
-    E.call('seg3d_gn_bwd_finalize', E.ptr(part), E.ptr(gamma), E.ptr(mean_rstd), E.ptr(abx), E.ptr(s12), E.ptr(dgamma),
-           E.ptr(dbeta), E.ptr(dbias), N, S, C, acc_mask, E.stream_ptr())
+    if GN_FUSED_FINALIZE:
+        E.call('seg3d_gn_bwd_finalize_fused', E.ptr(part), E.ptr(gamma), E.ptr(mean_rstd), E.ptr(abx), E.ptr(s12),
+               E.ptr(dgamma), E.ptr(dbeta), E.ptr(dbias), E.ptr(_gn_ticket(yn.device)), N, S, C, acc_mask, E.stream_ptr())
+    else:
+        E.call('seg3d_gn_bwd_finalize', E.ptr(part), E.ptr(gamma), E.ptr(mean_rstd), E.ptr(abx), E.ptr(s12), E.ptr(dgamma),
+               E.ptr(dbeta), E.ptr(dbias), N, S, C, acc_mask, E.stream_ptr())
     dy = torch.empty(yn.shape, dtype=torch.bfloat16 if dy_bf16 else torch.float32, device=yn.device)
     dres = torch.empty(yn.shape, dtype=torch.float32, device=yn.device) if want_dres else None
     if act_bf16:

@@ -123,6 +123,11 @@ int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const void* wp_mfma, const fl
 int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const void* wp_mfma, const float* bias, void* y,
                                 float* stats_partial, int N, int Di, int Hi, int Wi, int Cin, int Cout, int out_bf16,
                                 int w_bf16, void* stream);
+/* stride-2 conv data-gradient with the skip connection's gradient folded into the epilogue (y = scatter(x) + addend;
+ * DownBlock.down_conv = nn.Conv3d(in, out, 2, stride=2), network/module/vnet_downblock.py:11, whose input also feeds
+ * torch.cat in vnet_upblock.py:21).  x_mode 0: fp32; 1: bf16 x, fp32 weight image; 2: bf16 x and image */
+int seg3d_convT3d_k2s2_scatter_addend(const void* x, int x_mode, const void* wp, const void* addend, int ld_addend, void* y,
+                                      int N, int Di, int Hi, int Wi, int Cin, int Cout, int out_bf16, void* stream);
 int seg3d_k2_bf16_wgrad(const void* P_bf16, const void* Q_bf16, float* dw, float* workspace, int N, int Dq, int Hq, int Wq,
                         int CA, int CB, long long sa, long long sb, int accumulate, void* stream);
 int seg3d_conv3d_k3_thin_out_bf16_fwd(const void* x_bf16, const float* wq, const float* bias, float* y,

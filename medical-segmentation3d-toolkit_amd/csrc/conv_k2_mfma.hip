@@ -305,13 +305,16 @@ extern "C" int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const void* wp, co
 // ---------------------------------------------------------------------------------------------------------------
 // scatter: input tile TZ x TY x TX (<= 128 voxels), one accumulator per tap, output cell 2^3 per input voxel
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, bool OUT_BF = false>
+// ADD (data-gradient of a stride-2 conv whose input has a second consumer -- the skip connection): y = result + addend,
+// addend in y's dtype with row stride lda (a channel slice of the concatenated gradient); Cout % 8 == 0
+template <int MODE, bool OUT_BF = false, bool ADD = false>
 __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* __restrict__ x,
                                                                      const float* __restrict__ wp,
                                                                      const float* __restrict__ bias,
                                                                      float* __restrict__ y, float* __restrict__ stats,
                                                                      int N, int Di, int Hi, int Wi, int Cin, int Cout,
-                                                                     int TZ, int TY, int TX, int ntz, int nty, int ntx) {
+                                                                     int TZ, int TY, int TX, int ntz, int nty, int ntx,
+                                                                     const void* __restrict__ addend, int lda) {
   __shared__ __attribute__((aligned(16))) float xs[2 * 128 * 4];     // [2][MT<=128][4]
   __shared__ __attribute__((aligned(16))) float ws[K2_W_CHUNK];      // [8][2][32][4]
   __shared__ int obase[128];                                         // output voxel index of tap (0,0,0) or -1
@@ -409,17 +412,30 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
     const int ng = (Cout - cob * 32 + 7) / 8 < 4 ? (Cout - cob * 32 + 7) / 8 : 4;   // uniform; Cout % 8 == 0 fast path
     if ((Cout & 7) == 0) {
       if (o >= 0) {
+        // ADD: the addend quads of tap t + 1 are requested before tap t is stored (loads and stores share vmcnt)
+        typename Seg3dQuad<OUT_BF>::raw ar[2][4];
+        auto load_addend = [&](int tap, typename Seg3dQuad<OUT_BF>::raw (&dst)[4]) {
+          const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
+          const i64 src = ((i64)o + (kz * Ho + ky) * Wo + kx) * lda + co0;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            if (g4 < ng) dst[g4] = Seg3dQuad<OUT_BF>::load(addend, src + 8 * g4);
+        };
+        if (ADD) load_addend(0, ar[0]);
 #pragma unroll
         for (int tap = 0; tap < 8; ++tap) {
           const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
           const i64 dsto = ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co0;
+          if (ADD && tap + 1 < 8) load_addend(tap + 1, ar[(tap + 1) & 1]);
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             if (g4 < ng) {
               f32x4 v;
+              f32x4 av = {0.f, 0.f, 0.f, 0.f};
+              if (ADD) av = Seg3dQuad<OUT_BF>::cvt(ar[tap & 1][g4]);
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
-                v[c] = acc[tap][4 * g4 + c] + bv[g4][c];
+                v[c] = acc[tap][4 * g4 + c] + bv[g4][c] + av[c];
                 s[0] += v[c];
                 s[1] += v[c] * v[c];
               }
@@ -469,7 +485,8 @@ extern "C" long long seg3d_convT3d_k2s2_mfma_stats_count(int Di, int Hi, int Wi,
 
 // x [N][Di][Hi][Wi][Cin] -> y [N][2Di][2Hi][2Wi][Cout];  wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 8)
 static int k2_scatter_launch(const void* x, int x_bf16, const float* wp, const float* bias, float* y, float* stats, int N,
-                             int Di, int Hi, int Wi, int Cin, int Cout, void* stream, int out_bf16 = 0) {
+                             int Di, int Hi, int Wi, int Cin, int Cout, void* stream, int out_bf16 = 0,
+                             const void* addend = nullptr, int lda = 0) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_convT3d_k2s2_mfma_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && Di > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "seg3d_convT3d_k2s2_mfma_fwd: bad dims");
   SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
@@ -481,9 +498,17 @@ static int k2_scatter_launch(const void* x, int x_bf16, const float* wp, const f
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "2x2x2 stride-2 MFMA kernels: more than 2^22 tiles");
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
   SEG3D_REQUIRE(x_bf16 != 2 || (Cin % 16) == 0, "seg3d_convT3d_k2s2_bf16_fwd: the bf16 weight image needs Cin %% 16 == 0");
+  SEG3D_REQUIRE(!addend || ((Cout & 7) == 0 && lda >= Cout && (lda & 3) == 0),
+                "seg3d_convT3d_k2s2_scatter_addend: needs Cout %% 8 == 0 and a row stride >= Cout, multiple of 4");
 #define K2_SCATTER(MODE_, OB_)                                                                                       \
-  hipLaunchKernelGGL((convT3d_k2s2_mfma_kernel<MODE_, OB_>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, stats, \
-                     N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx)
+  do {                                                                                                               \
+    if (addend)                                                                                                      \
+      hipLaunchKernelGGL((convT3d_k2s2_mfma_kernel<MODE_, OB_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
+                         stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, addend, lda);             \
+    else                                                                                                             \
+      hipLaunchKernelGGL((convT3d_k2s2_mfma_kernel<MODE_, OB_, false>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
+                         stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, addend, lda);             \
+  } while (0)
   if (x_bf16 == 2 && out_bf16) K2_SCATTER(2, true);
   else if (x_bf16 == 2) K2_SCATTER(2, false);
   else if (x_bf16 && out_bf16) K2_SCATTER(1, true);
@@ -504,6 +529,18 @@ extern "C" int seg3d_convT3d_k2s2_bf16_fwd(const void* x_bf16, const void* wp, c
                                            void* stream) {
   return k2_scatter_launch(x_bf16, w_bf16 ? 2 : 1, reinterpret_cast<const float*>(wp), bias, reinterpret_cast<float*>(y),
                            stats, N, Di, Hi, Wi, Cin, Cout, stream, out_bf16);
+}
+
+// data-gradient form with a second gradient of the same tensor folded into the epilogue: y = scatter(x) + addend.
+// x_mode: 0 fp32 x / fp32 image, 1 bf16 x / fp32 image, 2 bf16 x / bf16 image; addend has y's dtype (bf16 iff out_bf16)
+// and row stride ld_addend elements (a channel slice of a wider tensor); Cout % 8 == 0
+extern "C" int seg3d_convT3d_k2s2_scatter_addend(const void* x, int x_mode, const void* wp, const void* addend, int ld_addend,
+                                                 void* y, int N, int Di, int Hi, int Wi, int Cin, int Cout, int out_bf16,
+                                                 void* stream) {
+  SEG3D_REQUIRE(addend && x_mode >= 0 && x_mode <= 2 && (x_mode != 0 || !out_bf16),
+                "seg3d_convT3d_k2s2_scatter_addend: bad arguments");
+  return k2_scatter_launch(x, x_mode, reinterpret_cast<const float*>(wp), nullptr, reinterpret_cast<float*>(y), nullptr, N, Di,
+                           Hi, Wi, Cin, Cout, stream, out_bf16, addend, ld_addend);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

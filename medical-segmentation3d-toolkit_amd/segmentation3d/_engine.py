@@ -57,6 +57,7 @@ _SIGNATURES = {
     'seg3d_conv3d_k3_bf16_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 7 + [_c_p]),
     'seg3d_conv3d_k2s2_bf16_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 8 + [_c_p]),
     'seg3d_convT3d_k2s2_bf16_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 8 + [_c_p]),
+    'seg3d_convT3d_k2s2_scatter_addend': (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_int, _c_p] + [_c_int] * 7 + [_c_p]),
     'seg3d_k2_bf16_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 6 + [_c_ll, _c_ll, _c_int, _c_p]),
     'seg3d_conv3d_k3_thin_out_bf16_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 7 + [_c_p]),
     'seg3d_conv3d_k3_thin_in_mfma16_supported': (_c_int, [_c_int] * 2),

@@ -441,6 +441,22 @@ def _check_w(w, shape, kind):
         raise ValueError('conv weights must be contiguous')
 
 
+# stride-2 conv data-gradient: the skip connection's gradient is added in the kernel epilogue (SEG3D_K2_DGRAD_ADDEND=0:
+# separate elementwise add, as autograd would do)
+K2_DGRAD_ADDEND = os.environ.get('SEG3D_K2_DGRAD_ADDEND', '1') != '0'
+
+
+def _addend_row_stride(t, C):
+    """row stride (elements) of an NDHWC tensor or channel slice whose voxels are evenly spaced rows; 0 if it is not one"""
+    if t.dim() != 5 or t.shape[4] != C or t.stride(4) != 1:
+        return 0
+    ld = t.stride(3)
+    if ld < C or ld % 4 or t.stride(2) != ld * t.shape[3] or t.stride(1) != ld * t.shape[3] * t.shape[2] or \
+            t.stride(0) != ld * t.shape[3] * t.shape[2] * t.shape[1]:
+        return 0
+    return ld
+
+
 def conv_dgrad(dyn, w, kind, addend=None, want_bf16=None):
     """gradient w.r.t. the conv input (+ addend, an extra gradient for the same tensor that is folded into the kernel
     epilogue); dyn: [N,Do,Ho,Wo,Cout] contiguous.  want_bf16: the input is a bf16 activation, so its gradient should be
@@ -455,6 +471,21 @@ def conv_dgrad(dyn, w, kind, addend=None, want_bf16=None):
         dx, _ = _conv_k3_generic(dyn, w, None, Cout, Cin, Cin * 27, 27, 1, False, addend=addend, out_bf16=want_bf16)
         return dx
     if addend is not None:
+        if kind == 'k2s2' and K2_DGRAD_ADDEND:
+            Cout, Cin = w.shape[0], w.shape[1]
+            dy16 = _is_bf16(dyn) and _use_mfma(Cout, Cin) and Cin % 4 == 0
+            ld = _addend_row_stride(addend, Cin)
+            if _use_mfma(Cout, Cin) and Cin % 8 == 0 and ld and _is_bf16(addend) == dy16 and \
+                    tuple(addend.shape) == (N, 2 * D, 2 * H, 2 * W_, Cin):
+                # the skip connection's gradient (a channel slice of the concatenated gradient) joins in the epilogue
+                if _is_bf16(dyn) and not dy16:
+                    dyn = _to_f32(dyn)
+                w16 = dy16 and Cout % 16 == 0 and K2_BF16_MFMA
+                wp = _pack_mfma(w, Cout, Cin, 8, Cin * 8, 8, bf16=w16)
+                dx = _empty((N, 2 * D, 2 * H, 2 * W_, Cin), dyn, dyn.dtype)
+                E.call('seg3d_convT3d_k2s2_scatter_addend', E.ptr(dyn), (2 if w16 else 1) if dy16 else 0, E.ptr(wp),
+                       E.ptr(addend), ld, E.ptr(dx), N, D, H, W_, Cout, Cin, int(dy16), E.stream_ptr())
+                return dx
         return conv_dgrad(dyn, w, kind).add_(addend)
     if _is_bf16(dyn):
         cout, cin = (w.shape[0], w.shape[1]) if kind == 'k2s2' else (w.shape[1], w.shape[0])
@@ -836,8 +867,9 @@ class UpCatFunction(torch.autograd.Function):
     to autograd as a strided view of it (no copy either)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, skip, relu, eps):
+    def forward(ctx, x, weight, bias, gamma, beta, skip, relu, eps, link_out=None):
         E.require_device(x, weight, bias, gamma, beta, skip)
+        ctx.link_out = link_out
         xn = to_ndhwc(x)
         sn = to_ndhwc(skip)
         w = weight.detach()
@@ -879,12 +911,19 @@ class UpCatFunction(torch.autograd.Function):
                 _wgrad_to_sink(xn, dy, ctx.w_shape, 'convT', sw.view)
             else:
                 dw = conv_wgrad(xn, dy, ctx.w_shape, 'convT')
-        dskip = from_ndhwc(dn[..., ctx.ca:]) if ctx.needs_input_grad[5] else None     # strided view, no copy
-        return dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta, dskip, None, None
+        dskip = None
+        if ctx.needs_input_grad[5]:
+            if ctx.link_out is not None:
+                # the skip tensor's other consumer (the next DownBlock's stride-2 conv) runs later in backward and adds
+                # this slice in its data-gradient epilogue: no elementwise pass over two full tensors
+                ctx.link_out.grad = dn[..., ctx.ca:]
+            else:
+                dskip = from_ndhwc(dn[..., ctx.ca:])                                  # strided view, no copy
+        return dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta, dskip, None, None, None
 
 
-def up_cat(x, weight, bias, gamma, beta, skip, relu=True, eps=GN_EPS):
-    return UpCatFunction.apply(x, weight, bias, gamma, beta, skip, relu, eps)
+def up_cat(x, weight, bias, gamma, beta, skip, relu=True, eps=GN_EPS, link_out=None):
+    return UpCatFunction.apply(x, weight, bias, gamma, beta, skip, relu, eps, link_out)
 
 
 class ConvFunction(torch.autograd.Function):

@@ -8,6 +8,8 @@ of truth; attribute names match the reference so checkpoints keep their keys.
 import torch
 import torch.nn as nn
 
+from segmentation3d import _ops
+
 from segmentation3d.network.module.vnet_inblock import InputBlock
 from segmentation3d.network.module.vnet_outblock import OutputBlock
 from segmentation3d.network.module.vnet_upblock import UpBlock
@@ -41,12 +43,16 @@ class VNetBase(nn.Module):
             raise ValueError('input must be [N, C, D, H, W] with D, H, W divisible by {} (got {})'.format(
                 MAX_STRIDE, tuple(input.shape)))
         feats = {'in_block': self.in_block(input)}
-        x = feats['in_block']
+        x, source = feats['in_block'], 'in_block'
+        # every encoder feature but the deepest has two consumers: the next DownBlock and a decoder skip.  The link lets the
+        # DownBlock's data-gradient kernel add the skip gradient instead of autograd summing two full tensors.
+        links = {}
         for name, _, _ in ENCODER_STAGES:
-            x = getattr(self, name)(x)
-            feats[name] = x
+            links[source] = _ops.ResidualLink() if (x.requires_grad and torch.is_grad_enabled()) else None
+            x = getattr(self, name)(x, skip_link=links[source])
+            feats[name], source = x, name
         for name, _, _, _, skip in DECODER_STAGES:
-            x = getattr(self, name)(x, feats[skip])
+            x = getattr(self, name)(x, feats[skip], skip_link=links.get(skip))
         return self.out_block(x)
 
     def max_stride(self):

@@ -21,5 +21,7 @@ class DownBlock(nn.Module):
         attach_unit(self, _DOWN, 'k2s2', in_channels, width)
         self.rblock = make_residual_block(width, num_convs, compression, ratio)
 
-    def forward(self, input):
-        return self.rblock(run_unit(self, _DOWN, input, relu=True))
+    def forward(self, input, skip_link=None):
+        """skip_link: _ops.ResidualLink shared with the UpBlock that concatenates `input` as its skip tensor; in backward
+        that block parks the skip gradient there and the stride-2 conv's data-gradient kernel adds it"""
+        return self.rblock(run_unit(self, _DOWN, input, relu=True, link_in=skip_link))

@@ -22,10 +22,11 @@ class UpBlock(nn.Module):
         attach_unit(self, _UP, 'convT', in_channels, out_channels // 2)
         self.rblock = make_residual_block(out_channels, num_convs, compression, ratio)
 
-    def forward(self, input, skip):
+    def forward(self, input, skip, skip_link=None):
         conv, gn = self.up_conv, self.up_gn
         if conv.out_channels % 4 == 0 and skip.shape[1] % 4 == 0:
-            merged = _ops.up_cat(input, conv.weight, conv.bias, gn.weight, gn.bias, skip, relu=True, eps=gn.eps)
+            merged = _ops.up_cat(input, conv.weight, conv.bias, gn.weight, gn.bias, skip, relu=True, eps=gn.eps,
+                                 link_out=skip_link)
         else:   # odd channel counts: separate concatenation kernel
             merged = _ops.cat_channels(run_unit(self, _UP, input, relu=True), skip)
         return self.rblock(merged)

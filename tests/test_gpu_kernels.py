@@ -464,6 +464,34 @@ def test_strided_convs_fwd_bwd(hip_device, kind, cin, cout, dims, force_direct):
     assert e.get('stat_sum', 0.0) < 1e-5 and e.get('stat_sq', 0.0) < 1e-5, e
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 32, 16, 4, 4, 8, 16), (1, 64, 32, 3, 5, 6, 0), (1, 16, 8, 2, 2, 2, 24)])
+def test_k2s2_dgrad_with_skip_addend(hip_device, shape, mode):
+    """stride-2 conv data-gradient with the skip gradient (a channel slice of a wider tensor) added in the epilogue equals
+    the plain data-gradient + the slice, bit for bit in fp32 and to one bf16 rounding of the sum in bf16 mode"""
+    from segmentation3d import _ops
+    N, Cout, Cin, D, H, W, extra = shape
+    bf = mode == 'bf16'
+    dy = _t(81, 'kdy', (N, Cout, D, H, W)).to(hip_device)
+    w = _t(82, 'kw', (Cout, Cin, 2, 2, 2), std=0.2).to(hip_device)
+    wide = _t(83, 'kadd', (N, 2 * D, 2 * H, 2 * W, extra + Cin)).to(hip_device)
+    dyn = _ops.to_ndhwc(dy)
+    if bf:
+        dyn, wide = dyn.bfloat16(), wide.bfloat16()
+    addend = wide[..., extra:]
+    plain = _ops.conv_dgrad(dyn, w, 'k2s2')
+    fused = _ops.conv_dgrad(dyn, w, 'k2s2', addend=addend)
+    assert fused.dtype == plain.dtype and fused.shape == plain.shape
+    if bf and plain.dtype == torch.bfloat16:
+        # plain was rounded once before the add; compare against the fp32 data-gradient of the same bf16 operands
+        exact = _ops.conv_dgrad(dyn.float(), w, 'k2s2') + addend.float()
+        scale = float(exact.abs().max())
+        assert float((fused.float() - exact).abs().max()) < (2.0 ** -8 + 1e-3) * scale
+    else:
+        assert torch.equal(fused, plain + addend)
+    report('k2s2_dgrad_addend_{}_{}'.format(mode, 'x'.join(str(v) for v in shape)), fused_is_bf16=float(fused.dtype == torch.bfloat16))
+
+
 @pytest.mark.parametrize('C,dims,relu,with_res', [
     (16, (2, 8, 8, 8), True, False), (32, (1, 6, 10, 12), True, True), (256, (2, 2, 3, 3), False, True),
     (2, (2, 8, 8, 8), True, False), (5, (1, 4, 6, 8), False, False), (64, (1, 20, 20, 24), True, False),

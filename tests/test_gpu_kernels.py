@@ -464,6 +464,44 @@ def test_strided_convs_fwd_bwd(hip_device, kind, cin, cout, dims, force_direct):
     assert e.get('stat_sum', 0.0) < 1e-5 and e.get('stat_sq', 0.0) < 1e-5, e
 
 
+def test_gn_backward_fused_finalize_equals_two_launches(hip_device):
+    """GroupNorm backward with both finalize stages in one launch (last-ticket workgroup) is bit-identical to the
+    two-launch path, repeatedly (the ticket counter returns to zero), with and without gradient sinks"""
+    from segmentation3d import _ops
+    N, C, D, H, W = 3, 64, 6, 10, 12
+    y = _ops.to_ndhwc(_t(91, 'fy', (N, C, D, H, W)).to(hip_device))
+    dout = _ops.to_ndhwc(_t(92, 'fd', (N, C, D, H, W)).to(hip_device))
+    gamma, beta = _t(93, 'fg', (C,)).to(hip_device), _t(94, 'fb', (C,)).to(hip_device)
+    mean_rstd = torch.stack([y.reshape(N, -1).mean(1), 1.0 / (y.reshape(N, -1).var(1, unbiased=False) + 1e-5).sqrt()], 1).contiguous()
+    results = []
+    for fused in (False, True, True, False, True):
+        _ops.GN_FUSED_FINALIZE = fused
+        try:
+            sink = torch.ones(C, device=hip_device)
+            dy, _, dgamma, dbeta, dbias = _ops.gn_backward(dout, None, y, mean_rstd, gamma, beta, True, want_dres=False,
+                                                           want_dbias=True, sinks=(None, sink, None))
+            results.append((dy, dgamma, sink, dbias))
+        finally:
+            _ops.GN_FUSED_FINALIZE = True
+    assert int(_ops._gn_ticket(hip_device).item()) == 0
+    for r in results[1:]:
+        for a, b in zip(results[0], r):
+            assert torch.equal(a, b)
+    assert dbeta is None
+
+
+def test_wgrad_reduce_many_chunks(hip_device):
+    """1x1x1 conv weight gradient over enough voxels for the chunk-parallel reduce (>= 512 partial chunks, 4 outputs)"""
+    from segmentation3d import _ops
+    N, C, D, H, W = 2, 2, 48, 48, 48
+    x = _t(95, 'rx', (N, C, D, H, W))
+    dy = _t(96, 'rdy', (N, C, D, H, W))
+    dw = _ops.conv_wgrad(_ops.to_ndhwc(x.to(hip_device)), _ops.to_ndhwc(dy.to(hip_device)), (C, C, 1, 1, 1), 'k1')
+    ref = torch.einsum('nodhw,nidhw->oi', dy.double(), x.double()).reshape(C, C, 1, 1, 1)
+    assert rel_err(dw.double().cpu(), ref) < 1e-5
+    report('wgrad_reduce_many_chunks', rel_err=rel_err(dw.double().cpu(), ref))
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 32, 16, 4, 4, 8, 16), (1, 64, 32, 3, 5, 6, 0), (1, 16, 8, 2, 2, 2, 24)])
 def test_k2s2_dgrad_with_skip_addend(hip_device, shape, mode):

@@ -1401,15 +1401,16 @@ static int seg3d_thin_wgrad_bf16_mfma_enabled() {   // SEG3D_THIN_WGRAD_BF16_MFM
 }
 
 // dw[ct*s_ct + cf*s_cf + (flip ? 26 - t : t)] = sum_slab part[slab][cfb][row = t*CT + ct][cf % 32]
-// 16 outputs x 16 slab groups per workgroup (the output is tiny: the reduction over <= 512 slabs is the work),
-// combined through LDS in a fixed order.
+// 4 outputs x 64 slab groups per workgroup (the output is tiny: the reduction over <= 512 slabs is the work, and it sits
+// at the very end of backward where nothing overlaps it: 16 x 16 left each thread 32 dependent-latency loads), combined
+// through LDS in a fixed order.
 __global__ __launch_bounds__(256) void k3_thin_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                      int slabs, int CT, int CF, int CFB, int RB, i64 s_ct,
                                                                      i64 s_cf, int flip, int accumulate) {
   __shared__ float red[256];
   const i64 total = (i64)27 * CT * CF;
-  const i64 idx = (i64)blockIdx.x * 16 + (threadIdx.x & 15);
-  const int g = threadIdx.x >> 4;
+  const i64 idx = (i64)blockIdx.x * 4 + (threadIdx.x & 3);
+  const int g = threadIdx.x >> 2;
   float s = 0.f;
   int t = 0, ct = 0, cf = 0;
   if (idx < total) {
@@ -1418,14 +1419,14 @@ __global__ __launch_bounds__(256) void k3_thin_wgrad_reduce_kernel(const float* 
     t = row / CT;
     ct = row % CT;
     const float* p = part + ((i64)(cf >> 5) * RB * 1024) + (i64)row * 32 + (cf & 31);
-    for (int k = g; k < slabs; k += 16) s += p[(i64)k * CFB * RB * 1024];
+    for (int k = g; k < slabs; k += 64) s += p[(i64)k * CFB * RB * 1024];
   }
   red[threadIdx.x] = s;
   __syncthreads();
   if (g == 0 && idx < total) {
     float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v += red[k * 16 + threadIdx.x];
+    for (int k = 0; k < 64; ++k) v += red[k * 4 + threadIdx.x];
     float* d = dw + ct * s_ct + cf * s_cf + (flip ? 26 - t : t);
     *d = accumulate ? *d + v : v;
   }
@@ -1513,7 +1514,7 @@ static int thin_wgrad_launch(const float* thin, const void* fat, int fat_bf16, f
   }
   SEG3D_LAUNCH_CHECK("seg3d_k3_thin_wgrad");
   const i64 total = (i64)27 * CT * CF;
-  hipLaunchKernelGGL(k3_thin_wgrad_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, workspace, dw, slabs, CT, CF,
+  hipLaunchKernelGGL(k3_thin_wgrad_reduce_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, workspace, dw, slabs, CT, CF,
                      CFB, RB, (i64)s_ct, (i64)s_cf, flip, accumulate);
   SEG3D_LAUNCH_CHECK("seg3d_k3_thin_wgrad(reduce)");
   return SEG3D_OK;

@@ -280,6 +280,12 @@ def main():
             step(x, t)
     for _ in range(args.warmup):
         loss = step(x, t)
+    if not step.use_graph and os.environ.get('SEG3D_BENCH_GC_FREEZE', '1') != '0':
+        # eager steps (the multi-GPU path): the objects that live for the whole run leave the collector's young generations,
+        # so the collections triggered by a step's short-lived autograd objects stay short (standard training-loop practice)
+        import gc
+        gc.collect()
+        gc.freeze()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

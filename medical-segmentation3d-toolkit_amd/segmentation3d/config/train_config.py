@@ -42,6 +42,7 @@ __C.train.save_epochs = 100
 # extensions of this build (absent keys mean the reference's behaviour: fp32, eager steps)
 __C.train.compute_dtype = 'fp32'                       # 'bf16': bf16 activations / packed weights, fp32 accumulate + master weights
 __C.train.use_graph = False                            # capture the whole train step in one hipGraph (single process only)
+__C.train.gc_freeze = True                             # gc.freeze() after the first steps: short collector pauses in the eager loop
 
 __C.debug = {}
 __C.debug.save_inputs = False

@@ -159,8 +159,14 @@ def pmc_traffic_gb(kernel_name):
 
 
 def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):
-    """oracle train step (stock torch CPU ops + torch.optim.Adam), B = 1, on this host: ~10-30 s of CPU work"""
-    from oracle import torch_ref
+    """the CPU side of every number this file reports, on this box's host cores, with
+    oracle/torch_ref.py + oracle/numpy_ref.py = the stock torch CPU ops and host loops the reference composes:
+      * train step (fwd + loss + bwd + torch.optim.Adam) at batch 1 (2 timed steps after a warm-up) and batch 4 (1 step);
+      * forward only, batch 1 (2 timed);
+      * BASELINE config 1: whole-volume sliding window over a synthetic 128^3 volume (96^3 boxes, stride 48 => 8 patches,
+        adaptive normaliser, accumulate, divide, arg-max) with ONE forward per patch and with the reference's TWO.
+    A bounded sample (~1 minute of CPU work on the 8-core build container class of host, less on the GPU box)."""
+    from oracle import numpy_ref, torch_ref
     from segmentation3d.network import vnet, vbnet
     plugin = {'vnet': vnet, 'vbnet': vbnet}[net_name]
     torch.manual_seed(0)
@@ -168,29 +174,53 @@ def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):
     plugin.parameters_kaiming_init(net)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     opt = torch.optim.Adam(list(sd.values()), lr=1e-4, betas=(0.9, 0.999))
-    x, t = synthetic_batch(1, cin, ncls, patch, torch.device('cpu'), 123)
+    x4, t4 = synthetic_batch(4, cin, ncls, patch, torch.device('cpu'), 123)
+    x, t = x4[:1].contiguous(), t4[:1].contiguous()
     kw = {'weights': [1.0 / ncls] * ncls} if loss_name == 'Dice' else {'class_num': ncls, 'alpha': None, 'gamma': 2}
     times = []
-    for i in range(4):
+    for i in range(3):
         t0 = time.time()
         torch_ref.train_step(sd, opt, x, t, net_name, loss_name, kw)
         times.append(time.time() - t0)
     steady = times[1:]
-    # the CPU side of the inference metric (BASELINE config 1 / 4: one forward per 96^3 patch): same oracle, forward only
+    t0 = time.time()
+    torch_ref.train_step(sd, opt, x4, t4, net_name, loss_name, kw)
+    step_b4 = time.time() - t0
     fwd = []
+    sd_eval = {k: v.detach() for k, v in sd.items()}
     with torch.no_grad():
-        sd_eval = {k: v.detach() for k, v in sd.items()}
         for i in range(3):
             t0 = time.time()
             torch_ref.segmentation_net(x, sd_eval, net_name)
             fwd.append(time.time() - t0)
     fwd_steady = fwd[1:]
-    return {'value': round(1.0 / (sum(steady) / len(steady)), 4), 'unit': 'patches/s', 'cores': torch.get_num_threads(),
-            'forward_only_patches_per_s': round(1.0 / (sum(fwd_steady) / len(fwd_steady)), 4),
-            'kind': 'port',
-            'sample': '{} timed train steps (fwd+{}+bwd+Adam) of {}({},{}) on one {}^3 patch, batch 1, after 1 warm-up; '
-                      'oracle/torch_ref.py = the stock torch CPU ops the reference composes'.format(
-                          len(steady), loss_name, net_name, cin, ncls, patch)}
+    out = {'value': round(1.0 / (sum(steady) / len(steady)), 4), 'unit': 'patches/s', 'cores': torch.get_num_threads(),
+           'batch4_patches_per_s': round(4.0 / step_b4, 4),
+           'forward_only_patches_per_s': round(1.0 / (sum(fwd_steady) / len(fwd_steady)), 4),
+           'kind': 'port',
+           'sample': '{} timed train steps (fwd+{}+bwd+Adam) of {}({},{}) on one {}^3 patch, batch 1, after 1 warm-up, plus 1 '
+                     'step at batch 4 and 2 forward-only passes; oracle/torch_ref.py = the stock torch CPU ops the '
+                     'reference composes'.format(len(steady), loss_name, net_name, cin, ncls, patch)}
+    if cin == 1:
+        vol = torch.randn((128, 128, 128), generator=torch.Generator().manual_seed(11)).numpy()
+
+        def net_fn(a):
+            with torch.no_grad():
+                return torch_ref.segmentation_net(torch.from_numpy(a), sd_eval, net_name).numpy()
+        secs = {}
+        for label, double in (('single_forward', False), ('double_forward_as_reference', True)):
+            t0 = time.time()
+            _, _, (starts, _) = numpy_ref.sliding_window_inference(vol, net_fn, ncls, (1.0, 1.0, 1.0), [float(patch)] * 3,
+                                                                    [patch / 2.0] * 3, 16, {'type': 1, 'clip_sigma': 3},
+                                                                    double_forward=double)
+            secs[label] = round(time.time() - t0, 3)
+        out['config1_whole_volume_128'] = {'patches': len(starts), 'seconds_' + 'single_forward': secs['single_forward'],
+                                           'seconds_double_forward_as_reference': secs['double_forward_as_reference'],
+                                           'what': 'oracle/numpy_ref.sliding_window_inference on a synthetic 128^3 volume, '
+                                                   '{0}^3 boxes at stride {1}, adaptive normaliser, host accumulate / '
+                                                   'divide / arg-max (BASELINE config 1 without file IO)'.format(
+                                                       patch, patch // 2)}
+    return out
 
 
 def time_inference(net, volume_xyz, patch, stride, ncls, batch, device):
@@ -231,17 +261,50 @@ def time_inference(net, volume_xyz, patch, stride, ncls, batch, device):
             'mask_nonzero': int((mask_host != 0).sum())}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: this process (which has not touched the
+    GPU and never will) starts N ranks, one per GPU, through torch.distributed.run on the loopback address, relays their
+    output (rank 0 prints the JSON line) and exits with their exit code.  The ranks re-enter main() with WORLD_SIZE set."""
+    import socket
+    import subprocess
+    share = os.environ.get('SEG3D_BENCH_SHARE_GPU', '0') == '1'   # rehearsal only: several gloo ranks on one GPU
+    visible = torch.cuda.device_count()                            # (does not initialise the GPU)
+    if visible < args.gpus and not share:
+        sys.stderr.write('bench.py: --gpus {} requested but only {} GPU(s) are visible; refusing to report a {}-GPU number '
+                         'from fewer devices\n'.format(args.gpus, visible, args.gpus))
+        return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if rank == 0:
+            sys.stderr.write('bench.py: --gpus {} does not match WORLD_SIZE {} of the launcher\n'.format(args.gpus, world))
+        sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device (the engine has no CPU path)')
     # one process per GPU over RCCL ("nccl" on ROCm).  SEG3D_DIST_BACKEND=gloo allows rehearsing the N > 1 code path
     # with several ranks sharing one GPU (RCCL refuses two ranks on one device); never used for reported numbers.
     backend = os.environ.get('SEG3D_DIST_BACKEND', 'nccl')
-    dev_index = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if world > ndev and not (backend != 'nccl' and os.environ.get('SEG3D_BENCH_SHARE_GPU', '0') == '1'):
+        raise SystemExit('bench.py: {} ranks but {} visible GPU(s)'.format(world, ndev))
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     if world > 1:
@@ -250,8 +313,6 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0:
-        sys.stderr.write('note: --gpus {} but WORLD_SIZE {}\n'.format(args.gpus, world))
 
     args.graph = (world == 1) and not args.no_graph
     from segmentation3d.core.seg_train import TrainStep
@@ -374,10 +435,18 @@ def main():
     if not args.no_cpu_baseline and world == 1 and rank == 0:
         cpu_baseline = time_cpu_baseline(args.net, args.in_channels, args.classes, args.patch, args.loss)
 
+    collective_lib = 'none'
+    if world > 1:
+        collective_lib = backend
+        if backend == 'nccl':
+            try:
+                collective_lib = 'RCCL {}'.format('.'.join(str(v) for v in torch.cuda.nccl.version()))
+            except Exception:
+                collective_lib = 'RCCL'
     if rank == 0:
         out = {
             'metric': 'patches/sec (96^3, 1-mod V-Net) train-step', 'value': round(value, 3), 'unit': 'patches/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'n_gpus': dist.get_world_size() if world > 1 else 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.dtype == 'fp32' else 'bf16 (activations + packed k3 weights; f32 accumulate, GN statistics, master weights)',
             'data': 'synthetic',
@@ -385,7 +454,8 @@ def main():
                                    '{}, random-init weights'.format(args.net, args.in_channels, args.classes, args.loss,
                                                                     args.batch, args.patch, args.dtype),
                        'global_batch': world * args.batch, 'patch': args.patch,
-                       'parallelism': 'dp{} (bucketed RCCL all-reduce overlapped with backward)'.format(world) if world > 1 else 'single GPU',
+                       'parallelism': 'dp{} (one process per GPU, bucketed {} all-reduce overlapped with backward)'.format(
+                           world, collective_lib) if world > 1 else 'single GPU',
                        'wgrad_overlap': not args.no_wgrad_overlap, 'train_step_hipgraph': bool(args.graph and world == 1)},
             'final_loss': round(final_loss, 6),
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'infer': infer,

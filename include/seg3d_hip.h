@@ -239,6 +239,12 @@ int seg3d_dice_fwd(const float* probs, const float* target, const float* weights
                    int N, int C, long long S, void* stream);
 int seg3d_dice_bwd(const float* probs, const float* target, const float* sums, const float* weights, const float* gout,
                    float* dprobs, int N, int C, long long S, void* stream);
+/* BinaryDiceLoss called on its own (loss/binary_dice_loss.py:9-36): probs [N][2][S], pred = p1 * [p1 > p0] (ties -> 0),
+ * float target; part: [N][seg3d_dice_blocks(S)][3], sums: [N][2] (kept for backward), one: device float 1.0f */
+int seg3d_binary_dice_fwd(const float* probs, const float* target, const float* one, float* part, float* sums, float* loss,
+                          int N, long long S, void* stream);
+int seg3d_binary_dice_bwd(const float* probs, const float* target, const float* sums, const float* gout, float* dprobs,
+                          int N, long long S, void* stream);
 long long seg3d_focal_blocks(long long total_vox);
 int seg3d_focal_fwd(const float* probs, const float* target, const float* alpha, float* part, float* loss, int N, int C,
                     long long S, long long sn, long long sc, long long ss, float gamma, int size_average, void* stream);
@@ -264,7 +270,8 @@ int seg3d_patch_gather_normalize(const float* volume, const int* starts_xyz, flo
 int seg3d_patch_scatter_accumulate(const float* probs, const int* starts_xyz, const int* ctl /* device int32[7] */,
                                    float* acc, float* count, int Z, int Y, int X, int bx, int by, int bz, int C,
                                    long long max_box_voxels, void* stream);
-int seg3d_finalize_argmax(float* acc, const float* count, signed char* mask, int C, long long voxels, void* stream);
+int seg3d_finalize_argmax(float* acc, const float* count, signed char* mask, int C, long long voxels,
+                          long long class_stride, void* stream);
 
 /* ---- evaluation metric: utils/metrics.py:5-37 cal_dsc, core/seg_eval.py:8-57 ---------------
  * counts[3k..3k+2] += (area_gt, area_seg, intersection) of labels_host[k] over two label volumes of n elements;

@@ -209,6 +209,77 @@ extern "C" int seg3d_dice_bwd(const float* probs, const float* target, const flo
   return SEG3D_OK;
 }
 
+// ---- BinaryDiceLoss on its own (loss/binary_dice_loss.py:9-36) ------------------------------------------------------
+// probs [N][2][S]; (value, index) = max over the two channels, value *= index  ==>  pred = p1 where p1 > p0 STRICTLY (a tie
+// takes index 0), else 0; target is used as a float (t * t in the area).  part[n][blk][1][3] = (sum pred t, sum pred^2,
+// sum t^2): the layout of dice_partial_kernel with one class, so dice_finalize_kernel (C = 1, weight 1) finishes it.
+__global__ __launch_bounds__(256) void bdice_partial_kernel(const float* __restrict__ probs, const float* __restrict__ target,
+                                                              float* __restrict__ part, i64 S, int nblk) {
+  __shared__ float red[12];
+  const int n = blockIdx.y;
+  const i64 s0 = (i64)blockIdx.x * DICE_VPB;
+  i64 s1 = s0 + DICE_VPB;
+  if (s1 > S) s1 = S;
+  float v[3] = {0.f, 0.f, 0.f};
+  for (i64 s = s0 + threadIdx.x; s < s1; s += 256) {
+    const float t = target[(i64)n * S + s];
+    const float p0 = probs[((i64)n * 2 + 0) * S + s], p1 = probs[((i64)n * 2 + 1) * S + s];
+    const float ph = p1 > p0 ? p1 : 0.f;
+    v[0] += ph * t;
+    v[1] += ph * ph;
+    v[2] += t * t;
+  }
+  block_sum_256<3>(v, red);
+  if (threadIdx.x == 0) {
+    float* dst = part + ((i64)n * nblk + blockIdx.x) * 3;
+    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+  }
+}
+
+// dprobs[n][1][s] = gout / N * [p1 > p0] * -(2 t (sum + eps) - (2 I + eps) 2 p1) / (sum + eps)^2;  dprobs[n][0][s] = 0
+__global__ __launch_bounds__(256) void bdice_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ target,
+                                                          const float* __restrict__ sums, const float* __restrict__ gout,
+                                                          float* __restrict__ dprobs, int N, i64 S) {
+  const i64 total = (i64)N * S;
+  const float go = gout[0];
+  for (i64 v = (i64)blockIdx.x * 256 + threadIdx.x; v < total; v += (i64)gridDim.x * 256) {
+    const i64 n = v / S, s = v - n * S;
+    const float t = target[v];
+    const float p0 = probs[(n * 2 + 0) * S + s], p1 = probs[(n * 2 + 1) * S + s];
+    float d = 0.f;
+    if (p1 > p0) {
+      const float eps = 1e-6f;
+      const float I = sums[2 * n + 0], den = sums[2 * n + 1] + eps;
+      const float num = 2.0f * I + eps;
+      d = -(2.0f * t * den - num * 2.0f * p1) / (den * den) * (go / (float)N);
+    }
+    dprobs[(n * 2 + 0) * S + s] = 0.f;
+    dprobs[(n * 2 + 1) * S + s] = d;
+  }
+}
+
+// workspace part: [N][seg3d_dice_blocks(S)][3]; sums: [N][2] (kept for backward); one: device float holding 1.0f; loss: 1 float
+extern "C" int seg3d_binary_dice_fwd(const float* probs, const float* target, const float* one, float* part, float* sums,
+                                     float* loss, int N, long long S, void* stream) {
+  SEG3D_REQUIRE(probs && target && one && part && sums && loss && N > 0 && S > 0, "seg3d_binary_dice_fwd: bad arguments");
+  const int nblk = (int)seg3d_dice_blocks(S);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bdice_partial_kernel, dim3(nblk, N), dim3(256), 0, s, probs, target, part, (i64)S, nblk);
+  SEG3D_LAUNCH_CHECK("seg3d_binary_dice_fwd(partial)");
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, s, part, one, sums, loss, N, 1, nblk);
+  SEG3D_LAUNCH_CHECK("seg3d_binary_dice_fwd(finalize)");
+  return SEG3D_OK;
+}
+
+extern "C" int seg3d_binary_dice_bwd(const float* probs, const float* target, const float* sums, const float* gout,
+                                     float* dprobs, int N, long long S, void* stream) {
+  SEG3D_REQUIRE(probs && target && sums && gout && dprobs && N > 0 && S > 0, "seg3d_binary_dice_bwd: bad arguments");
+  hipLaunchKernelGGL(bdice_bwd_kernel, dim3(seg3d_ew_grid((i64)N * S, 256)), dim3(256), 0, (hipStream_t)stream, probs, target,
+                     sums, gout, dprobs, N, (i64)S);
+  SEG3D_LAUNCH_CHECK("seg3d_binary_dice_bwd");
+  return SEG3D_OK;
+}
+
 // ---- Focal ----------------------------------------------------------------------------------------------------------
 // probs element (n, c, s) lives at n*sn + c*sc + s*ss (planar NCDHW: sn = C*S, sc = S, ss = 1;
 // [sample, class] matrices: sn = 0, sc = 1, ss = C)

@@ -191,16 +191,21 @@ extern "C" int seg3d_patch_scatter_accumulate(const float* probs, const int* sta
   return SEG3D_OK;
 }
 
-// acc[c][v] *= 1/count[v] (in place);  mask[v] = argmax_c (first maximum), int8
+// acc[c][v] *= 1/count[v] (in place);  mask[v] = argmax_c (first maximum), int8.
+// A voxel no patch covered (count 0: bounding-box runs of the coarse -> fine cascade) gets probabilities 0 and class 0: the
+// reference divides SimpleITK images (core/seg_infer.py:325-327), and ITK's Div functor yields NumericTraits::max() -- not
+// inf -- for a zero denominator, so its product with the zero accumulator is 0, never NaN.
 __global__ __launch_bounds__(256) void finalize_argmax_kernel(float* __restrict__ acc, const float* __restrict__ count,
-                                                                signed char* __restrict__ mask, int C, i64 vol) {
+                                                                signed char* __restrict__ mask, int C, i64 vol,
+                                                                i64 cstride) {
   for (i64 v = (i64)blockIdx.x * 256 + threadIdx.x; v < vol; v += (i64)gridDim.x * 256) {
-    const float r = 1.0f / count[v];
+    const float cnt = count[v];
+    const float r = cnt > 0.f ? 1.0f / cnt : 0.f;
     int best = 0;
     float bv = 0.f;
     for (int c = 0; c < C; ++c) {
-      const float p = acc[(i64)c * vol + v] * r;
-      acc[(i64)c * vol + v] = p;
+      const float p = acc[(i64)c * cstride + v] * r;
+      acc[(i64)c * cstride + v] = p;
       if (c == 0 || p > bv) {
         best = c;
         bv = p;
@@ -210,11 +215,14 @@ __global__ __launch_bounds__(256) void finalize_argmax_kernel(float* __restrict_
   }
 }
 
+// class_stride: elements between the class planes of acc (the whole volume; `voxels` may be a z-slab of it -- a rank of
+// the sharded sliding window finalizes only the slab it owns); 0 = voxels
 extern "C" int seg3d_finalize_argmax(float* acc, const float* count, signed char* mask, int C, long long voxels,
-                                     void* stream) {
-  SEG3D_REQUIRE(acc && count && C > 0 && voxels > 0, "seg3d_finalize_argmax: bad arguments");
+                                     long long class_stride, void* stream) {
+  SEG3D_REQUIRE(acc && count && C > 0 && voxels > 0 && (class_stride == 0 || class_stride >= voxels),
+                "seg3d_finalize_argmax: bad arguments");
   hipLaunchKernelGGL(finalize_argmax_kernel, dim3(seg3d_ew_grid(voxels, 256)), dim3(256), 0, (hipStream_t)stream, acc, count,
-                     mask, C, (i64)voxels);
+                     mask, C, (i64)voxels, (i64)(class_stride ? class_stride : voxels));
   SEG3D_LAUNCH_CHECK("seg3d_finalize_argmax");
   return SEG3D_OK;
 }

@@ -104,6 +104,8 @@ _SIGNATURES = {
     'seg3d_dice_blocks': (_c_ll, [_c_ll]),
     'seg3d_dice_fwd': (_c_int, [_c_p] * 6 + [_c_int, _c_int, _c_ll, _c_p]),
     'seg3d_dice_bwd': (_c_int, [_c_p] * 6 + [_c_int, _c_int, _c_ll, _c_p]),
+    'seg3d_binary_dice_fwd': (_c_int, [_c_p] * 6 + [_c_int, _c_ll, _c_p]),
+    'seg3d_binary_dice_bwd': (_c_int, [_c_p] * 5 + [_c_int, _c_ll, _c_p]),
     'seg3d_focal_blocks': (_c_ll, [_c_ll]),
     'seg3d_focal_fwd': (_c_int, [_c_p] * 5 + [_c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_f, _c_int, _c_p]),
     'seg3d_focal_bwd': (_c_int, [_c_p] * 5 + [_c_int, _c_int, _c_ll, _c_ll, _c_ll, _c_ll, _c_f, _c_int, _c_p]),
@@ -112,7 +114,7 @@ _SIGNATURES = {
     'seg3d_patch_stats_blocks': (_c_ll, [_c_int] * 3),
     'seg3d_patch_gather_normalize': (_c_int, [_c_p] * 5 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_f, _c_p]),
     'seg3d_patch_scatter_accumulate': (_c_int, [_c_p] * 5 + [_c_int] * 7 + [_c_ll, _c_p]),
-    'seg3d_finalize_argmax': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_p]),
+    'seg3d_finalize_argmax': (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_ll, _c_ll, _c_p]),
 }
 
 _lib = None
@@ -169,6 +171,11 @@ def ptr(t):
 
 
 def require_device(*tensors):
+    """every operator entry checks its tensors here: on a ROCm device, and on the CURRENT one -- stream_ptr() hands the
+    kernels the current device's stream, so a tensor of another GPU would be launched on the wrong device's queue
+    (callers pin the device: load_single_model / TrainStep call torch.cuda.set_device, the sliding window runs under
+    torch.cuda.device(volume.device))"""
+    current = None
     for t in tensors:
         if t is None:
             continue
@@ -178,6 +185,12 @@ def require_device(*tensors):
             raise Seg3dEngineError(
                 'segmentation3d HIP engine needs tensors on a ROCm device (got device={}); '
                 'there is no CPU path in this package'.format(t.device))
+        if current is None:
+            current = torch.cuda.current_device()
+        if t.device.index is not None and t.device.index != current:
+            raise Seg3dEngineError(
+                'tensor on {} but the current device is cuda:{} -- segmentation3d launches on the current device\'s stream; '
+                'select the device first (torch.cuda.set_device / `with torch.cuda.device(...)`)'.format(t.device, current))
         if t.dtype not in (torch.float32, torch.int32, torch.int8, torch.float64, torch.uint8, torch.int16, torch.int64,
                            torch.bfloat16):
             raise TypeError('unsupported dtype {}'.format(t.dtype))

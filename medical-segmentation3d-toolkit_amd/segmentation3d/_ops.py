@@ -1091,6 +1091,41 @@ class DiceLossFunction(torch.autograd.Function):
         return dp, None, None
 
 
+class BinaryDiceLossFunction(torch.autograd.Function):
+    """BinaryDiceLoss.forward called on its own (loss/binary_dice_loss.py:9-36): one fused reduction + one elementwise
+    backward; probs [N, 2, ...], float target with N * S elements"""
+
+    @staticmethod
+    def forward(ctx, probs, target):
+        E.require_device(probs, target)
+        p = probs.contiguous()
+        t = target.contiguous().float()
+        N = p.shape[0]
+        S = p[0, 0].numel()
+        if p.shape[1] != 2 or t.numel() != N * S:
+            raise ValueError('BinaryDiceLoss needs a [N, 2, ...] input and a target of N x spatial elements, got {} and {}'
+                             .format(tuple(probs.shape), tuple(target.shape)))
+        nblk = E.query('seg3d_dice_blocks', S)
+        part = _empty((N, nblk, 3), p)
+        sums = _empty((N, 2), p)
+        loss = _empty((1,), p)
+        one = torch.ones(1, dtype=torch.float32, device=p.device)
+        E.call('seg3d_binary_dice_fwd', E.ptr(p), E.ptr(t), E.ptr(one), E.ptr(part), E.ptr(sums), E.ptr(loss), N, S,
+               E.stream_ptr())
+        ctx.save_for_backward(p, t, sums)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, t, sums = ctx.saved_tensors
+        N = p.shape[0]
+        S = p[0, 0].numel()
+        g = gout.contiguous().reshape(1).float()
+        dp = torch.empty_like(p)
+        E.call('seg3d_binary_dice_bwd', E.ptr(p), E.ptr(t), E.ptr(sums), E.ptr(g), E.ptr(dp), N, S, E.stream_ptr())
+        return dp, None
+
+
 class FocalLossFunction(torch.autograd.Function):
     """FocalLoss.forward (loss/focal_loss.py:27-61); probs viewed as [N][C][S] through strides (sn, sc, ss)"""
 

@@ -144,18 +144,118 @@ class SlidingWindowBatcher(object):
             probs = torch.cat((probs, pad), 0)
         self.scatter_current(probs.contiguous())
 
-    def finalize(self):
-        """acc *= 1/count (in place) and arg-max -> (probs [C,Z,Y,X], mask int8 [Z,Y,X])"""
-        mask = torch.empty((self.Z, self.Y, self.X), dtype=torch.int8, device=self.volume.device)
-        E.call('seg3d_finalize_argmax', E.ptr(self.acc), E.ptr(self.count), E.ptr(mask), self.C,
-               self.Z * self.Y * self.X, E.stream_ptr())
+    def finalize(self, z_range=None):
+        """acc *= 1/count (in place) and arg-max -> (probs [C,Z,Y,X], mask int8 [Z,Y,X]).
+        z_range = (z0, z1): only that slab of planes (a rank of the sharded sliding window finalizes the slab it owns);
+        the mask is zero outside it"""
+        import ctypes
+        plane = self.Y * self.X
+        if z_range is None:
+            mask = torch.empty((self.Z, self.Y, self.X), dtype=torch.int8, device=self.volume.device)
+            z0, z1 = 0, self.Z
+        else:
+            mask = torch.zeros((self.Z, self.Y, self.X), dtype=torch.int8, device=self.volume.device)
+            z0, z1 = int(z_range[0]), int(z_range[1])
+            if not 0 <= z0 <= z1 <= self.Z:
+                raise ValueError('z range {} outside the volume'.format(z_range))
+        if z1 > z0:
+            E.call('seg3d_finalize_argmax', ctypes.c_void_p(self.acc.data_ptr() + 4 * z0 * plane),
+                   ctypes.c_void_p(self.count.data_ptr() + 4 * z0 * plane), ctypes.c_void_p(mask.data_ptr() + z0 * plane),
+                   self.C, (z1 - z0) * plane, self.Z * plane, E.stream_ptr())
         return self.acc, mask
 
 
 def shard_batches(batches, rank, world_size):
-    """patch batches of this rank: patches are independent, so the ordered batch list is dealt round-robin over the
-    ranks; each rank accumulates into its own acc / count and ONE sum all-reduce merges them (no other exchange)"""
+    """round-robin deal of patch batches (kept for callers that merge with a full all-reduce; the sliding window itself
+    uses SlabShardPlan below)"""
     return [b for i, b in enumerate(batches) if i % world_size == rank]
+
+
+class SlabShardPlan(object):
+    """Patch inference over several GPUs: patches are independent, so the patch list is cut into `world`
+    chunks that are CONTIGUOUS IN Z (sorted by z start, ties in list order; equal patch counts).  Rank r then only ever
+    touches the planes [touch_lo[r], touch_hi[r]) of its accumulators, and the volume is cut into disjoint OWNED slabs
+    [bounds[r], bounds[r + 1]) with bounds[r] = the smallest z start of rank r.  A lower rank's patches reach at most
+    box_z - stride_z planes into the slabs above it, so the merge moves only those halo planes (rank q -> owner r,
+    q < r) instead of all-reducing (C + 1) full volumes; every rank finalizes (divide + arg-max) its own slab.
+    Pure host index arithmetic: the same plan is computed by every rank."""
+
+    def __init__(self, starts, box, volume_zyx, world_size):
+        self.world = int(world_size)
+        self.Z = int(volume_zyx[0])
+        bz = int(box[2])
+        n = len(starts)
+        order = sorted(range(n), key=lambda k: (int(starts[k][2]), k))
+        cuts = [(n * r) // self.world for r in range(self.world + 1)]
+        self.patches = [sorted(order[cuts[r]:cuts[r + 1]]) for r in range(self.world)]   # list order within a rank
+        self.touch_lo, self.touch_hi, self.bounds = [], [], []
+        prev = 0
+        for r in range(self.world):
+            zs = [int(starts[k][2]) for k in self.patches[r]]
+            lo = min(zs) if zs else prev
+            hi = max(zs) + bz if zs else prev
+            self.touch_lo.append(lo)
+            self.touch_hi.append(hi)
+            self.bounds.append(0 if r == 0 else max(lo, prev))
+            prev = self.bounds[-1]
+        self.bounds.append(self.Z)
+
+    def owned(self, rank):
+        return self.bounds[rank], self.bounds[rank + 1]
+
+    def transfers(self):
+        """[(src rank, dst rank, z0, z1)]: planes of src's accumulators that belong to dst's slab, in a fixed global order"""
+        out = []
+        for r in range(self.world):
+            o0, o1 = self.owned(r)
+            for q in range(self.world):
+                if q == r or not self.patches[q]:
+                    continue
+                z0, z1 = max(o0, self.touch_lo[q]), min(o1, self.touch_hi[q])
+                if z1 > z0:
+                    out.append((q, r, z0, z1))
+        return out
+
+
+def merge_slabs(acc, count, plan, rank, group=None):
+    """exchange the halo planes of a SlabShardPlan: afterwards acc [C,Z,Y,X] / count [Z,Y,X] of rank r are complete
+    inside plan.owned(r) (point-to-point sends over RCCL / xGMI; nothing is exchanged for planes only one rank touched).
+    The owner adds the incoming partial sums in ascending source-rank order (fixed => reproducible)."""
+    import torch.distributed as dist
+    C = acc.shape[0]
+    ops, recvs, keep = [], [], []
+    for q, r, z0, z1 in plan.transfers():
+        if rank == q:
+            buf = torch.cat((acc[:, z0:z1], count[z0:z1].unsqueeze(0)), 0).contiguous()
+            keep.append(buf)
+            peer = r if group is None else dist.get_global_rank(group, r)
+            ops.append(dist.P2POp(dist.isend, buf, peer, group))
+        elif rank == r:
+            buf = torch.empty((C + 1, z1 - z0) + tuple(acc.shape[2:]), dtype=acc.dtype, device=acc.device)
+            peer = q if group is None else dist.get_global_rank(group, q)
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group))
+            recvs.append((z0, z1, buf))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for z0, z1, buf in recvs:
+        acc[:, z0:z1] += buf[:C]
+        count[z0:z1] += buf[C]
+
+
+def gather_slabs(probs, mask, plan, group=None, with_probs=True):
+    """replicate the finalized slabs on every rank: each owner broadcasts its slab of every class map (contiguous planes,
+    no staging) and of the mask -- the output's own size, once"""
+    import torch.distributed as dist
+    for r in range(plan.world):
+        z0, z1 = plan.owned(r)
+        if z1 <= z0:
+            continue
+        src = r if group is None else dist.get_global_rank(group, r)
+        dist.broadcast(mask[z0:z1], src=src, group=group)
+        if with_probs:
+            for c in range(probs.shape[0]):
+                dist.broadcast(probs[c, z0:z1], src=src, group=group)
 
 
 def _forward_two_streams(net, batch, side):
@@ -177,19 +277,36 @@ def _forward_two_streams(net, batch, side):
 
 
 def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, batch_size=8, use_graph=True,
-                             process_group=None, shard=False, two_streams=True):
+                             process_group=None, shard=False, two_streams=True, gather='all'):
     """run `net` over all patches of a device-resident volume; returns (probs [C,Z,Y,X], mask int8 [Z,Y,X], batcher).
-    With shard=True under an initialised torch.distributed group every rank processes its share of the batches and
-    the accumulators are summed with one all-reduce before the final divide + arg-max (float summation order then
-    differs from the sequential reference loop by rounding only)."""
+    With shard=True under an initialised torch.distributed group the patch list is cut into z-contiguous chunks, one per
+    rank (SlabShardPlan); after the patch loop only the halo planes are exchanged (merge_slabs), every rank divides and
+    arg-maxes the slab it owns, and the slabs are replicated (gather='all': probabilities and mask, 'mask': mask only,
+    'none': each rank keeps just its slab; batcher.shard_plan tells which).  Float summation order inside a halo then
+    differs from the sequential reference loop by rounding only."""
+    with torch.cuda.device(volume.device):
+        return _sliding_window_inference(net, volume, starts, box, num_classes, normalizer, batch_size, use_graph,
+                                         process_group, shard, two_streams, gather)
+
+
+def _sliding_window_inference(net, volume, starts, box, num_classes, normalizer, batch_size, use_graph, process_group,
+                              shard, two_streams, gather):
+    if gather not in ('all', 'mask', 'none'):
+        raise ValueError("gather must be 'all', 'mask' or 'none'")
     batcher = SlidingWindowBatcher(volume, starts, box, num_classes, normalizer, max_batch=batch_size)
     P = batcher.max_batch
-    batches = [list(range(i, min(i + P, len(starts)))) for i in range(0, len(starts), P)]
     sharded = shard and torch.distributed.is_available() and torch.distributed.is_initialized() and \
         torch.distributed.get_world_size(process_group) > 1
+    plan, rank = None, 0
     if sharded:
-        batches = shard_batches(batches, torch.distributed.get_rank(process_group),
-                                torch.distributed.get_world_size(process_group))
+        rank = torch.distributed.get_rank(process_group)
+        plan = SlabShardPlan(batcher.starts, batcher.box, (batcher.Z, batcher.Y, batcher.X),
+                             torch.distributed.get_world_size(process_group))
+        mine = plan.patches[rank]
+    else:
+        mine = list(range(len(starts)))
+    batcher.shard_plan = plan
+    batches = [mine[i:i + P] for i in range(0, len(mine), P)]
     if batches:
         batcher.plan(batches)
     graph, first = None, 0
@@ -225,9 +342,12 @@ def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, 
                 else:
                     batcher.scatter_current(_forward_two_streams(net, batcher.gather_current(), side))
             if sharded:
-                torch.distributed.all_reduce(batcher.acc, group=process_group)
-                torch.distributed.all_reduce(batcher.count, group=process_group)
-            probs, mask = batcher.finalize()
+                merge_slabs(batcher.acc, batcher.count, plan, rank, process_group)
+                probs, mask = batcher.finalize(plan.owned(rank))
+                if gather != 'none':
+                    gather_slabs(probs, mask, plan, process_group, with_probs=(gather == 'all'))
+            else:
+                probs, mask = batcher.finalize()
     finally:
         if not cache_was_on:
             torch.cuda.synchronize()   # the images were allocated on the warm-up stream: nothing may still read them
@@ -251,6 +371,9 @@ def load_single_model(model_folder, gpu_id=0):
     if gpu_id is None or int(gpu_id) < 0:
         raise E.Seg3dEngineError('segmentation3d HIP engine needs gpu_id >= 0 (no CPU inference path)')
     device = torch.device('cuda:{}'.format(int(gpu_id)))
+    # the reference pins the GPU with CUDA_VISIBLE_DEVICES (seg_infer.py:104-105); here the chosen device becomes the
+    # CURRENT device: every kernel of this engine is launched on the current device's stream
+    torch.cuda.set_device(device)
     chk_dir = get_checkpoint_folder(os.path.join(model_folder, 'checkpoints'), -1)
     state = torch.load(os.path.join(chk_dir, 'params.pth'), map_location='cpu', weights_only=True)
     net_module = importlib.import_module('segmentation3d.network.' + state['net'])
@@ -324,8 +447,13 @@ def segmentation_volume(model, cfg, image, bbox_start_voxel, bbox_end_voxel, use
     `use_gpu` is kept for signature compatibility (the reference shrinks spacing / partitions on the CPU path only).
     Returns (mean_probs: list of Image3d, mask: Image3d int8).
     """
-    from segmentation3d.utils import image_tools
     assert isinstance(image, Image3d)
+    with torch.cuda.device(model['device']):
+        return _segmentation_volume(model, cfg, image, bbox_start_voxel, bbox_end_voxel, batch_size)
+
+
+def _segmentation_volume(model, cfg, image, bbox_start_voxel, bbox_end_voxel, batch_size):
+    from segmentation3d.utils import image_tools
     dev = model['device']
     ms = int(model['max_stride'])
     num_classes = int(model['out_channels'])
@@ -356,8 +484,8 @@ def segmentation_volume(model, cfg, image, bbox_start_voxel, bbox_end_voxel, use
     norm = model['crop_normalizer_dicts'][0] if model['crop_normalizer_dicts'] else None
     probs, _, batcher = sliding_window_inference(model['net'], vol, starts, box, num_classes, norm,
                                                  batch_size=min(batch_size, max(1, len(starts))))
-    # (voxels no patch covered -- bounding-box runs -- have count 0: as in the reference their probabilities are 0 * inf =
-    # NaN and the arg-max there is class 0)
+    # (voxels no patch covered -- bounding-box runs -- have count 0: their probabilities are 0 and the arg-max there is
+    # class 0, as with ITK's division in the reference, see finalize_argmax_kernel)
     # back to the image grid (identity when the image already is at the model spacing and a stride multiple)
     same_grid = (Xp, Yp, Zp) == (X, Y, Z) and all(abs(a - b) <= 1e-9 * max(abs(a), abs(b), 1.0)
                                                  for a, b in zip(image.GetSpacing(), spacing))
@@ -376,28 +504,87 @@ def segmentation_volume(model, cfg, image, bbox_start_voxel, bbox_end_voxel, use
     return mean_probs, Image3d(mask.cpu().numpy(), *img_frame)
 
 
+_IMAGE_SUFFIXES = ('.mhd', '.nii', '.hdr', '.nii.gz', '.mha', '.image3d')     # core/seg_infer.py:80, 375-376
+_READABLE_SUFFIXES = ('.mha', '.mhd', '.nii', '.nii.gz')
+
+
+def read_test_txt(txt_file):
+    """single-modality list file: first line = number of cases, then `<case name> <image path>` per line
+    (reference: seg_infer.py:23-45)"""
+    from segmentation3d.utils.file_io import readlines
+    lines = readlines(txt_file)
+    case_num = int(lines[0])
+    if len(lines) - 1 != case_num:
+        raise ValueError('case num do not equal path num!')
+    names, paths = [], []
+    for line in lines[1:1 + case_num]:
+        parts = line.strip().split()
+        if len(parts) < 2:
+            raise ValueError('expected "<case name> <image path>", got: {}'.format(line))
+        if not os.path.isfile(parts[1]):
+            raise ValueError('image not exist: {}'.format(parts[1]))
+        names.append(parts[0])
+        paths.append(parts[1])
+    return names, paths
+
+
+def read_test_folder(folder_path):
+    """every image file of a folder, case name = file name up to the image suffix (reference: seg_infer.py:68-96; DICOM
+    series folders are out of scope here)"""
+    import glob
+    files = []
+    for suf in _IMAGE_SUFFIXES:
+        files += glob.glob(os.path.join(folder_path, '*' + suf))
+    names, paths = [], []
+    for path in sorted(set(files)):
+        name = os.path.basename(path)
+        for suf in _IMAGE_SUFFIXES:
+            idx = name.find(suf)
+            if idx != -1:
+                name = name[:idx]
+                break
+        names.append(name)
+        paths.append(path)
+    return names, paths
+
+
 def segmentation(input_path, model_folder, output_folder, seg_name, gpu_id, return_mask, save_mask, save_image,
                  save_prob):
-    """volumetric image segmentation engine for MetaImage files (reference: seg_infer.py:353-493): single-scale
-    ('coarse' / 'fine') or the coarse -> fine cascade ('DISABLE') through the coarse mask's bounding box."""
+    """volumetric image segmentation engine for image files (reference: seg_infer.py:353-493): single-scale
+    ('coarse' / 'fine') or the coarse -> fine cascade ('DISABLE') through the coarse mask's bounding box.
+    input_path: a list file (.txt), one image file, or a folder of image files; results go to
+    `<output_folder>/<case name>/` with the reference's file names (seg_name, org.mha, mean_prob_<c>.mha)."""
     from segmentation3d.utils.image_io import read_image, write_image
     begin = time.time()
     models = load_models(model_folder, gpu_id)
     load_model_time = time.time() - begin
-    if os.path.isfile(input_path) and input_path.endswith('.txt'):
-        with open(input_path) as f:
-            paths = [ln.strip() for ln in f.readlines()[1:] if ln.strip()]
-    elif os.path.isfile(input_path) and input_path.endswith(('.mha', '.mhd', '.nii', '.nii.gz')):
-        paths = [input_path]
+    if os.path.isfile(input_path):
+        if input_path.endswith('.txt'):
+            names, paths = read_test_txt(input_path)
+        elif input_path.endswith(_IMAGE_SUFFIXES):
+            names, paths = [os.path.basename(input_path)], [input_path]        # seg_infer.py:377-379: name = file name
+        else:
+            raise ValueError('Unsupported input path.')
+    elif os.path.isdir(input_path):
+        names, paths = read_test_folder(input_path)
+        if len(names) == 0:
+            raise ValueError('Empty test folder!')
     else:
-        raise ValueError('Unsupported input path.')
+        raise ValueError('The file {} does not exist.'.format(input_path))
+    for path in paths:
+        if not path.endswith(_READABLE_SUFFIXES):
+            raise ValueError('Unsupported image format (MetaImage and NIfTI are read here): {}'.format(path))
     scale = models['infer_cfg'].general.single_scale
     if scale not in ('coarse', 'fine', 'DISABLE'):
         raise ValueError('Unsupported scale type!')
     masks, total = [], 0.0
     for i, path in enumerate(paths):
         print('{}: {}'.format(i, path))
+        begin = time.time()
         image = read_image(path)
+        if image.array.dtype != np.float32:                                     # sitk.ReadImage(path, sitk.sitkFloat32)
+            image = image.like(image.array.astype(np.float32))
+        read_image_time = time.time() - begin
         begin = time.time()
         if scale == 'coarse':
             mean_probs, mask = segmentation_volume(models['coarse_model'], models['infer_cfg'].coarse, image, None, None, True)
@@ -418,10 +605,12 @@ def segmentation(input_path, model_folder, output_folder, seg_name, gpu_id, retu
             mean_probs, mask = segmentation_volume(models['fine_model'], models['infer_cfg'].fine, image, start_voxel,
                                                    end_voxel, True)
         torch.cuda.synchronize()
-        total += time.time() - begin
+        inference_time = time.time() - begin
+        total += inference_time
         if return_mask:
             masks.append(mask)
-        case = os.path.basename(path).split('.')[0]
+        begin = time.time()
+        case = names[i]
         if save_mask or save_image or save_prob:
             os.makedirs(os.path.join(output_folder, case), exist_ok=True)
         if save_mask:
@@ -431,5 +620,7 @@ def segmentation(input_path, model_folder, output_folder, seg_name, gpu_id, retu
         if save_prob:
             for c, p in enumerate(mean_probs):
                 write_image(p, os.path.join(output_folder, case, 'mean_prob_{}.mha'.format(c)))
-        print('load model time: {:.2f}, average inference time: {:.2f}'.format(load_model_time, total / (i + 1)))
+        save_time = time.time() - begin
+        print('total test time: {:.2f}, average inference time: {:.2f}'.format(
+            load_model_time + read_image_time + inference_time + save_time, total / (i + 1)))
     return masks

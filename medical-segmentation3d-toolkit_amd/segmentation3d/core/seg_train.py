@@ -40,7 +40,9 @@ class TrainStep(object):
 
     def __init__(self, net_name, in_channels, num_classes, loss_name='Dice', obj_weight=None, focal_gamma=2, lr=1e-4,
                  betas=(0.9, 0.999), device=None, seed=0, distributed=None, num_buckets=4, use_graph=False):
-        self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        if self.device.type == 'cuda' and self.device.index is not None:
+            torch.cuda.set_device(self.device)   # the engine launches on the current device's stream (_engine.stream_ptr)
         net_module = importlib.import_module('segmentation3d.network.' + net_name)      # core/seg_train.py:72
         torch.manual_seed(seed)
         self.net = net_module.SegmentationNet(in_channels, num_classes)
@@ -121,6 +123,14 @@ class TrainStep(object):
         return loss
 
 
+def epoch_of_batch(batch_idx, batchsize, num_samples, world_size=1):
+    """epoch index after `batch_idx` steps (core/seg_train.py:135: batch_idx * batchsize // len(dataset)).  Under data
+    parallelism every step consumes world_size * batchsize samples -- each rank draws its 1/world shard of a pass
+    (EpochConcateDistributedSampler) -- so the GLOBAL batch is what advances the epoch; with world_size = 1 this is the
+    reference's formula."""
+    return int(batch_idx) * int(batchsize) * int(world_size) // int(num_samples)
+
+
 def train(train_config_file, data_iter_factory=None):
     """training engine with the reference's config schema (config/train_config.py) and checkpoint layout.
 
@@ -135,7 +145,9 @@ def train(train_config_file, data_iter_factory=None):
     assert os.path.isfile(train_config_file), 'Config not found: {}'.format(train_config_file)
     cfg = load_config(train_config_file)
     model_folder = os.path.join(cfg.general.save_dir, cfg.general.model_scale)
-    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else 0
+    world_size = dist.get_world_size() if distributed else 1
     if rank == 0:
         if os.path.isdir(model_folder) and cfg.general.resume_epoch < 0:
             shutil.rmtree(model_folder)
@@ -174,14 +186,16 @@ def train(train_config_file, data_iter_factory=None):
     else:
         batches = data_iter_factory(cfg)
         num_samples = int(getattr(cfg.dataset, 'num_samples', cfg.train.batchsize))
+    steps_this_run = 0
     for batch in batches:
         crops, masks = batch[0], batch[1]
         begin_t = time.time()
         crops, masks = crops.to(step.device, non_blocking=True), masks.to(step.device, non_blocking=True)
         loss = step(crops, masks)
-        epoch_idx = batch_idx * cfg.train.batchsize // num_samples
+        epoch_idx = epoch_of_batch(batch_idx, cfg.train.batchsize, num_samples, world_size)
         batch_idx += 1
-        if batch_idx == 3 and bool(getattr(cfg.train, 'gc_freeze', True)):
+        steps_this_run += 1
+        if steps_this_run == 3 and bool(getattr(cfg.train, 'gc_freeze', True)):   # (also after a resume: counted per run)
             # everything that lives for the whole run (modules, packed-weight cache, dataset) leaves the collector's young
             # generations: the collections that a step's short-lived autograd objects trigger were the largest single
             # host cost of an eager step (bf16 mode: 10.6 -> 6.5 ms per step)

@@ -99,3 +99,32 @@ def sampling_cases():
         ('smaller_than_crop', (60, 200, 40), (1.0, 1.0, 1.0), (5.0, 5.0, 5.0), eye, (96, 96, 96), (1.0, 1.0, 1.0), 13),
         ('flipped_x', (100, 100, 100), (0.8, 0.8, 0.8), (40.0, -40.0, 0.0), flip, (48, 48, 48), (1.0, 1.0, 1.0), 14),
     ]
+
+
+def normalizer_cases():
+    """(name, roi float32 [z, y, x], 'fixed' | 'adaptive', params) shared by oracle/gen_golden.py and the tests"""
+    ct = normal(401, 'norm/ct', (12, 20, 28), std=350.0, mean=-200.0)          # CT-like intensities
+    mr = (uniform(402, 'norm/mr', (16, 16, 24)) ** 3 * 1800.0).astype(np.float32)  # skewed MR-like intensities
+    flat = np.full((8, 8, 8), 7.25, dtype=np.float32)                           # zero variance -> std floor 1e-6
+    return [
+        ('fixed_ct_clip', ct, 'fixed', {'mean': -150.0, 'stddev': 350.0, 'clip': True}),
+        ('fixed_ct_noclip', ct, 'fixed', {'mean': 40.0, 'stddev': 120.5, 'clip': False}),
+        ('fixed_mr_clip', mr, 'fixed', {'mean': 300.0, 'stddev': 250.0, 'clip': True}),
+        ('adaptive_ct_3', ct, 'adaptive', {'clip_sigma': 3}),
+        ('adaptive_mr_2', mr, 'adaptive', {'clip_sigma': 2}),
+        ('adaptive_mr_0p5', mr, 'adaptive', {'clip_sigma': 0.5}),
+        ('adaptive_flat', flat, 'adaptive', {'clip_sigma': 3}),
+    ]
+
+
+def accumulate_case():
+    """(volume shape [z, y, x], [(start xyz, end xyz), ...]): 12 x 10 x 8 boxes at stride 6 x 5 x 4 over a 24 x 20 x 16 volume
+    (overlap counts 1..8), in the reference's x-outer / z-inner order"""
+    vol = (16, 20, 24)
+    box, stride = (12, 10, 8), (6, 5, 4)
+    patches = []
+    for x in range(0, 24 - box[0] + 1, stride[0]):
+        for y in range(0, 20 - box[1] + 1, stride[1]):
+            for z in range(0, 16 - box[2] + 1, stride[2]):
+                patches.append(([x, y, z], [x + box[0], y + box[1], z + box[2]]))
+    return vol, patches

@@ -295,6 +295,163 @@ def gen_sampling():
         json.dump(out, f)
 
 
+class _DuckSitkImage(object):
+    """what the reference's helpers ask of a `sitk.Image`: a [z, y, x] array plus a frame.  `GetArrayFromImage` COPIES,
+    as SimpleITK does (add_image_region relies on writing the copy back through GetImageFromArray)"""
+
+    def __init__(self, array, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=(1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0)):
+        self.a = np.array(array)
+        self.sp, self.o, self.d = tuple(spacing), tuple(origin), tuple(direction)
+
+    def GetSize(self):
+        z, y, x = self.a.shape
+        return (x, y, z)
+
+    def GetSpacing(self):
+        return self.sp
+
+    def GetOrigin(self):
+        return self.o
+
+    def GetDirection(self):
+        return self.d
+
+    def SetSpacing(self, v):
+        self.sp = tuple(float(x) for x in v)
+
+    def SetOrigin(self, v):
+        self.o = tuple(float(x) for x in v)
+
+    def SetDirection(self, v):
+        self.d = tuple(float(x) for x in v)
+
+    def CopyInformation(self, other):
+        self.sp, self.o, self.d = other.sp, other.o, other.d
+
+    def GetPixelID(self):
+        return self.a.dtype
+
+
+class _DuckSitk(object):
+    Image = _DuckSitkImage
+    sitkFloat32, sitkInt8, sitkInt16 = np.dtype(np.float32), np.dtype(np.int8), np.dtype(np.int16)
+
+    @staticmethod
+    def GetArrayFromImage(image):
+        return np.array(image.a)
+
+    @staticmethod
+    def GetImageFromArray(array):
+        return _DuckSitkImage(np.array(array))
+
+    @staticmethod
+    def Cast(image, pixel_id):
+        out = _DuckSitkImage(image.a.astype(pixel_id), image.sp, image.o, image.d)
+        return out
+
+
+def _ref_defs(rel_path, names, ns):
+    """execute the named top-level functions / classes of one reference file in the namespace `ns` (in memory only)"""
+    tree = ast.parse(open(os.path.join(REF, 'segmentation3d', rel_path)).read())
+    nodes = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert len(nodes) == len(names), (rel_path, names)
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), rel_path, 'exec'), ns)
+
+
+def gen_normalizers():
+    """normalize_image / get_mean_std_from_image / add_image_region / add_image_value / convert_* of the reference's
+    utils/image_tools.py and the two normaliser classes of utils/normalizer.py, executed through `ast` on a duck-typed
+    sitk (their modules import SimpleITK).  Inputs come from detgen (see detgen.normalizer_cases), only outputs are
+    stored."""
+    ns = {'np': np, 'sitk': _DuckSitk, 'torch': torch,
+          'type_conversion_from_numpy_to_sitk': {np.int8: _DuckSitk.sitkInt8, np.int16: _DuckSitk.sitkInt16,
+                                                 np.float32: _DuckSitk.sitkFloat32}}
+    _ref_defs('utils/image_tools.py', ['get_image_frame', 'set_image_frame', 'normalize_image', 'get_mean_std_from_image',
+                                       'add_image_region', 'add_image_value', 'convert_image_to_tensor',
+                                       'convert_tensor_to_image'], ns)
+    _ref_defs('utils/normalizer.py', ['FixedNormalizer', 'AdaptiveNormalizer'], ns)
+    data = {}
+    for name, roi, kind, params in detgen.normalizer_cases():
+        img = _DuckSitkImage(roi, (0.5, 0.75, 1.25), (3.0, -2.0, 7.0))
+        if kind == 'fixed':
+            norm = ns['FixedNormalizer'](params['mean'], params['stddev'], params['clip'])
+        else:
+            norm = ns['AdaptiveNormalizer'](params['clip_sigma'])
+        out = norm(img)
+        assert isinstance(out, _DuckSitkImage) and out.a.dtype == roi.dtype
+        data['norm/' + name] = out.a
+        d = norm.to_dict()
+        data['normdict/' + name] = np.array(json.dumps({k: (bool(v) if isinstance(v, bool) else float(v)) for k, v in d.items()}))
+        m, s = ns['get_mean_std_from_image'](img)
+        data['meanstd/' + name] = np.array([m, s], dtype=np.float64)
+        print('normalizer', name, kind, float(out.a.min()), float(out.a.max()), float(m), float(s))
+    # accumulate: the reference's loop core/seg_infer.py:313-323 over a small partition (overlaps 1..8), per class
+    vol_shape, patches = detgen.accumulate_case()
+    C = 3
+    acc = [_DuckSitkImage(np.zeros(vol_shape, dtype=np.float32)) for _ in range(C)]
+    cnt = _DuckSitkImage(np.zeros(vol_shape, dtype=np.float32))
+    for k, (start, end) in enumerate(patches):
+        size = [end[d] - start[d] for d in range(3)]
+        for c in range(C):
+            patch = _DuckSitkImage(detgen.uniform(71, 'acc/p{}c{}'.format(k, c), (size[2], size[1], size[0])).astype(np.float32))
+            acc[c] = ns['add_image_region'](acc[c], list(start), list(end), patch)
+        cnt = ns['add_image_value'](cnt, list(start), list(end), 1.0)
+    data['acc/sum'] = np.stack([a.a for a in acc])
+    data['acc/count'] = cnt.a
+    print('accumulate', data['acc/sum'].shape, float(cnt.a.min()), float(cnt.a.max()))
+    # tensor <-> image conversion (layout contract: tensor dims = (C, z, y, x))
+    a0 = detgen.normal(72, 'conv/a0', (5, 6, 7))
+    a1 = detgen.normal(72, 'conv/a1', (5, 6, 7))
+    t1 = ns['convert_image_to_tensor'](_DuckSitkImage(a0))
+    t2 = ns['convert_image_to_tensor']([_DuckSitkImage(a0), _DuckSitkImage(a1)])
+    data['convert/single'] = t1.numpy()
+    data['convert/list'] = t2.numpy()
+    im3 = ns['convert_tensor_to_image'](torch.from_numpy(a0 * 10), np.int8)
+    im4 = ns['convert_tensor_to_image'](torch.from_numpy(np.stack([a0, a1])), None)
+    data['convert/to_image_int8'] = im3.a
+    data['convert/to_image_list'] = np.stack([im.a for im in im4])
+    np.savez_compressed(os.path.join(OUT, 'normalizers.npz'), **data)
+
+
+def gen_small_losses():
+    """BinaryDiceLoss on its own (loss/binary_dice_loss.py:9-36) and the CrossEntropyLoss plugin applied to soft-max
+    OUTPUT (the reference's double soft-max, loss/cross_entropy_loss.py:13-18), values + input gradients"""
+    from segmentation3d.loss.binary_dice_loss import BinaryDiceLoss
+    from segmentation3d.loss.cross_entropy_loss import CrossEntropyLoss
+    data = {}
+    for name, shape in (('b2', (2, 2, 6, 8, 10)), ('b3_ties', (3, 2, 4, 4, 8))):
+        logits = detgen.normal(81, 'bdice/' + name, shape, std=1.5)
+        e = np.exp(logits - logits.max(1, keepdims=True))
+        probs = (e / e.sum(1, keepdims=True)).astype(np.float32)
+        if 'ties' in name:
+            probs[:, :, 0] = 0.5          # exact ties: arg-max takes channel 0 -> pred 0
+            probs[1] = np.float32(0.25)   # a sample where nothing is foreground
+            probs[1, 0] = np.float32(0.75)
+        target = detgen.labels(82, 'bdice/t' + name, (shape[0], 1) + shape[2:], 2)
+        pt = torch.from_numpy(probs).clone().requires_grad_(True)
+        loss = BinaryDiceLoss()(pt * 1.0, torch.from_numpy(target))    # (the module writes into its max() result, not the input)
+        loss.backward()
+        data['bdice_{}/probs'.format(name)] = probs
+        data['bdice_{}/target'.format(name)] = target
+        data['bdice_{}/loss'.format(name)] = np.float32(loss.item())
+        data['bdice_{}/grad'.format(name)] = pt.grad.numpy()
+        print('binary dice', name, float(loss))
+    for C, shape in ((2, (2, 2, 4, 6, 8)), (5, (1, 5, 4, 4, 8))):
+        logits = detgen.normal(83, 'ce/logits{}'.format(C), shape, std=2.0)
+        e = np.exp(logits - logits.max(1, keepdims=True))
+        probs = (e / e.sum(1, keepdims=True)).astype(np.float32)
+        target = detgen.labels(84, 'ce/t{}'.format(C), (shape[0], 1) + shape[2:], C)
+        pt = torch.from_numpy(probs).clone().requires_grad_(True)
+        loss = CrossEntropyLoss()(pt, torch.from_numpy(target))
+        loss.backward()
+        data['ce{}/probs'.format(C)] = probs
+        data['ce{}/target'.format(C)] = target
+        data['ce{}/loss'.format(C)] = np.float32(loss.item())
+        data['ce{}/grad'.format(C)] = pt.grad.numpy()
+        print('cross entropy on probabilities', C, float(loss))
+    np.savez_compressed(os.path.join(OUT, 'small_losses.npz'), **data)
+
+
 def gen_shapes():
     from segmentation3d.network import vnet, vbnet
     out = {}
@@ -311,7 +468,8 @@ def gen_shapes():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['blocks', 'nets', 'losses', 'partitions', 'shapes', 'metrics', 'sampling']
+    which = sys.argv[1:] or ['blocks', 'nets', 'losses', 'partitions', 'shapes', 'metrics', 'sampling', 'normalizers',
+                              'small_losses']
     if 'blocks' in which:
         gen_blocks()
     if 'nets' in which:
@@ -326,3 +484,7 @@ if __name__ == '__main__':
         gen_metrics()
     if 'sampling' in which:
         gen_sampling()
+    if 'normalizers' in which:
+        gen_normalizers()
+    if 'small_losses' in which:
+        gen_small_losses()

@@ -7,11 +7,11 @@ Restated from (all relative to /root/reference/segmentation3d):
   utils/normalizer.py:6-81 + utils/image_tools.py:221-238,472-478 -> fixed_normalize / adaptive_normalize
   utils/image_tools.py:435-469  add_image_region / add_image_value -> accumulate_patch
   core/seg_infer.py:313-327,336-339  accumulate loop, 1/count, argmax -> sliding_window_inference
-These reference modules import SimpleITK (absent here), so they cannot be imported; the partition function is pure
-index arithmetic and was pinned by executing the reference's own function body (extracted with `ast`, see
-oracle/gen_golden.py) on duck-typed images -> tests/golden/partition_*.json.  Normalisers / accumulate are a few numpy
-lines restated from the text; they have no reference-generated fixture ("parity unpinned" for those three helpers,
-stated in DESIGN.md) but are exercised against hand-computed cases.
+These reference modules import SimpleITK (absent here), so they cannot be imported; their function bodies were executed
+in place instead (extracted with `ast`, see oracle/gen_golden.py) on duck-typed images: the partition function ->
+tests/golden/partitions.json, the normalisers (both classes + normalize_image + get_mean_std_from_image) and the
+accumulate helpers (add_image_region / add_image_value) -> tests/golden/normalizers.npz.  tests/test_oracle_golden.py
+checks this restatement against those fixtures bit for bit.
 
 Array convention: a volume with sitk size (X, Y, Z) is a numpy array [Z, Y, X] (image_tools.py:448,465).
 """
@@ -103,22 +103,33 @@ def accumulate_patch(acc, count, start, end, patch_probs):
 
 
 def finalize(acc, count):
-    """probs *= 1/count; mask = argmax over classes (first maximum), int8 -- seg_infer.py:325-327,336-339"""
+    """probs *= 1/count; mask = argmax over classes (first maximum), int8 -- seg_infer.py:325-327,336-339.
+    Voxels no patch covered (count 0; bounding-box runs of the coarse -> fine cascade): the reference computes
+    `1.0 / count` on SimpleITK images, i.e. ITK's Div functor, which returns NumericTraits::max() for a zero denominator
+    instead of inf, so the product with the zero accumulator is 0 (NOT NaN) and the arg-max there is class 0.
+    Restated as inv = 0 where count == 0 (same products; ITK is absent here, so this rule is unpinned)."""
     with np.errstate(divide='ignore', invalid='ignore'):
-        inv = (1.0 / count).astype(np.float32)
+        inv = np.where(count > 0, 1.0 / count, 0.0).astype(np.float32)
         probs = acc * inv[None]
-    mask = np.argmax(probs, axis=0).astype(np.int8)  # uncovered voxels (count 0 -> NaN) resolve to class 0
+    mask = np.argmax(probs, axis=0).astype(np.int8)
     return probs, mask
 
 
 def sliding_window_inference(volume, net_fn, num_classes, spacing, partition_size, partition_stride, max_stride,
-                             normalizer, double_forward=True):
+                             normalizer, double_forward=True, bbox=None, partition_type='SIZE'):
     """segmentation_volume's patch loop at model spacing (no resample): seg_infer.py:276-339.
     volume: float32 [Z, Y, X]; net_fn: array [1,1,bz,by,bx] -> array [1,C,bz,by,bx].
-    double_forward reproduces the reference's two identical forwards + mean (seg_infer.py:230-234)."""
+    double_forward reproduces the reference's two identical forwards + mean (seg_infer.py:230-234).
+    bbox: (start xyz, end xyz) on this grid restricting the partition (seg_infer.py:292-303), None = whole volume;
+    partition_type 'DISABLE' = one box covering the volume (seg_infer.py:277-279)."""
     Z, Y, X = volume.shape
-    starts, ends = partition_by_fixed_size((X, Y, Z), spacing, [0, 0, 0], [X, Y, Z], partition_size, partition_stride,
-                                           max_stride)
+    if partition_type == 'DISABLE':
+        starts, ends = [[0, 0, 0]], [[X, Y, Z]]
+    elif partition_type == 'SIZE':
+        s0, e0 = ([0, 0, 0], [X, Y, Z]) if bbox is None else (list(bbox[0]), list(bbox[1]))
+        starts, ends = partition_by_fixed_size((X, Y, Z), spacing, s0, e0, partition_size, partition_stride, max_stride)
+    else:
+        raise ValueError('Unsupported partition type!')                                    # seg_infer.py:311
     acc = np.zeros((num_classes, Z, Y, X), dtype=np.float32)
     count = np.zeros((Z, Y, X), dtype=np.float32)
     for s, e in zip(starts, ends):
@@ -233,17 +244,38 @@ def get_bounding_box(mask, selected_labels):
     return [int(xx.min()), int(yy.min()), int(zz.min())], [int(xx.max()) + 1, int(yy.max()) + 1, int(zz.max()) + 1]
 
 
+def physical_to_index(frame, point):
+    """sitk TransformPhysicalPointToIndex: nearest index (round half up per axis)"""
+    spacing, origin, direction = (np.asarray(v, dtype=np.float64) for v in frame)
+    c = np.diag(1.0 / spacing) @ np.linalg.inv(direction.reshape(3, 3)) @ (np.asarray(point, dtype=np.float64) - origin)
+    return [int(np.floor(v + 0.5)) for v in c]
+
+
+def index_to_physical(frame, index):
+    """sitk TransformContinuousIndexToPhysicalPoint"""
+    spacing, origin, direction = (np.asarray(v, dtype=np.float64) for v in frame)
+    return origin + direction.reshape(3, 3) @ (spacing * np.asarray(index, dtype=np.float64))
+
+
 def segmentation_volume(image, frame, net_fn, num_classes, model_spacing, partition_size, partition_stride, max_stride,
-                        normalizer, interpolation='LINEAR', pick_largest_cc=False, remove_small_cc=0):
+                        normalizer, interpolation='LINEAR', pick_largest_cc=False, remove_small_cc=0, bbox=None,
+                        partition_type='SIZE', double_forward=False):
     """the whole of core/seg_infer.py:249-350 on the host: resample to the model spacing -> patch loop -> resample the
     class probabilities back (padding 1.0 for class 0, 0.0 otherwise) -> arg-max -> component post-processing.
-    image [Z, Y, X], frame = (spacing, origin, direction) of the image; returns (probs [C, Z, Y, X], mask int8)"""
+    image [Z, Y, X], frame = (spacing, origin, direction) of the image; bbox = (start xyz, end xyz) in IMAGE voxels
+    (converted to the model grid like seg_infer.py:292-303); returns (probs [C, Z, Y, X], mask int8)"""
     Z, Y, X = image.shape
     iso_frame = (list(model_spacing), frame[1], frame[2])
     size = resampled_size((X, Y, Z), frame[0], model_spacing, max_stride)
     iso = resample_affine(image, index_affine(frame, iso_frame), size, interpolation == 'LINEAR', 0.0)
+    iso_bbox = None
+    if bbox is not None and bbox[0] is not None and bbox[1] is not None:
+        s0 = physical_to_index(iso_frame, index_to_physical(frame, [float(v) for v in bbox[0]]))
+        e0 = physical_to_index(iso_frame, index_to_physical(frame, [float(v) for v in bbox[1]]))
+        iso_bbox = ([max(0, v) for v in s0], [min(v, lim) for v, lim in zip(e0, size)])
     probs, _, _ = sliding_window_inference(iso, net_fn, num_classes, model_spacing, partition_size, partition_stride,
-                                           max_stride, normalizer, double_forward=False)
+                                           max_stride, normalizer, double_forward=double_forward, bbox=iso_bbox,
+                                           partition_type=partition_type)
     back = index_affine(iso_frame, frame)
     out = np.stack([resample_affine(probs[c], back, (X, Y, Z), True, 1.0 if c == 0 else 0.0) for c in range(num_classes)])
     mask = np.argmax(out, axis=0).astype(np.int8)
@@ -253,6 +285,19 @@ def segmentation_volume(image, frame, net_fn, num_classes, model_spacing, partit
     if remove_small_cc > 0 and labels:
         mask = connected_component_filter(mask, labels, 'min_size', remove_small_cc)
     return out, mask
+
+
+def segmentation_cascade(image, frame, coarse, fine):
+    """core/seg_infer.py:428-444 (single_scale == 'DISABLE'): the coarse model on the whole image, the bounding box of its
+    mask (all labels), then the fine model restricted to that box.  coarse / fine: dicts of segmentation_volume keyword
+    arguments (net_fn, num_classes, model_spacing, partition_*, normalizer, ...).
+    Returns (fine probs, fine mask, (bbox start, bbox end))"""
+    _, cmask = segmentation_volume(image, frame, **coarse)
+    start, end = get_bounding_box(cmask, None)
+    if start is None:                 # (an empty coarse mask: the whole image; the reference would fail on None here)
+        start, end = [0, 0, 0], list(image.shape[::-1])
+    probs, mask = segmentation_volume(image, frame, bbox=(start, end), **fine)
+    return probs, mask, (start, end)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

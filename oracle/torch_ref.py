@@ -140,6 +140,24 @@ def focal_loss(probs, target, class_num, alpha=None, gamma=2, size_average=True)
     return batch.mean() if size_average else batch.sum()              # focal_loss.py:56-59
 
 
+def binary_dice_loss(probs, target):
+    """loss/binary_dice_loss.py:9-36 on a 2-channel input: (value, index) = max over channels, value *= index, i.e.
+    pred = p1 where p1 > p0 STRICTLY (a tie takes index 0) and 0 elsewhere"""
+    n = probs.shape[0]
+    pred = (probs[:, 1] * (probs[:, 1] > probs[:, 0]).to(probs.dtype)).reshape(n, -1)      # :13-14
+    t = target.float().reshape(n, -1)
+    inter = (pred * t).sum(1)
+    area = (pred * pred).sum(1) + (t * t).sum(1)
+    eps = torch.tensor(1e-6)
+    return (torch.tensor(1.0) - (torch.tensor(2.0) * inter + eps) / (area + eps)).mean()   # :33-34
+
+
+def cross_entropy_on_probs(probs, target):
+    """loss/cross_entropy_loss.py:13-18: nn.CrossEntropyLoss applied to the network's soft-max OUTPUT (a second
+    log-softmax over probabilities -- the reference's quirk), labels = squeeze(target, 1).long()"""
+    return F.cross_entropy(probs, target.squeeze(1).long())
+
+
 # ---- train step -------------------------------------------------------------------------------------------------------
 def train_step(sd_params, opt, x, target, name, loss_name, loss_kwargs):
     """core/seg_train.py:119-127: zero_grad -> forward -> loss -> backward -> Adam step; returns the loss value"""

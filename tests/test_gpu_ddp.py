@@ -83,3 +83,60 @@ def test_two_rank_train_step_matches_global_batch(hip_device, tmp_path, mode):
         cos = float((g_ddp.double() * g_ref.double()).sum() / (g_ddp.double().norm() * g_ref.double().norm()))
         assert abs(0.5 * (r0['loss'] + r1['loss']) - float(loss)) < 1e-3
         assert cos > 0.98, (cos, rel)
+
+
+def _infer_setup():
+    import numpy as np
+    from oracle import detgen
+    from segmentation3d.utils.image_tools import image_partition_by_fixed_size
+    Z, Y, X = 80, 48, 64
+    vol = (detgen.normal(85, 'ddp/vol', (Z, Y, X)) * 200 - 100).astype(np.float32)
+    starts, _ = image_partition_by_fixed_size(((X, Y, Z), (1.0, 1.0, 1.0)), [0, 0, 0], [X, Y, Z], [32] * 3, [16] * 3, 16)
+    return vol, starts
+
+
+def _infer_worker(rank, world, port, out):
+    from conftest import PKG  # noqa: F401
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from segmentation3d.core.seg_infer import sliding_window_inference
+    from segmentation3d.network import vnet
+    torch.manual_seed(5)
+    net = vnet.SegmentationNet(1, 3)
+    vnet.parameters_kaiming_init(net)
+    net = net.to('cuda:0').eval()
+    vol, starts = _infer_setup()
+    probs, mask, batcher = sliding_window_inference(net, torch.from_numpy(vol).cuda(), starts, (32, 32, 32), 3,
+                                                    {'type': 1, 'clip_sigma': 3}, batch_size=4, shard=True)
+    torch.cuda.synchronize()
+    plan = batcher.shard_plan
+    torch.save({'probs': probs.cpu(), 'mask': mask.cpu(), 'mine': len(plan.patches[rank]), 'owned': list(plan.owned(rank)),
+                'moved_planes': sum(b - a for _, _, a, b in plan.transfers())}, out.format(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_sliding_window_matches_single_rank(hip_device, tmp_path):
+    """sliding_window_inference(shard=True) on two ranks (z-contiguous patch chunks, hipGraph replay per rank, halo planes
+    exchanged point to point, every rank finalizes its own slab, slabs replicated) == the single-rank result"""
+    from segmentation3d.core.seg_infer import sliding_window_inference
+    from segmentation3d.network import vnet
+    world, port, out = 2, _free_port(), str(tmp_path / 'infer{}.pt')
+    mp.spawn(_infer_worker, args=(world, port, out), nprocs=world, join=True)
+    torch.manual_seed(5)
+    net = vnet.SegmentationNet(1, 3)
+    vnet.parameters_kaiming_init(net)
+    net = net.to(hip_device).eval()
+    vol, starts = _infer_setup()
+    probs, mask, _ = sliding_window_inference(net, torch.from_numpy(vol).to(hip_device), starts, (32, 32, 32), 3,
+                                              {'type': 1, 'clip_sigma': 3}, batch_size=4)
+    r = [torch.load(out.format(k), weights_only=True) for k in range(world)]
+    assert r[0]['mine'] + r[1]['mine'] == len(starts) and abs(r[0]['mine'] - r[1]['mine']) <= 1
+    assert r[0]['owned'][0] == 0 and r[0]['owned'][1] == r[1]['owned'][0] and r[1]['owned'][1] == 80
+    assert 0 < r[0]['moved_planes'] <= 32                   # only the halo of one box travels, not 80 planes x (C + 1)
+    for k in range(world):
+        assert float((r[k]['probs'] - probs.cpu()).abs().max()) < 1e-6
+        assert float((r[k]['mask'] != mask.cpu()).float().mean()) < 1e-4
+    assert torch.equal(r[0]['probs'], r[1]['probs']) and torch.equal(r[0]['mask'], r[1]['mask'])

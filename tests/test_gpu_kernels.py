@@ -67,6 +67,58 @@ def test_conv3d_k3_fwd_bwd(hip_device, case, force_direct):
     assert e['out'] < 1e-4 and e['dx'] < 1e-4 and e['dw'] < 2e-4 and e['db'] < 1e-4, e
 
 
+# the kernel instantiations the headline bench actually launches (BASELINE config 2: vnet(1,2), 4 x 96^3): variant codes of
+# seg3d_conv3d_k3_mfma_variant -- 321 = conv3d_k3_mfma2w8_kernel<2,1> (512-voxel tiles, 8 waves; the kernel bench.py's
+# `roofline` is quoted on), 131 = conv3d_k3_mfma2_kernel<3,1>, 311 = conv3d_k3_mfma2w8_kernel<1,1>
+BENCH_VARIANT_CASES = [
+    # (N, C, D, H, W), expected variant
+    ((4, 64, 24, 24, 24), 321),      # up_128 / down_64 level at batch 4
+    ((4, 128, 24, 24, 24), 321),     # up_128.rblock
+    ((1, 64, 48, 48, 48), 321),
+    ((1, 32, 96, 96, 96), 131),      # the 96^3 level of one patch
+    ((4, 64, 48, 48, 48), 131),      # up_64.rblock
+    ((4, 32, 48, 48, 48), 311),      # down_32.rblock
+    ((1, 128, 24, 24, 24), 311),
+]
+
+
+@pytest.mark.parametrize('shape,variant', BENCH_VARIANT_CASES)
+def test_conv3d_k3_bench_variants_full_size(hip_device, shape, variant):
+    """forward, data-gradient (fused addend included) and weight-gradient of the C -> C 3x3x3 convolution at the FULL sizes
+    of the headline configuration against stock torch CPU ops, asserting which kernel instantiation ran"""
+    from segmentation3d import _ops, _engine as E
+    N, C, D, H, W = shape
+    assert E.query('seg3d_conv3d_k3_mfma_variant', N, D, H, W, C, C) == variant
+    name = 'bench_variant_{}_{}'.format(variant, '_'.join(map(str, shape)))
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    x = _t(15, name + 'x', (N, C, D, H, W)).requires_grad_(True)
+    w = _t(16, name + 'w', (C, C, 3, 3, 3), std=(2.0 / (C * 27)) ** 0.5).requires_grad_(True)
+    b = _t(17, name + 'b', (C,), std=0.1)
+    g = _t(18, name + 'g', (N, C, D, H, W))
+    ad = _t(19, name + 'a', (N, C, D, H, W))
+    ref = F.conv3d(x, w, b, padding=1)
+    rdx, rdw = torch.autograd.grad(ref, (x, w), g)
+    xn = _ops.to_ndhwc(x.detach().to(hip_device))
+    gn = _ops.to_ndhwc(g.to(hip_device))
+    an = _ops.to_ndhwc(ad.to(hip_device))
+    wd, bd = w.detach().to(hip_device), b.to(hip_device)
+    y, part = _ops.conv_forward(xn, wd, bd, 'k3', want_stats=True)
+    dx = _ops.conv_dgrad(gn, wd, 'k3', addend=an)
+    dw = _ops.conv_wgrad(xn, gn, (C, C, 3, 3, 3), 'k3')
+    base = _t(20, name + 'base', (C, C, 3, 3, 3)).to(hip_device)
+    acc = base.clone()
+    _ops.conv_wgrad(xn, gn, (C, C, 3, 3, 3), 'k3', out=acc)          # gradient-sink form (accumulate flag)
+    torch.cuda.synchronize()
+    rr = ref.detach().double().reshape(N, -1)
+    st = part.double().sum(1).cpu()
+    e = dict(out=max_err(_ops.from_ndhwc(y), ref), dx=rel_err(_ops.from_ndhwc(dx), rdx + ad), dw=rel_err(dw, rdw),
+             dw_acc=rel_err(acc - base, rdw), stat_sum=float(((st[:, 0] - rr.sum(1)).abs() / rr.abs().sum(1)).max()),
+             stat_sq=rel_err(st[:, 1], (rr * rr).sum(1)), variant=float(variant))
+    report(name, **e)
+    assert e['out'] < 1e-4 and e['dx'] < 1e-4 and e['dw'] < 2e-4 and e['dw_acc'] < 2e-4, e
+    assert e['stat_sum'] < 1e-5 and e['stat_sq'] < 1e-5, e
+
+
 def test_conv_k3_mfma_addend_and_accumulate_flags(hip_device):
     """C-ABI flags of the second-generation kernels: `addend` of seg3d_conv3d_k3_mfma_fwd (y = conv + bias + addend, the
     fused residual-path gradient) and `accumulate` of seg3d_conv3d_k3_mfma_wgrad (dw += ..., gradient sinks), checked
@@ -677,6 +729,76 @@ def test_losses_golden_ties(hip_device):
             loss.backward()
             assert abs(float(loss) - float(gold['focal_' + gname])) < 1e-6, (name, gname)
             assert rel_err(p.grad, gold['focal_{}_grad'.format(gname)]) < 1e-5
+
+
+def test_small_losses_match_reference_fixtures(hip_device):
+    """BinaryDiceLoss on its own (HIP kernels seg3d_binary_dice_*) and the CrossEntropyLoss plugin (stock torch op on the
+    device, double soft-max quirk kept) against values + gradients produced by the reference's own modules"""
+    from conftest import golden_npz
+    from segmentation3d.loss.binary_dice_loss import BinaryDiceLoss
+    from segmentation3d.loss.cross_entropy_loss import CrossEntropyLoss
+    gold = golden_npz('small_losses')
+    for name in ('b2', 'b3_ties'):
+        p = torch.from_numpy(gold['bdice_{}/probs'.format(name)]).to(hip_device).requires_grad_(True)
+        t = torch.from_numpy(gold['bdice_{}/target'.format(name)]).to(hip_device)
+        loss = BinaryDiceLoss()(p, t)
+        loss.backward()
+        e = dict(loss=abs(float(loss) - float(gold['bdice_{}/loss'.format(name)])),
+                 grad=max_err(p.grad, gold['bdice_{}/grad'.format(name)]))
+        report('binary_dice_' + name, **e)
+        assert e['loss'] < 1e-6 and e['grad'] < 1e-7, e
+    with pytest.raises(ValueError):
+        BinaryDiceLoss()(torch.zeros(1, 3, 4, 4, 4, device=hip_device), torch.zeros(1, 1, 4, 4, 4, device=hip_device))
+    for C in (2, 5):
+        p = torch.from_numpy(gold['ce{}/probs'.format(C)]).to(hip_device).requires_grad_(True)
+        loss = CrossEntropyLoss()(p, torch.from_numpy(gold['ce{}/target'.format(C)]).to(hip_device))
+        loss.backward()
+        e = dict(loss=abs(float(loss) - float(gold['ce{}/loss'.format(C)])), grad=max_err(p.grad, gold['ce{}/grad'.format(C)]))
+        report('cross_entropy_on_probs_{}'.format(C), **e)
+        assert e['loss'] < 1e-5 and e['grad'] < 1e-6, e
+
+
+def test_patch_kernels_against_reference_fixtures(hip_device):
+    """seg3d_patch_gather_normalize against the reference's OWN FixedNormalizer / AdaptiveNormalizer outputs and
+    seg3d_patch_scatter_accumulate against its add_image_region / add_image_value loop (tests/golden/normalizers.npz,
+    produced by executing the reference's function bodies)"""
+    from conftest import golden_npz
+    from segmentation3d.core.seg_infer import SlidingWindowBatcher
+    gold = golden_npz('normalizers')
+    for name, roi, kind, params in detgen.normalizer_cases():
+        d = {'type': 0, 'mean': params['mean'], 'stddev': params['stddev'], 'clip': params['clip']} if kind == 'fixed' \
+            else {'type': 1, 'clip_sigma': params['clip_sigma']}
+        Z, Y, X = roi.shape
+        # the ROI sits inside a larger volume (other voxels must not leak into the adaptive statistics)
+        vol = np.full((Z + 3, Y + 5, X + 2), 1e4, dtype=np.float32)
+        vol[2:2 + Z, 1:1 + Y, 1:1 + X] = roi
+        b = SlidingWindowBatcher(torch.from_numpy(vol).to(hip_device), [[1, 1, 2]], (X, Y, Z), 2, d, max_batch=2)
+        out = b.gather([0])[0, 0]
+        want = gold['norm/' + name]
+        scale = max(1.0, float(np.abs(want).max()))
+        e = max_err(out, want)
+        report('gather_normalize_' + name, err=e)
+        assert e <= 4e-6 * scale, (name, e)
+        assert float(out.min()) >= float(want.min()) and float(out.max()) <= float(want.max())   # clip bounds exact
+    vol_shape, patches = detgen.accumulate_case()
+    box = tuple(patches[0][1][d] - patches[0][0][d] for d in range(3))
+    b = SlidingWindowBatcher(torch.zeros(vol_shape, device=hip_device), [p[0] for p in patches], box, 3, None, max_batch=4)
+    for i in range(0, len(patches), 4):
+        idx = list(range(i, min(i + 4, len(patches))))
+        probs = torch.stack([torch.stack([torch.from_numpy(detgen.uniform(71, 'acc/p{}c{}'.format(k, c), box[::-1]).astype(np.float32))
+                                          for c in range(3)]) for k in idx]).to(hip_device)
+        b.scatter(idx, probs)
+    assert np.array_equal(b.acc.cpu().numpy(), gold['acc/sum'])            # list order, no atomics: bit-identical
+    assert np.array_equal(b.count.cpu().numpy(), gold['acc/count'])
+    # finalize on a z-slab (what a rank of the sharded sliding window does) and the zero-count rule
+    ref_p, ref_m = numpy_ref.finalize(gold['acc/sum'].copy(), gold['acc/count'])
+    b.count[:2] = 0
+    b.acc[:, :2] = 0
+    probs_d, mask_d = b.finalize((0, 9))
+    got = probs_d.cpu().numpy()
+    assert np.isfinite(got).all() and (got[:, :2] == 0).all() and (mask_d[:2] == 0).all()
+    assert np.array_equal(got[:, 2:9], ref_p[:, 2:9]) and np.array_equal(mask_d[2:9].cpu().numpy(), ref_m[2:9])
+    assert np.array_equal(got[:, 9:], gold['acc/sum'][:, 9:]) and (mask_d[9:] == 0).all()    # outside the slab: untouched
 
 
 def test_fused_adam_matches_torch_adam(hip_device):

@@ -146,3 +146,31 @@ def test_image_io_roundtrips_nifti_and_compressed_mha(tmp_path):
     assert np.array_equal(c_img.array, lab) and c_img.GetSpacing() == (0.5, 0.5, 2.0) and c_img.GetOrigin() == (1.0, 2.0, 3.0)
     with pytest.raises(ValueError):
         read_image(str(tmp_path / 'x.dcm'))
+
+
+def test_tensor_on_another_device_is_refused(monkeypatch):
+    """the engine launches on the CURRENT device's stream: a tensor living on another GPU must raise at the operator
+    entry instead of being launched on the wrong queue (checked here with a stand-in tensor, no GPU needed)"""
+    import torch
+    from segmentation3d import _engine
+
+    class OnGpu1(torch.Tensor):
+        @property
+        def is_cuda(self):
+            return True
+
+        @property
+        def device(self):
+            return torch.device('cuda', 1)
+    t = torch.zeros(4).as_subclass(OnGpu1)
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: 0)
+    with pytest.raises(_engine.Seg3dEngineError, match='current device'):
+        _engine.require_device(t)
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: 1)
+    _engine.require_device(t)          # same device: accepted
+
+
+def test_epoch_accounting_counts_the_global_batch():
+    from segmentation3d.core.seg_train import epoch_of_batch
+    assert epoch_of_batch(10, 4, 40) == 1 and epoch_of_batch(9, 4, 40) == 0           # the reference's formula at world 1
+    assert epoch_of_batch(5, 4, 40, world_size=2) == 1 and epoch_of_batch(10, 4, 40, world_size=8) == 8

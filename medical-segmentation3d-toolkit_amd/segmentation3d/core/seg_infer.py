@@ -217,21 +217,32 @@ class SlabShardPlan(object):
         return out
 
 
+def _stage_on_host(t, group):
+    """gloo (the CPU rehearsal backend; also used when several test ranks share one GPU) moves host memory only: device
+    buffers are staged through the host there.  RCCL ("nccl") takes device pointers directly."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
 def merge_slabs(acc, count, plan, rank, group=None):
     """exchange the halo planes of a SlabShardPlan: afterwards acc [C,Z,Y,X] / count [Z,Y,X] of rank r are complete
     inside plan.owned(r) (point-to-point sends over RCCL / xGMI; nothing is exchanged for planes only one rank touched).
     The owner adds the incoming partial sums in ascending source-rank order (fixed => reproducible)."""
     import torch.distributed as dist
     C = acc.shape[0]
+    stage = _stage_on_host(acc, group)
     ops, recvs, keep = [], [], []
     for q, r, z0, z1 in plan.transfers():
         if rank == q:
             buf = torch.cat((acc[:, z0:z1], count[z0:z1].unsqueeze(0)), 0).contiguous()
+            if stage:
+                buf = buf.cpu()
             keep.append(buf)
             peer = r if group is None else dist.get_global_rank(group, r)
             ops.append(dist.P2POp(dist.isend, buf, peer, group))
         elif rank == r:
-            buf = torch.empty((C + 1, z1 - z0) + tuple(acc.shape[2:]), dtype=acc.dtype, device=acc.device)
+            buf = torch.empty((C + 1, z1 - z0) + tuple(acc.shape[2:]), dtype=acc.dtype,
+                              device='cpu' if stage else acc.device)
             peer = q if group is None else dist.get_global_rank(group, q)
             ops.append(dist.P2POp(dist.irecv, buf, peer, group))
             recvs.append((z0, z1, buf))
@@ -239,6 +250,7 @@ def merge_slabs(acc, count, plan, rank, group=None):
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     for z0, z1, buf in recvs:
+        buf = buf.to(acc.device)
         acc[:, z0:z1] += buf[:C]
         count[z0:z1] += buf[C]
 
@@ -247,15 +259,24 @@ def gather_slabs(probs, mask, plan, group=None, with_probs=True):
     """replicate the finalized slabs on every rank: each owner broadcasts its slab of every class map (contiguous planes,
     no staging) and of the mask -- the output's own size, once"""
     import torch.distributed as dist
+    stage = _stage_on_host(mask, group)
+
+    def bcast(view, src):
+        if not stage:
+            dist.broadcast(view, src=src, group=group)
+            return
+        host = view.cpu()
+        dist.broadcast(host, src=src, group=group)
+        view.copy_(host)
     for r in range(plan.world):
         z0, z1 = plan.owned(r)
         if z1 <= z0:
             continue
         src = r if group is None else dist.get_global_rank(group, r)
-        dist.broadcast(mask[z0:z1], src=src, group=group)
+        bcast(mask[z0:z1], src)
         if with_probs:
             for c in range(probs.shape[0]):
-                dist.broadcast(probs[c, z0:z1], src=src, group=group)
+                bcast(probs[c, z0:z1], src)
 
 
 def _forward_two_streams(net, batch, side):

@@ -1,6 +1,6 @@
 """per-kernel roofline table (markdown) from the committed round profiles:
   kernel statistics (rocprofv3 --kernel-trace --stats), the FETCH_SIZE / WRITE_SIZE PMC passes, the MFMA shape report
-usage: python tools/roofline_table.py <kernel_stats.csv> <pmc_fetch_write.json> <mfma_shapes.json> <steps> > table.md"""
+usage: python tools/roofline_table.py <kernel_stats.csv> <pmc_fetch_write.json> <mfma_shapes.json> [steps | auto] > table.md"""
 import csv
 import json
 import sys
@@ -9,7 +9,11 @@ HBM_PEAK_GBS, MFMA_PEAK_TF = 8000.0, 157.3
 stats = list(csv.DictReader(open(sys.argv[1])))
 pmc = json.load(open(sys.argv[2]))
 shapes = json.load(open(sys.argv[3]))['mfma_conv_launches']
-steps = int(sys.argv[4])
+steps_arg = sys.argv[4] if len(sys.argv) > 4 else 'auto'
+if steps_arg == 'auto':   # every step the traced process ran = calls of the once-per-step loss kernel
+    steps = next(int(r['Calls']) for r in stats if r['Name'].split('(')[0].strip().endswith(('dice_partial_kernel', 'focal_partial_kernel')))
+else:
+    steps = int(steps_arg)
 
 # algorithmic FLOPs per second of the 3x3x3 forward/dgrad instantiations from the live shape report
 variant_flops = {}

@@ -180,6 +180,17 @@ int seg3d_pack_weights_thin_out(const float* w, float* wq, int A, int B, int CO,
 long long seg3d_conv3d_k3_thin_out_stats_count(int D, int H, int W);
 int seg3d_conv3d_k3_thin_out_fwd(const float* x, const float* wq, const float* bias, float* y, float* stats_partial, int N,
                                  int D, int H, int W, int Cin, int Cout, int CO, void* stream);
+/* fp32 head conv on the fp32 matrix cores (csrc/conv_thin_f32.hip; Cin in {16, 32}, Cout <= 5): x taps in the reduction
+ * dimension of v_mfma_f32_16x16x4_f32, (kz, ky) taps in its output rows, the ninth tap on the VALU when 8 taps fill the
+ * rows exactly (2 and 4 classes); every voxel row is read once, no LDS staging of activations.  Exact fp32 arithmetic.
+ * replaces OutputBlock.conv1 = nn.Conv3d(in, out, 3, padding=1), network/module/vnet_outblock.py:13 */
+int seg3d_conv3d_k3_thin_out_f32mfma_supported(int Cin, int Cout);
+long long seg3d_thin_out_f32mfma_packed_floats(int Cin, int Cout);
+int seg3d_pack_weights_thin_out_f32mfma(const float* w, float* wpk, int A, int B, long long sa, long long sb, int flip,
+                                        void* stream);
+long long seg3d_conv3d_k3_thin_out_f32mfma_stats_count(int N, int D, int H, int W);
+int seg3d_conv3d_k3_thin_out_f32mfma_fwd(const float* x, const float* wpk, const float* bias, float* y,
+                                         float* stats_partial, int N, int D, int H, int W, int Cin, int Cout, void* stream);
 long long seg3d_k3_thin_wgrad_workspace_floats(int N, int D, int H, int W, int CT, int CF);
 int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* dw, float* workspace, int N, int D, int H, int W, int CT,
                         int CF, long long s_ct, long long s_cf, int flip, int accumulate, void* stream);

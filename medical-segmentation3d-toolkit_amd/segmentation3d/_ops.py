@@ -312,8 +312,18 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
         E.call('seg3d_conv3d_k3_thin_in_bf16out_fwd' if _is_bf16(y) else 'seg3d_conv3d_k3_thin_in_fwd', E.ptr(xn), E.ptr(wp),
                E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B, E.stream_ptr())
         return y, stats
+    if not FORCE_DIRECT and E.query('seg3d_conv3d_k3_thin_out_f32mfma_supported', A, B):
+        # thin output (head forward, Cin 16 / 32 -> <= 5 classes): fp32 matrix cores, (kz, ky) taps in the MFMA rows
+        wq = _empty((E.query('seg3d_thin_out_f32mfma_packed_floats', A, B),), w)
+        E.call('seg3d_pack_weights_thin_out_f32mfma', E.ptr(w), E.ptr(wq), A, B, sa, sb, flip, E.stream_ptr())
+        stats = None
+        if want_stats:
+            stats = _empty((N, E.query('seg3d_conv3d_k3_thin_out_f32mfma_stats_count', N, D, H, W_), 2), xn)
+        E.call('seg3d_conv3d_k3_thin_out_f32mfma_fwd', E.ptr(xn), E.ptr(wq), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_,
+               A, B, E.stream_ptr())
+        return y, stats
     if B <= 8 and A % 4 == 0 and not FORCE_DIRECT:
-        # thin output (head forward): LDS-tiled VALU kernel, CO outputs per voxel
+        # thin output, other shapes: LDS-tiled VALU kernel, CO outputs per voxel
         CO = 2 if B <= 2 else (4 if B <= 4 else 8)
         wq = _empty(((A + 7) // 8 * 27 * 8 * CO,), w)
         E.call('seg3d_pack_weights_thin_out', E.ptr(w), E.ptr(wq), A, B, CO, sa, sb, flip, E.stream_ptr())

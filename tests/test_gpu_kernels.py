@@ -37,6 +37,8 @@ CONV_K3_CASES = [
     (2, 32, 64, 6, 6, 6),     # weight-gradient tile 2x6x6; split-K forward
     (1, 24, 40, 4, 12, 20),   # partial 32-channel blocks on both sides
     (1, 16, 64, 8, 8, 16),    # two output-channel blocks
+    (1, 24, 6, 5, 9, 11),     # thin-out shapes outside the fp32-MFMA head kernel: LDS-tiled VALU kernel
+    (1, 32, 7, 4, 8, 16),
 ]
 
 
@@ -263,6 +265,48 @@ def test_conv3d_k3_thin_out_mfma(hip_device, shape, flip):
     assert torch.equal(y2 + bd, y) or float((y2 + bd - y).abs().max()) < 1e-6 * scale
     report('thin_out_mfma_{}x{}x{}x{}_{}_{}_flip{}'.format(N, D, H, W, Cin, Cout, flip), max_abs_err=float((got - ref).abs().max()),
            out_scale=scale)
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 2, 8, 8, 16), (2, 32, 2, 16, 16, 32), (1, 32, 3, 5, 9, 11), (2, 16, 1, 6, 10, 18),
+                                   (1, 16, 3, 9, 7, 33), (1, 32, 2, 3, 2, 1), (1, 32, 2, 40, 24, 48), (1, 32, 4, 7, 9, 17),
+                                   (2, 32, 5, 6, 10, 18), (1, 16, 4, 4, 8, 16), (1, 16, 5, 12, 8, 16), (3, 16, 2, 33, 8, 16)])
+@pytest.mark.parametrize('flip', [0, 1])
+def test_conv3d_k3_thin_out_f32mfma(hip_device, shape, flip):
+    """fp32 head conv on the fp32 matrix cores (x taps in K of v_mfma_f32_16x16x4_f32, (kz, ky) taps in the output rows,
+    ninth tap on the VALU for 2 / 4 classes) against the float64 convolution: 1..5 classes, Cin 16 / 32, ragged tiles in
+    every dimension, z marches longer than one tile, flipped taps (the adjoint form), no-bias / no-stats calls, and
+    per-tile statistics equal to those of its own output"""
+    from segmentation3d import _ops, _engine as E
+    N, Cin, Cout, D, H, W = shape
+    assert E.query('seg3d_conv3d_k3_thin_out_f32mfma_supported', Cin, Cout) == 1
+    assert E.query('seg3d_conv3d_k3_thin_out_f32mfma_supported', 24, 2) == 0 and E.query('seg3d_conv3d_k3_thin_out_f32mfma_supported', 32, 6) == 0
+    x = _t(61, 'fx', (N, Cin, D, H, W))
+    w = _t(62, 'fw', (Cout, Cin, 3, 3, 3), std=0.05)
+    b = _t(63, 'fb', (Cout,), std=0.5)
+    xn = _ops.to_ndhwc(x.to(hip_device))
+    wd = w.to(hip_device)
+    wp = torch.full((E.query('seg3d_thin_out_f32mfma_packed_floats', Cin, Cout),), float('nan'), device=hip_device)
+    E.call('seg3d_pack_weights_thin_out_f32mfma', E.ptr(wd), E.ptr(wp), Cin, Cout, 27, Cin * 27, flip, E.stream_ptr())
+    y = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
+    cnt = E.query('seg3d_conv3d_k3_thin_out_f32mfma_stats_count', N, D, H, W)
+    st = torch.full((N, cnt, 2), float('nan'), device=hip_device)
+    bd = b.to(hip_device)
+    E.call('seg3d_conv3d_k3_thin_out_f32mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bd), E.ptr(y), E.ptr(st), N, D, H, W, Cin, Cout,
+           E.stream_ptr())
+    wref = w.flip(2, 3, 4) if flip else w
+    ref = F.conv3d(x.double(), wref.double(), b.double(), padding=1)
+    got = _ops.from_ndhwc(y).double().cpu()
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert err < 2e-6 * scale, (err, scale)
+    s = st.double().sum(1).cpu()
+    rr = got.reshape(N, -1)
+    assert float(((s[:, 0] - rr.sum(1)).abs() / rr.abs().sum(1)).max()) < 1e-5 and rel_err(s[:, 1], (rr * rr).sum(1)) < 1e-5
+    y2 = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
+    E.call('seg3d_conv3d_k3_thin_out_f32mfma_fwd', E.ptr(xn), E.ptr(wp), None, E.ptr(y2), None, N, D, H, W, Cin, Cout,
+           E.stream_ptr())
+    assert torch.equal(y2 + bd, y) or float((y2 + bd - y).abs().max()) < 1e-6 * scale
+    report('thin_out_f32mfma_{}x{}x{}x{}_{}_{}_flip{}'.format(N, D, H, W, Cin, Cout, flip), max_abs_err=err, out_scale=scale)
 
 
 @pytest.mark.parametrize('shape', [(1, 32, 2, 4, 8, 8), (2, 32, 2, 12, 16, 24), (1, 32, 3, 5, 9, 11), (2, 16, 1, 6, 10, 18),

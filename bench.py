@@ -134,7 +134,7 @@ def variant_kernel_name(v):
     if v >= 300:   # two waves per SIMD, MA row blocks per wave
         return 'conv3d_k3_mfma2w8_kernel<{}, {}>'.format((v - 300) // 10, v % 10)
     if v >= 200:
-        # third template argument: bf16 output -- every data-gradient, and every forward launch unless SEG3D_BF16_Y=0
+        # third template argument: bf16 output -- every data-gradient, and every forward launch
         return 'conv3d_k3_mfma2_bf16_kernel<{}, {}, true>'.format((v - 200) // 10, v % 10)
     if v >= 100:
         return 'conv3d_k3_mfma2_kernel<{}, {}>'.format((v - 100) // 10, v % 10)

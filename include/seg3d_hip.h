@@ -196,7 +196,7 @@ int seg3d_k3_thin_wgrad(const float* thin, const float* fat, float* dw, float* w
                         int CF, long long s_ct, long long s_cf, int flip, int accumulate, void* stream);
 /* bf16 mode: the same with a bf16 `fat` operand (head weight gradient: fat = the bf16 input activation; stem weight
  * gradient: fat = the bf16 gradient of the conv output).  Runs on the bf16 matrix cores with `thin` split into a bf16
- * hi + lo pair (exact to 2^-17); SEG3D_THIN_WGRAD_BF16_MFMA=0 selects the fp32-MFMA kernel on the widened operand */
+ * hi + lo pair (exact to 2^-17) */
 int seg3d_k3_thin_wgrad_fatbf16(const float* thin, const void* fat_bf16, float* dw, float* workspace, int N, int D, int H,
                                 int W, int CT, int CF, long long s_ct, long long s_cf, int flip, int accumulate,
                                 void* stream);

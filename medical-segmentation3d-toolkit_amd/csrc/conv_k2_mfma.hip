@@ -925,12 +925,7 @@ static int k2_wgrad_launch(const void* P, const void* Q, int bf16, float* dw, fl
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "seg3d_k2_mfma_wgrad: more than 2^22 tiles");
   const int slabs = k2_wgrad_slabs(N, Dq, Hq, Wq, npairs);
   hipStream_t s = (hipStream_t)stream;
-  static int mf16 = -1;
-  if (mf16 < 0) {
-    const char* e = getenv("SEG3D_K2_WGRAD_BF16_MFMA");   // 0: widen the bf16 operands and use the fp32 MFMA kernel
-    mf16 = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (bf16 && mf16 && (CA & 7) == 0 && (CB & 7) == 0)
+  if (bf16 && (CA & 7) == 0 && (CB & 7) == 0)
     hipLaunchKernelGGL(k2_wgrad_bf16_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s,
                        reinterpret_cast<const seg3d_bf16*>(P), reinterpret_cast<const seg3d_bf16*>(Q), workspace, N, Dq, Hq,
                        Wq, CA, CB, ntz, nty, ntx, ntiles, BB32);

@@ -936,42 +936,6 @@ struct Seg3dFwdPlan {
   int nw;       // waves per workgroup of the version-2 kernel: 4, or 8 (two per SIMD, ma / 2 row blocks each)
 };
 
-static int seg3d_fwd_w8_enabled() {   // SEG3D_FWD_W8=0: always one wave per SIMD (measurement switch)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SEG3D_FWD_W8");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
-static int seg3d_fwd_v2_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SEG3D_FWD_V2");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
-static int seg3d_fwd_v2_ksplit_enabled() {  // SEG3D_FWD_V2_KSPLIT=0: whole-K items only (measurement switch)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SEG3D_FWD_V2_KSPLIT");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
-static int seg3d_force_ks() {   // SEG3D_FWD_V2_FORCE_KS=n: measurement switch, forces the K split where it is legal
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SEG3D_FWD_V2_FORCE_KS");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
 // time model (cycles): 256 workgroups run at once, every round costs one workgroup's duration =
 // K-chunks x 27 taps x 4 x MA x NB MFMAs of 64 cycles + DMA issue + a fixed prologue/epilogue
 // With ks > 1 an item covers only ceil(cib / ks) chunks and a finish pass (read ks slabs, write y) is added; that pays
@@ -1004,8 +968,7 @@ static bool seg3d_pick_tile_v2(int N, int D, int H, int W, int Cin, int Cout, Se
           const double wgs = (double)N * seg3d_cdiv(D, tz) * seg3d_cdiv(H, ty) * seg3d_cdiv(W, tx) * (cobs / nb);
           const double pieces = (((8 * nv + 255) >> 8) + 27 * nb) / 4.0;
           for (int ks : cand_ks) {
-            if (ks > 1 && (2 * ks > cib || !seg3d_fwd_v2_ksplit_enabled())) break;
-            if (seg3d_force_ks() > 0 && ks != seg3d_force_ks() && 2 * seg3d_force_ks() <= cib) continue;
+            if (ks > 1 && 2 * ks > cib) break;
             const int cpk = (cib + ks - 1) / ks;
             const int slabs = (cib + cpk - 1) / cpk;
             if (slabs != ks) continue;  // this ks leaves an empty slab; a smaller one covers the same split
@@ -1043,7 +1006,7 @@ static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout
   p.nb = 1;
   p.t = seg3d_pick_tile(N, D, H, W, (Cout + 31) / 32);
   p.ma = ((p.t.tz * p.t.ty * p.t.tx + 31) / 32 + 3) / 4;
-  if ((Cin & 7) == 0 && (Cout & 3) == 0 && seg3d_fwd_v2_enabled()) {
+  if ((Cin & 7) == 0 && (Cout & 3) == 0) {
     Seg3dTile t2;
     int ma2, nb2, ks2 = 1;
     if (seg3d_pick_tile_v2(N, D, H, W, Cin, Cout, &t2, &ma2, &nb2, &ks2) &&
@@ -1055,7 +1018,7 @@ static Seg3dFwdPlan seg3d_fwd_plan(int N, int D, int H, int W, int Cin, int Cout
       p.nb = nb2;
       p.ks = ks2;
       // (fp32: the 384-voxel tiles -- 12 row blocks over 8 waves -- measured 0..2 % slower with 8 waves, bf16 4 % faster)
-      if (seg3d_fwd_w8_enabled() && ks2 == 1 && nb2 == 1 && (ma2 == 2 || ma2 == 4)) p.nw = 8;
+      if (ks2 == 1 && nb2 == 1 && (ma2 == 2 || ma2 == 4)) p.nw = 8;
     }
   }
   return p;
@@ -1079,7 +1042,7 @@ static Seg3dFwdPlan seg3d_fwd_plan_bf16(int N, int D, int H, int W, int Cin, int
     p.ma = ma2;
     p.nb = nb2;
     p.ks = ks2;
-    if (seg3d_fwd_w8_enabled() && ks2 == 1 && nb2 == 1 && ma2 >= 2) p.nw = 8;
+    if (ks2 == 1 && nb2 == 1 && ma2 >= 2) p.nw = 8;
   }
   return p;
 }
@@ -1528,14 +1491,6 @@ __device__ __forceinline__ void conv3d_k3_wgrad_mfma_body(const void* __restrict
       for (int r = 0; r < 16; ++r) dst[tap * 1024 + mfma_row(r, lh) * 32 + li] = acc[j][r];
     }
   }
-}
-
-__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_kernel(const float* __restrict__ x,
-                                                                        const float* __restrict__ dy,
-                                                                        float* __restrict__ part, int N, int D, int H,
-                                                                        int W, int Cin, int Cout, int ntz, int nty,
-                                                                        int ntx, int ntiles, int COB32) {
-  conv3d_k3_wgrad_mfma_body<false>(x, dy, part, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, COB32);
 }
 
 __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_mfma_bf16_kernel(const void* __restrict__ x,
@@ -2121,48 +2076,32 @@ static int seg3d_wgrad_slabs(int N, int D, int H, int W, int npairs) {
 }
 
 struct Seg3dWgradPlan {
-  int version;  // 1: two workgroups per CU, register-staged; 2: one persistent workgroup per CU, LDS-DMA
+  int version;  // 2: one persistent workgroup per CU, LDS-DMA (the only fp32 form; kept for the variant codes)
   int nb;       // 32-channel blocks of dy per workgroup (version 2)
   int slabs;
   int tz, ty, tx;  // spatial tile (version 2; version 1 is 4 x 4 x 8)
 };
 
-static int seg3d_wgrad_v2_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SEG3D_WGRAD_V2");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
 static Seg3dWgradPlan seg3d_wgrad_plan(int N, int D, int H, int W, int Cin, int Cout) {
   const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
-  const int npairs = CIB32 * COB32;
   Seg3dWgradPlan p;
-  p.version = 1;
-  p.nb = 1;
+  p.version = 2;
+  p.nb = 1;   // NB = 2 (two dy blocks per workgroup) halves the x staging, but hipcc spills the unrolled loop's piece
+              // table and reloads it behind vmcnt(0) waits (negative results): not used until that is solved
   p.tz = SEG3D_WG_TZ, p.ty = SEG3D_WG_TY, p.tx = SEG3D_WG_TX;
-  p.slabs = seg3d_wgrad_slabs(N, D, H, W, npairs);
-  if (seg3d_wgrad_v2_enabled()) {
-    // a tile shape that divides the level: no half-empty tiles, every tile on the fast DMA path
-    if (D % 4 == 0 && H % 4 == 0 && W % 8 == 0) {
-    } else if (D % 4 == 0 && H % 4 == 0 && W % 4 == 0) {
-      p.tz = 4, p.ty = 4, p.tx = 4;
-    } else if (D % 2 == 0 && H % 6 == 0 && W % 6 == 0) {
-      p.tz = 2, p.ty = 6, p.tx = 6;
-    }
-    const int ntiles = N * seg3d_cdiv(D, p.tz) * seg3d_cdiv(H, p.ty) * seg3d_cdiv(W, p.tx);
-    if (ntiles >= SEG3D_FDIV_MAX) return p;   // tile decoding by float reciprocal is exact below 2^22 only
-    p.version = 2;
-    p.nb = 1;   // NB = 2 (two dy blocks per workgroup) halves the x staging, but hipcc spills the unrolled loop's piece
-                // table and reloads it behind vmcnt(0) waits (negative results): not used until that is solved
-    const int npg = CIB32 * (COB32 / p.nb);
-    int slabs = 256 / npg;  // one resident workgroup per CU over the whole grid
-    if (slabs > (ntiles + 1) / 2) slabs = (ntiles + 1) / 2;  // small levels: >= 2 tiles per workgroup
-    if (slabs < 1) slabs = 1;
-    p.slabs = slabs;
+  // a tile shape that divides the level: no half-empty tiles, every tile on the fast DMA path
+  if (D % 4 == 0 && H % 4 == 0 && W % 8 == 0) {
+  } else if (D % 4 == 0 && H % 4 == 0 && W % 4 == 0) {
+    p.tz = 4, p.ty = 4, p.tx = 4;
+  } else if (D % 2 == 0 && H % 6 == 0 && W % 6 == 0) {
+    p.tz = 2, p.ty = 6, p.tx = 6;
   }
+  const i64 ntiles = (i64)N * seg3d_cdiv(D, p.tz) * seg3d_cdiv(H, p.ty) * seg3d_cdiv(W, p.tx);
+  const int npg = CIB32 * (COB32 / p.nb);
+  i64 slabs = 256 / npg;  // one resident workgroup per CU over the whole grid
+  if (slabs > (ntiles + 1) / 2) slabs = (ntiles + 1) / 2;  // small levels: >= 2 tiles per workgroup
+  if (slabs < 1) slabs = 1;
+  p.slabs = (int)slabs;
   return p;
 }
 
@@ -2202,23 +2141,19 @@ extern "C" int seg3d_conv3d_k3_mfma_wgrad(const float* x, const float* dy, float
                 "seg3d_conv3d_k3_mfma_wgrad: Cin and Cout must be multiples of 4 (got %d, %d)", Cin, Cout);
   const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
   const int npairs = CIB32 * COB32;
-  const int ntz = seg3d_cdiv(D, SEG3D_WG_TZ), nty = seg3d_cdiv(H, SEG3D_WG_TY), ntx = seg3d_cdiv(W, SEG3D_WG_TX);
-  const int ntiles = N * ntz * nty * ntx;
   SEG3D_REQUIRE((i64)N * D * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31),
                 "seg3d_conv3d_k3_mfma_wgrad: tensor exceeds 2^31 elements");
   const Seg3dWgradPlan plan = seg3d_wgrad_plan(N, D, H, W, Cin, Cout);
+  // (tile decoding by float reciprocal is exact below 2^22 tiles only)
+  SEG3D_REQUIRE((i64)N * seg3d_cdiv(D, plan.tz) * seg3d_cdiv(H, plan.ty) * seg3d_cdiv(W, plan.tx) < SEG3D_FDIV_MAX,
+                "seg3d_conv3d_k3_mfma_wgrad: more than 2^22 tiles");
   const int slabs = plan.slabs;
   hipStream_t s = (hipStream_t)stream;
-  if (plan.version == 2) {
-    int rc;
-    if (plan.tx == 4) rc = launch_wgrad2<1, 4, 4, 4>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
-    else if (plan.tx == 6) rc = launch_wgrad2<1, 2, 6, 6>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
-    else rc = launch_wgrad2<1, 4, 4, 8>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
-    if (rc != SEG3D_OK) return rc;
-  } else {
-    hipLaunchKernelGGL(conv3d_k3_wgrad_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s, x, dy, workspace, N, D, H, W,
-                       Cin, Cout, ntz, nty, ntx, ntiles, COB32);
-  }
+  int rc;
+  if (plan.tx == 4) rc = launch_wgrad2<1, 4, 4, 4>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
+  else if (plan.tx == 6) rc = launch_wgrad2<1, 2, 6, 6>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
+  else rc = launch_wgrad2<1, 4, 4, 8>(x, dy, workspace, N, D, H, W, Cin, Cout, slabs, s);
+  if (rc != SEG3D_OK) return rc;
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_mfma_wgrad");
   const i64 total = (i64)npairs * 27 * 1024;  // padded (32 x 32 per pair) partial elements, 64 per workgroup
   hipLaunchKernelGGL(conv3d_k3_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dw, slabs,
@@ -2242,12 +2177,7 @@ static Seg3dWgrad16Plan seg3d_wgrad16_plan(int N, int D, int H, int W, int Cin, 
   p.version = 1;
   p.tx = 8;
   p.slabs = seg3d_wgrad_slabs(N, D, H, W, npairs);
-  static int v3 = -1;
-  if (v3 < 0) {
-    const char* e = getenv("SEG3D_WGRAD_BF16_MFMA");   // 0: always the register-staged kernel (measurement switch)
-    v3 = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (!v3 || (Cin & 7) || (Cout & 7)) return p;
+  if ((Cin & 7) || (Cout & 7)) return p;
   // tile 4x4x8 unless 4x4x4 wastes fewer voxels (levels that are multiples of 4 but not of 8, e.g. 12^3)
   const i64 vol8 = (i64)seg3d_cdiv(D, 4) * seg3d_cdiv(H, 4) * seg3d_cdiv(W, 8) * 128;
   const i64 vol4 = (i64)seg3d_cdiv(D, 4) * seg3d_cdiv(H, 4) * seg3d_cdiv(W, 4) * 64;

@@ -1391,15 +1391,6 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_bf16_mfma_kernel(const f
   }
 }
 
-static int seg3d_thin_wgrad_bf16_mfma_enabled() {   // SEG3D_THIN_WGRAD_BF16_MFMA=0: fp32-MFMA kernel on the widened operand
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SEG3D_THIN_WGRAD_BF16_MFMA");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
 // dw[ct*s_ct + cf*s_cf + (flip ? 26 - t : t)] = sum_slab part[slab][cfb][row = t*CT + ct][cf % 32]
 // 4 outputs x 64 slab groups per workgroup (the output is tiny: the reduction over <= 512 slabs is the work, and it sits
 // at the very end of backward where nothing overlaps it: 16 x 16 left each thread 32 dependent-latency loads), combined
@@ -1439,14 +1430,6 @@ __global__ __launch_bounds__(256, 2) void k3_thin_wgrad_kernel(const float* __re
   k3_thin_wgrad_body<CT, false>(thin, fat, part, N, D, H, W, CF, ntz, nty, ntx, ntiles);
 }
 
-template <int CT>
-__global__ __launch_bounds__(256, 2) void k3_thin_wgrad_fatbf16_kernel(const float* __restrict__ thin,
-                                                                         const void* __restrict__ fat,
-                                                                 float* __restrict__ part, int N, int D, int H, int W,
-                                                                 int CF, int ntz, int nty, int ntx, int ntiles) {
-  k3_thin_wgrad_body<CT, true>(thin, fat, part, N, D, H, W, CF, ntz, nty, ntx, ntiles);
-}
-
 static int thin_wgrad_slabs(int N, int D, int H, int W) {
   const int ntiles = N * seg3d_cdiv(D, TH_TZ) * seg3d_cdiv(H, TH_TY) * seg3d_cdiv(W, TH_TX);
   const int want = (ntiles + 7) / 8;  // >= 8 tiles per workgroup keeps the slab count (and the serial reduce) small
@@ -1462,12 +1445,9 @@ template <int CT>
 static void launch_thin_wgrad(const float* thin, const void* fat, int fat_bf16, float* part, int N, int D, int H, int W,
                               int CF, int slabs, hipStream_t s) {
   const int ntz = seg3d_cdiv(D, TH_TZ), nty = seg3d_cdiv(H, TH_TY), ntx = seg3d_cdiv(W, TH_TX);
-  if (fat_bf16 && seg3d_thin_wgrad_bf16_mfma_enabled())
+  if (fat_bf16)
     hipLaunchKernelGGL((k3_thin_wgrad_bf16_mfma_kernel<CT>), dim3(slabs, (CF + 31) / 32), dim3(256), 0, s, thin,
                        reinterpret_cast<const seg3d_bf16*>(fat), part, N, D, H, W, CF, ntz, nty, ntx, N * ntz * nty * ntx);
-  else if (fat_bf16)
-    hipLaunchKernelGGL((k3_thin_wgrad_fatbf16_kernel<CT>), dim3(slabs, (CF + 31) / 32), dim3(256), 0, s, thin, fat, part, N,
-                       D, H, W, CF, ntz, nty, ntx, N * ntz * nty * ntx);
   else
     hipLaunchKernelGGL((k3_thin_wgrad_kernel<CT>), dim3(slabs, (CF + 31) / 32), dim3(256), 0, s, thin,
                        reinterpret_cast<const float*>(fat), part, N, D, H, W, CF, ntz, nty, ntx, N * ntz * nty * ntx);

@@ -29,14 +29,8 @@ FORCE_DIRECT = False
 # The reference has no such switch (it computes in fp32 throughout); the default here is fp32 as well.
 _ACT_BF16 = [False]
 # bf16 mode, second switch: the raw conv output y (read by GroupNorm forward and backward, saved for backward) is bf16 as
-# well -- rounded by the conv epilogue AFTER the fp32 (sum, sumsq) statistics are taken.  SEG3D_BF16_Y=0 keeps y in fp32.
-BF16_CONV_OUTPUT = os.environ.get('SEG3D_BF16_Y', '1') != '0'
-# bf16 mode, stride-2 layers: bf16 weight images + bf16 MFMA (SEG3D_K2_BF16_MFMA=0: fp32 images, input widened while staging)
-K2_BF16_MFMA = os.environ.get('SEG3D_K2_BF16_MFMA', '1') != '0'
-# bf16 mode, head conv (Cin 16/32 -> <= 3): small GEMM per row block on the matrix cores (SEG3D_THIN_OUT_MFMA=0: VALU kernel)
-THIN_OUT_MFMA = os.environ.get('SEG3D_THIN_OUT_MFMA', '1') != '0'
-# bf16 mode, stem forward / head data-gradient (1-2 input channels, bf16 output): bf16 MFMA with hi + lo operands
-THIN_IN_MFMA16 = os.environ.get('SEG3D_THIN_IN_MFMA16', '1') != '0'
+# well -- rounded by the conv epilogue AFTER the fp32 (sum, sumsq) statistics are taken.  BF16_CONV_OUTPUT = False keeps y in fp32 (tests/test_gpu_bf16.py runs both).
+BF16_CONV_OUTPUT = True
 
 
 def set_activation_dtype(name):
@@ -269,7 +263,7 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
             stats = None
             if want_stats:
                 stats = _empty((N, E.query('seg3d_conv3d_k3_thin_out_stats_count', D, H, W_), 2), xn)
-            if THIN_OUT_MFMA and E.query('seg3d_conv3d_k3_thin_out_mfma_supported', A, B):
+            if E.query('seg3d_conv3d_k3_thin_out_mfma_supported', A, B):
                 wq = torch.empty(E.query('seg3d_thin_out_mfma_packed_elems', A), dtype=torch.bfloat16, device=w.device)
                 E.call('seg3d_pack_weights_thin_out_mfma', E.ptr(w), E.ptr(wq), A, B, sa, sb, flip, E.stream_ptr())
                 E.call('seg3d_conv3d_k3_thin_out_mfma_fwd', E.ptr(xn), E.ptr(wq), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D,
@@ -301,7 +295,7 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
         stats = None
         if want_stats:
             stats = _empty((N, E.query('seg3d_conv3d_k3_thin_stats_count', D, H, W_, (B + 31) // 32), 2), xn)
-        if _is_bf16(y) and THIN_IN_MFMA16 and E.query('seg3d_conv3d_k3_thin_in_mfma16_supported', A, B):
+        if _is_bf16(y) and E.query('seg3d_conv3d_k3_thin_in_mfma16_supported', A, B):
             wq = torch.empty(E.query('seg3d_packed_thin_in16_elems', A, B), dtype=torch.bfloat16, device=w.device)
             E.call('seg3d_pack_weights_thin_in16', E.ptr(w), E.ptr(wq), A, B, sa, sb, flip, E.stream_ptr())
             E.call('seg3d_conv3d_k3_thin_in_mfma16_fwd', E.ptr(xn), E.ptr(wq), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H,
@@ -341,7 +335,7 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
 def _k2_gather(xn, w, bias, y, A, B, sa, sb, want_stats):
     """y[v][b] = bias[b] + sum_{t,a} x[2v + t][a] W(a,b,t) on the matrix cores; y preallocated [N,Do,Ho,Wo,B]"""
     N, Do, Ho, Wo, _ = y.shape
-    w16 = _is_bf16(xn) and A % 16 == 0 and K2_BF16_MFMA    # bf16 weight image -> the kernel's bf16-MFMA mode
+    w16 = _is_bf16(xn) and A % 16 == 0    # bf16 weight image -> the kernel's bf16-MFMA mode
     wp = _pack_mfma(w, A, B, 8, sa, sb, bf16=w16)
     stats = None
     if want_stats:
@@ -358,7 +352,7 @@ def _k2_gather(xn, w, bias, y, A, B, sa, sb, want_stats):
 def _k2_scatter(xn, w, bias, y, A, B, sa, sb, want_stats):
     """y[2i + t][b] = bias[b] + sum_a x[i][a] W(a,b,t) on the matrix cores; y preallocated [N,2D,2H,2W,B]"""
     N, D, H, W_, _ = xn.shape
-    w16 = _is_bf16(xn) and A % 16 == 0 and K2_BF16_MFMA
+    w16 = _is_bf16(xn) and A % 16 == 0
     wp = _pack_mfma(w, A, B, 8, sa, sb, bf16=w16)
     stats = None
     if want_stats:
@@ -451,9 +445,7 @@ def _check_w(w, shape, kind):
         raise ValueError('conv weights must be contiguous')
 
 
-# stride-2 conv data-gradient: the skip connection's gradient is added in the kernel epilogue (SEG3D_K2_DGRAD_ADDEND=0:
-# separate elementwise add, as autograd would do)
-K2_DGRAD_ADDEND = os.environ.get('SEG3D_K2_DGRAD_ADDEND', '1') != '0'
+# stride-2 conv data-gradient: the skip connection's gradient is added in the kernel epilogue
 
 
 def _addend_row_stride(t, C):
@@ -481,7 +473,7 @@ def conv_dgrad(dyn, w, kind, addend=None, want_bf16=None):
         dx, _ = _conv_k3_generic(dyn, w, None, Cout, Cin, Cin * 27, 27, 1, False, addend=addend, out_bf16=want_bf16)
         return dx
     if addend is not None:
-        if kind == 'k2s2' and K2_DGRAD_ADDEND:
+        if kind == 'k2s2':
             Cout, Cin = w.shape[0], w.shape[1]
             dy16 = _is_bf16(dyn) and _use_mfma(Cout, Cin) and Cin % 4 == 0
             ld = _addend_row_stride(addend, Cin)
@@ -490,7 +482,7 @@ def conv_dgrad(dyn, w, kind, addend=None, want_bf16=None):
                 # the skip connection's gradient (a channel slice of the concatenated gradient) joins in the epilogue
                 if _is_bf16(dyn) and not dy16:
                     dyn = _to_f32(dyn)
-                w16 = dy16 and Cout % 16 == 0 and K2_BF16_MFMA
+                w16 = dy16 and Cout % 16 == 0
                 wp = _pack_mfma(w, Cout, Cin, 8, Cin * 8, 8, bf16=w16)
                 dx = _empty((N, 2 * D, 2 * H, 2 * W_, Cin), dyn, dyn.dtype)
                 E.call('seg3d_convT3d_k2s2_scatter_addend', E.ptr(dyn), (2 if w16 else 1) if dy16 else 0, E.ptr(wp),
@@ -652,10 +644,10 @@ def _row_stride(t, C):
     return ld
 
 
-# GroupNorm backward: both finalize stages in one launch (SEG3D_GN_FUSED_FINALIZE=0: two kernels).  The fused kernel takes
+# GroupNorm backward: both finalize stages in one launch (GN_FUSED_FINALIZE = False: two kernels; a test compares them).  The fused kernel takes
 # a ticket counter that is zero between calls; one per device, shared by all GroupNorm backward calls -- they are issued
 # on one stream (the weight-gradient side stream never runs GroupNorm), so two launches never hold tickets at once.
-GN_FUSED_FINALIZE = os.environ.get('SEG3D_GN_FUSED_FINALIZE', '1') != '0'
+GN_FUSED_FINALIZE = True
 _GN_TICKETS = {}
 
 
@@ -730,8 +722,7 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
 # HBM-bound GroupNorm / stride-2 / thin kernels of the main stream instead of running in series with them.
 # The main stream joins the side stream when backward finishes (engine callback); consumers that read gradients DURING
 # backward (the bucketed all-reduce, core/ddp.py) call wgrad_stream_join() themselves.
-WGRAD_SIDE_STREAM = os.environ.get('SEG3D_WGRAD_SIDE_STREAM', '1') != '0'
-WGRAD_SIDE_STREAM_IN_GRAPH = os.environ.get('SEG3D_WGRAD_SIDE_STREAM_IN_GRAPH', '1') != '0'
+WGRAD_SIDE_STREAM = True      # False (bench.py --no-wgrad-overlap, profiling): weight gradients on the main stream
 _SIDE_STREAMS = {}
 _JOIN_QUEUED_FOR = [-1]   # id of the backward pass (graph task) whose end-of-backward join is already queued
 
@@ -758,7 +749,7 @@ def _join_after_backward():
 
 def _wgrad_to_sink(xn, dyn, w_shape, kind, sink_view):
     """conv_wgrad accumulated into `sink_view`, on the side stream when enabled"""
-    if not WGRAD_SIDE_STREAM or (torch.cuda.is_current_stream_capturing() and not WGRAD_SIDE_STREAM_IN_GRAPH):
+    if not WGRAD_SIDE_STREAM:
         conv_wgrad(xn, dyn, w_shape, kind, out=sink_view)
         return
     # (inside a hipGraph capture the same fork / join becomes graph edges: the side stream joins the capture through

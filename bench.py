@@ -143,12 +143,14 @@ def variant_kernel_name(v):
 
 def pmc_traffic_gb(kernel_name):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_fetch_write_per_kernel.json: FETCH_SIZE and WRITE_SIZE in KB, collected in separate --pmc
+    (profiles/r02_pmc_fetch_write_per_kernel.json: FETCH_SIZE and WRITE_SIZE in KB, collected in separate --pmc
     passes).  gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE under-reports wide coalesced reads
     by 2x, WRITE_SIZE is exact.  Counters cannot be collected from inside bench.py; returns None when absent."""
-    path = os.path.join(REPO, 'profiles', 'r01_i_bf16_pmc_fetch_write_per_kernel.json' if 'bf16' in kernel_name
-                        else 'r01_pmc_fetch_write_per_kernel.json')
-    if not os.path.isfile(path):
+    prof = os.path.join(REPO, 'profiles')
+    cands = (['r02_bf16_pmc_fetch_write_per_kernel.json', 'r01_i_bf16_pmc_fetch_write_per_kernel.json'] if 'bf16' in kernel_name
+             else ['r02_pmc_fetch_write_per_kernel.json', 'r01_pmc_fetch_write_per_kernel.json'])
+    path = next((os.path.join(prof, c) for c in cands if os.path.isfile(os.path.join(prof, c))), None)
+    if path is None:
         return None
     with open(path) as f:
         table = json.load(f)
@@ -223,7 +225,7 @@ def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):
     return out
 
 
-def time_inference(net, volume_xyz, patch, stride, ncls, batch, device):
+def time_inference(net, volume_xyz, patch, stride, ncls, batch, device, two_streams=True):
     from segmentation3d.core.seg_infer import sliding_window_inference
     from segmentation3d.utils.image_tools import image_partition_by_fixed_size
     X, Y, Z = volume_xyz
@@ -244,7 +246,7 @@ def time_inference(net, volume_xyz, patch, stride, ncls, batch, device):
     for _ in range(3):
         t0 = time.time()
         probs, mask, _ = sliding_window_inference(net, vol, starts, (patch,) * 3, ncls, {'type': 1, 'clip_sigma': 3},
-                                                  batch_size=batch, use_graph=True)
+                                                  batch_size=batch, use_graph=True, two_streams=two_streams)
         torch.cuda.synchronize()
         runs.append(time.time() - t0)
         if len(runs) < 3:
@@ -253,7 +255,44 @@ def time_inference(net, volume_xyz, patch, stride, ncls, batch, device):
     t0 = time.time()
     mask_host = mask.cpu()
     t_d2h = time.time() - t0
-    return {'workload': 'sliding-window inference, {}x{}x{} volume, {}^3 patches stride {}, {} patches, batch {} per '
+    # roofline of the job: one eager, single-stream forward of a half batch (what one stream of a replay runs) with every
+    # launch of the MFMA 3x3x3 convolution bracketed by events -> its dominant instantiation against the fp32 MFMA peak,
+    # and the whole job against the FLOP floor (algorithmic forward FLOPs of all patches / peak)
+    roof = None
+    try:
+        from segmentation3d import _ops
+        half = max(1, batch // 2)
+        xb = torch.randn((half, 1, patch, patch, patch), device=device)
+        cache_was = _ops.weight_cache(True)
+        try:
+            with torch.no_grad():
+                net(xb)
+                with KernelTimer() as kt:
+                    net(xb)
+                table = kt.summary()
+        finally:
+            _ops.PACK_CACHE.enabled = cache_was
+        by_variant = {}
+        for key, e in table.items():
+            v = by_variant.setdefault(key[6], {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+            for k in v:
+                v[k] += e[k]
+        dom = max(by_variant, key=lambda m: by_variant[m]['ms'])
+        d = by_variant[dom]
+        conv_flops_per_patch = sum(e['flops'] for e in table.values()) / half
+        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        job_tflop = conv_flops_per_patch * len(starts) / 1e12
+        roof = {'kernel': variant_kernel_name(dom), 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'launches_per_forward': d['launches'],
+                'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                'job': {'algorithmic_tflop_mfma_convs': round(job_tflop, 2),
+                        'flop_floor_seconds': round(job_tflop / FP32_MFMA_PEAK_TFLOPS, 4),
+                        'frac_of_fp32_mfma_peak': round(job_tflop / t_dev / FP32_MFMA_PEAK_TFLOPS, 4)},
+                'note': 'one eager single-stream forward of {} patches after the timed jobs; the job runs two such half '
+                        'batches on two streams inside each hipGraph replay'.format(half)}
+    except Exception as exc:   # the roofline is a report, never a reason to lose the measurement
+        roof = {'error': repr(exc)}
+    return {'roofline': roof,'workload': 'sliding-window inference, {}x{}x{} volume, {}^3 patches stride {}, {} patches, batch {} per '
                         'hipGraph replay (two half batches on two streams), 1 forward/patch'.format(
                             X, Y, Z, patch, stride, len(starts), batch),
             'seconds': round(t_dev, 4), 'seconds_all_runs': [round(v, 4) for v in runs], 'h2d_seconds': round(t_h2d, 4),
@@ -411,6 +450,12 @@ def main():
                     'note': 'launch durations from 2 instrumented eager steps with the weight-gradient side stream off '
                             '(kernels back to back on one stream, garbage collector parked); value/ms_per_step are '
                             'measured with the side stream on (hipGraph replay)'}
+        # the whole step against the FLOP floor: algorithmic FLOPs of the MFMA convolutions (forward + data-gradient measured
+        # live above, weight gradients = one more forward's worth; SURVEY.md 8d: 541.6 GFLOP per 96^3 patch of vnet(1,2))
+        step_tflop = 1.5 * sum(e['flops'] for e in table.values()) / 2 / 1e12
+        roofline['step'] = {'algorithmic_tflop_mfma_convs': round(step_tflop, 3),
+                            'flop_floor_ms': round(step_tflop / peak * 1e3, 2),
+                            'frac_of_peak': round(step_tflop / (ms_per_step * 1e-3) / peak, 4)}
         if hbm_frac > achieved / peak:
             # (bf16 mode) the same launches priced against HBM: algorithmic bytes = input + output once
             roofline.update({'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

@@ -307,7 +307,118 @@ extern "C" int seg3d_conv3d_k2s2_bf16_fwd(const void* x_bf16, const void* wp, co
 // ---------------------------------------------------------------------------------------------------------------
 // ADD (data-gradient of a stride-2 conv whose input has a second consumer -- the skip connection): y = result + addend,
 // addend in y's dtype with row stride lda (a channel slice of the concatenated gradient); Cout % 8 == 0
-template <int MODE, bool OUT_BF = false, bool ADD = false>
+// epilogue of the scatter kernels (operands swapped: D[co][voxel]): per tap 4 dwordx4 stores of the lane's voxel, 32 per lane
+// instead of 128 dword stores.  Bias first, stores last, no load in between (stores count in vmcnt on gfx9).
+// o = output voxel index of tap (0, 0, 0) of this lane's input voxel, or -1
+template <bool OUT_BF, bool ADD, bool PAIR, int NACC>
+__device__ __forceinline__ void k2_scatter_epilogue(f32x16 (&acc)[NACC], int o, int cob, int lh, const float* __restrict__ bias,
+                                                    float* __restrict__ y, const void* __restrict__ addend, int lda, int Cout,
+                                                    int Ho, int Wo, float (&s)[2]) {
+  const int co0 = cob * 32 + 4 * lh;
+  f32x4 bv[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int co = co0 + 8 * g4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    bv[g4] = zero;
+    if (bias && co < Cout) bv[g4] = *reinterpret_cast<const f32x4*>(bias + co);
+  }
+  const int ng = (Cout - cob * 32 + 7) / 8 < 4 ? (Cout - cob * 32 + 7) / 8 : 4;   // uniform; Cout % 8 == 0 fast path
+  if (PAIR) {
+    // accumulator t holds taps 2 t (rows 0..15) and 2 t + 1 (rows 16..31): quads g4 = 0, 1 are channels 4 lh + 8 g4 of
+    // the even tap, g4 = 2, 3 the same channels of the odd tap.  Cout % 8 == 0 and Cout <= 16 (host-checked).
+    if (o >= 0) {
+      const int nq = Cout >> 3;   // channel quads per lane half: 1 or 2
+#pragma unroll
+      for (int tap = 0; tap < 8; ++tap) {
+        const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
+        const i64 dsto = ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co0;
+        typename Seg3dQuad<OUT_BF>::raw ar[2];
+        if (ADD) {
+          const i64 src = ((i64)o + (kz * Ho + ky) * Wo + kx) * lda + co0;
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            if (g < nq) ar[g] = Seg3dQuad<OUT_BF>::load(addend, src + 8 * g);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (g < nq) {
+            const int g4 = 2 * (tap & 1) + g;
+            f32x4 v;
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            if (ADD) av = Seg3dQuad<OUT_BF>::cvt(ar[g]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] = acc[PAIR ? (tap >> 1) : 0][4 * g4 + c] + bv[g][c] + av[c];
+              s[0] += v[c];
+              s[1] += v[c] * v[c];
+            }
+            Seg3dQuad<OUT_BF>::store(y, dsto + 8 * g, v);
+          }
+        }
+      }
+    }
+  } else if ((Cout & 7) == 0) {
+    if (o >= 0) {
+      // ADD: the addend quads of tap t + 1 are requested before tap t is stored (loads and stores share vmcnt)
+      typename Seg3dQuad<OUT_BF>::raw ar[2][4];
+      auto load_addend = [&](int tap, typename Seg3dQuad<OUT_BF>::raw (&dst)[4]) {
+        const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
+        const i64 src = ((i64)o + (kz * Ho + ky) * Wo + kx) * lda + co0;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          if (g4 < ng) dst[g4] = Seg3dQuad<OUT_BF>::load(addend, src + 8 * g4);
+      };
+      if (ADD) load_addend(0, ar[0]);
+#pragma unroll
+      for (int tap = 0; tap < 8; ++tap) {
+        const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
+        const i64 dsto = ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co0;
+        if (ADD && tap + 1 < 8) load_addend(tap + 1, ar[(tap + 1) & 1]);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          if (g4 < ng) {
+            f32x4 v;
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            if (ADD) av = Seg3dQuad<OUT_BF>::cvt(ar[tap & 1][g4]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] = acc[PAIR ? 0 : tap][4 * g4 + c] + bv[g4][c] + av[c];
+              s[0] += v[c];
+              s[1] += v[c] * v[c];
+            }
+            Seg3dQuad<OUT_BF>::store(y, dsto + 8 * g4, v);
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int tap = 0; tap < 8; ++tap) {
+      const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int co = co0 + 8 * g4;
+        if (o >= 0 && co < Cout) {
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            v[c] = acc[PAIR ? 0 : tap][4 * g4 + c] + bv[g4][c];
+            s[0] += v[c];
+            s[1] += v[c] * v[c];
+          }
+          Seg3dQuad<OUT_BF>::store(y, ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co, v);
+        }
+      }
+    }
+  }
+}
+
+// PAIR (Cout <= 16, e.g. the 64 -> 16 up-convolution of the top level and the 32 -> 16 data-gradient next to it): the 32
+// MFMA rows would be half empty -- and with 8 taps x Cin / 2 MFMAs of 64 cycles per 32 voxels these layers are MFMA-bound
+// at the top level, not HBM-bound -- so two taps share one MFMA: row = (tap & 1) * 16 + co.  The weight image is
+// re-paired while it is staged into LDS; 4 accumulators instead of 8.
+template <int MODE, bool OUT_BF = false, bool ADD = false, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* __restrict__ x,
                                                                      const float* __restrict__ wp,
                                                                      const float* __restrict__ bias,
@@ -354,13 +465,17 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
   }
   const int abase = (lh * MT + wave * 32 + li) * 4;  // rows >= MT read garbage inside xs (never stored)
   const int bbase = (lh * 32 + li) * 4;
-  f32x16 acc[8];
+  constexpr int NACC = PAIR ? 4 : 8;
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < 8; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // register prefetch of the next chunk (one float4 of x + two of weights per thread) behind the 32 MFMAs of this one
+  // register prefetch of the next chunk (one float4 of x + two of weights per thread) behind the MFMAs of this one.
+  // (Measured at the top level, 64 -> 16 at 48^3 -> 96^3: a ring of 8 x chunks in flight, and a whole-K variant that stages
+  // the complete x tile and weight image at once, changed nothing -- 116..129 us either way: per wave the epilogue's ~800
+  // vector instructions cost as much as its 128 MFMAs, and fp32 MFMA and VALU share one datapath.)
   typename K2In<MODE>::raw xst;
   f32x4 wst[2];
   auto load_chunk = [&](int cib) {
@@ -381,89 +496,32 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
     {
       f32x4* wdst = reinterpret_cast<f32x4*>(ws);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) wdst[tid + k * 256] = wst[k];
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + k * 256;          // entry ((tap * 2 + half) * 32 + co) of the standard image
+        if (PAIR) {
+          const int co = e & 31, th = e >> 5, tap = th >> 1, half = th & 1;
+          if (co < 16) wdst[(((tap >> 1) * 2 + half) << 5) + ((tap & 1) << 4) + co] = wst[k];
+        } else {
+          wdst[e] = wst[k];
+        }
+      }
     }
     __syncthreads();
     if (cib + 1 < CIB) load_chunk(cib + 1);
     f32x4 av = {0.f, 0.f, 0.f, 0.f};
     if (wave * 32 + li < MT) av = *reinterpret_cast<const f32x4*>(xs + abase);
 #pragma unroll
-    for (int tap = 0; tap < 8; ++tap) {
-      const f32x4 bw = *reinterpret_cast<const f32x4*>(ws + tap * 256 + bbase);
-      acc[tap] = k2_mfma_step<MODE>(bw, av, acc[tap]);
+    for (int t = 0; t < NACC; ++t) {
+      const f32x4 bw = *reinterpret_cast<const f32x4*>(ws + t * 256 + bbase);
+      acc[t] = k2_mfma_step<MODE>(bw, av, acc[t]);
     }
   }
 
-  // epilogue (operands swapped: D[co][voxel]): per tap 4 dwordx4 stores of the lane's voxel, 32 per lane instead of
-  // 128 dword stores.  Bias first, stores last, no load in between (stores count in vmcnt on gfx9).
   float s[2] = {0.f, 0.f};
   {
     const int idx = wave * 32 + li;
     const int o = idx < MT ? obase[idx] : -1;
-    const int co0 = cob * 32 + 4 * lh;
-    f32x4 bv[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int co = co0 + 8 * g4;
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      bv[g4] = zero;
-      if (bias && co < Cout) bv[g4] = *reinterpret_cast<const f32x4*>(bias + co);
-    }
-    const int ng = (Cout - cob * 32 + 7) / 8 < 4 ? (Cout - cob * 32 + 7) / 8 : 4;   // uniform; Cout % 8 == 0 fast path
-    if ((Cout & 7) == 0) {
-      if (o >= 0) {
-        // ADD: the addend quads of tap t + 1 are requested before tap t is stored (loads and stores share vmcnt)
-        typename Seg3dQuad<OUT_BF>::raw ar[2][4];
-        auto load_addend = [&](int tap, typename Seg3dQuad<OUT_BF>::raw (&dst)[4]) {
-          const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
-          const i64 src = ((i64)o + (kz * Ho + ky) * Wo + kx) * lda + co0;
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4)
-            if (g4 < ng) dst[g4] = Seg3dQuad<OUT_BF>::load(addend, src + 8 * g4);
-        };
-        if (ADD) load_addend(0, ar[0]);
-#pragma unroll
-        for (int tap = 0; tap < 8; ++tap) {
-          const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
-          const i64 dsto = ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co0;
-          if (ADD && tap + 1 < 8) load_addend(tap + 1, ar[(tap + 1) & 1]);
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            if (g4 < ng) {
-              f32x4 v;
-              f32x4 av = {0.f, 0.f, 0.f, 0.f};
-              if (ADD) av = Seg3dQuad<OUT_BF>::cvt(ar[tap & 1][g4]);
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                v[c] = acc[tap][4 * g4 + c] + bv[g4][c] + av[c];
-                s[0] += v[c];
-                s[1] += v[c] * v[c];
-              }
-              Seg3dQuad<OUT_BF>::store(y, dsto + 8 * g4, v);
-            }
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int tap = 0; tap < 8; ++tap) {
-        const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int co = co0 + 8 * g4;
-          if (o >= 0 && co < Cout) {
-            f32x4 v;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              v[c] = acc[tap][4 * g4 + c] + bv[g4][c];
-              s[0] += v[c];
-              s[1] += v[c] * v[c];
-            }
-            Seg3dQuad<OUT_BF>::store(y, ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co, v);
-          }
-        }
-      }
-    }
+    k2_scatter_epilogue<OUT_BF, ADD, PAIR, NACC>(acc, o, cob, lh, bias, y, addend, lda, Cout, Ho, Wo, s);
   }
   if (stats) {
     __syncthreads();
@@ -500,9 +558,16 @@ static int k2_scatter_launch(const void* x, int x_bf16, const float* wp, const f
   SEG3D_REQUIRE(x_bf16 != 2 || (Cin % 16) == 0, "seg3d_convT3d_k2s2_bf16_fwd: the bf16 weight image needs Cin %% 16 == 0");
   SEG3D_REQUIRE(!addend || ((Cout & 7) == 0 && lda >= Cout && (lda & 3) == 0),
                 "seg3d_convT3d_k2s2_scatter_addend: needs Cout %% 8 == 0 and a row stride >= Cout, multiple of 4");
+  const bool pair = Cout <= 16 && (Cout & 7) == 0;   // two taps per MFMA (rows (tap & 1) * 16 + co)
 #define K2_SCATTER(MODE_, OB_)                                                                                       \
   do {                                                                                                               \
-    if (addend)                                                                                                      \
+    if (addend && pair)                                                                                              \
+      hipLaunchKernelGGL((convT3d_k2s2_mfma_kernel<MODE_, OB_, true, true>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, \
+                         y, stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, addend, lda);         \
+    else if (pair)                                                                                                   \
+      hipLaunchKernelGGL((convT3d_k2s2_mfma_kernel<MODE_, OB_, false, true>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, \
+                         y, stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, addend, lda);         \
+    else if (addend)                                                                                                      \
       hipLaunchKernelGGL((convT3d_k2s2_mfma_kernel<MODE_, OB_, true>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
                          stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, addend, lda);             \
     else                                                                                                             \

@@ -517,7 +517,7 @@ def test_conv3d_k3_mfma_stats_partials(hip_device, shape):
     ('k2s2', 16, 32, (2, 8, 8, 8)), ('k2s2', 1, 16, (1, 4, 6, 8)), ('k2s2', 128, 256, (1, 2, 4, 4)),
     ('k2s2', 32, 64, (1, 6, 10, 12)), ('k2s2', 12, 20, (2, 2, 6, 14)),
     ('convT', 64, 16, (1, 4, 4, 6)), ('convT', 256, 128, (2, 2, 2, 2)), ('convT', 3, 5, (1, 3, 3, 3)),
-    ('convT', 128, 32, (1, 3, 5, 7)), ('convT', 16, 24, (2, 5, 4, 9)),
+    ('convT', 128, 32, (1, 3, 5, 7)), ('convT', 16, 24, (2, 5, 4, 9)), ('convT', 32, 8, (1, 3, 5, 7)), ('convT', 64, 16, (2, 6, 7, 9)),
     ('k1', 2, 2, (2, 8, 8, 8)), ('k1', 5, 5, (1, 4, 4, 4)), ('k1', 16, 8, (1, 4, 4, 4)),
 ])
 def test_strided_convs_fwd_bwd(hip_device, kind, cin, cout, dims, force_direct):

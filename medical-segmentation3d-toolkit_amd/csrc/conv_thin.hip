@@ -1111,6 +1111,11 @@ extern "C" int seg3d_conv3d_k3_thin_out_mfma_fwd(const void* x_bf16, const void*
 // thin weight gradient: G[t][ct][cf] = sum_u fat[u][cf] * thin[u + off(t)][ct]
 // ---------------------------------------------------------------------------------------------------------------
 // FAT_BF (bf16 mode, head weight gradient): the fat operand (the unit's bf16 input) is widened at the LDS store
+// Round 2: fp32 MFMA and the VALU share one datapath, and this kernel spent ~820 vector instructions per
+// tile and wave beside 32..64 MFMAs (index arithmetic of the staging loads and of the K loop).  Now every per-lane quantity
+// that does not depend on the tile is computed once: halo / tile coordinates of the staged entries (packed), LDS offsets of
+// the K steps (the loop is fully unrolled: the offsets are immediates), and rows beyond 27 CT read tap 0 instead of being
+// masked by a multiply (the reduce kernel never looks at them).
 template <int CT, bool FAT_BF>
 __device__ __forceinline__ void k3_thin_wgrad_body(const float* __restrict__ thin, const void* __restrict__ fat,
                                                                  float* __restrict__ part, int N, int D, int H, int W,
@@ -1124,16 +1129,15 @@ __device__ __forceinline__ void k3_thin_wgrad_body(const float* __restrict__ thi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int cf0 = blockIdx.y * 32;
-  // per-lane row descriptors
+  // per-lane row descriptors: LDS offset of row i = (tap, thin channel) relative to the voxel's own halo position
   int roff[RB];
-  float rmask[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    const int i = rb * 32 + li;
+    int i = rb * 32 + li;
+    if (i >= ROWS) i = 0;
     const int t = i / CT, a = i % CT;
     const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
-    roff[rb] = i < ROWS ? ((kz * TH_HY + ky) * TH_HX + kx) * CT + a : 0;
-    rmask[rb] = i < ROWS ? 1.f : 0.f;
+    roff[rb] = ((kz * TH_HY + ky) * TH_HX + kx) * CT + a;
   }
   f32x16 acc[RB];
 #pragma unroll
@@ -1143,45 +1147,86 @@ __device__ __forceinline__ void k3_thin_wgrad_body(const float* __restrict__ thi
   const int q = tid & 7;
   const bool fq_ok = cf0 + 4 * q < CF;
 
-  // register-prefetch pipeline over the tile loop (HBM-bound kernel: the next tile's loads stay in flight behind
-  // the MFMA block of the current one)
+  // staged entries of this thread (tile-invariant): thin halo entry k -> (hz, hy, hx, channel), fat entry k -> (tz, ty, tx);
+  // trel / frel = element offset from the tile's first voxel; tface = halo faces the entry lies on (bit 0..5 = z lo, z hi,
+  // y lo, y hi, x lo, x hi; bit 6 = no such entry).  When the level is a whole number of tiles (`regular`) an entry is
+  // padding exactly when one of its faces is outside the volume for this tile: no per-entry coordinate arithmetic.
   constexpr int TE = (TH_NV * CT + 255) / 256, FE = (TH_MT * 8) / 256;
+  static_assert(TE + FE <= 32, "okmask is 32 bits");
+  const bool regular = (D % TH_TZ) == 0 && (H % TH_TY) == 0 && (W % TH_TX) == 0;
+  int tpos[TE], fpos[FE], trel[TE], frel[FE], tface[TE];   // pos: hz << 20 | hy << 10 | hx (| channel << 28), -1: no entry
+#pragma unroll
+  for (int k = 0; k < TE; ++k) {
+    const int e = tid + k * 256;
+    const int v = e / CT, a = e % CT;
+    const int hx = v % TH_HX;
+    const int t = v / TH_HX;
+    const int hy = t % TH_HY, hz = t / TH_HY;
+    const bool have = e < TH_NV * CT;
+    tpos[k] = have ? ((a << 28) | (hz << 20) | (hy << 10) | hx) : -1;
+    trel[k] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * CT + a;
+    tface[k] = have ? ((hz == 0 ? 1 : 0) | (hz == TH_TZ + 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == TH_TY + 1 ? 8 : 0) |
+                       (hx == 0 ? 16 : 0) | (hx == TH_TX + 1 ? 32 : 0)) : 64;
+  }
+#pragma unroll
+  for (int k = 0; k < FE; ++k) {
+    const int v = (tid + k * 256) >> 3;
+    const int t = v / TH_TX;
+    fpos[k] = ((t / TH_TY) << 20) | ((t % TH_TY) << 10) | (v % TH_TX);
+    frel[k] = (((t / TH_TY) * H + (t % TH_TY)) * W + (v % TH_TX)) * CF + cf0 + 4 * q;
+  }
+  // K steps: wave w takes voxels [64 w, 64 w + 64); step kp, lane half lh is voxel 64 w + 2 kp + lh = (tz = w,
+  // ty = kp >> 2, tx = 2 (kp & 3) + lh): everything but the lane's own (lh, li) part is a compile-time offset
+  const int ts_lane = (wave * TH_HY * TH_HX + lh) * CT;
+  const int fs_lane = (wave * 64 + lh) * 32 + li;
+
+  // register-prefetch pipeline over the tile loop (the next tile's loads stay in flight behind the MFMA block of the
+  // current one)
   float tst[TE];
   typename Seg3dQuad<FAT_BF>::raw fst[FE];
-  static_assert(TE + FE <= 32, "okmask is 32 bits");
   unsigned okmask = 0;  // zero-select deferred to store_tile: a select right at the load would serialise the loads
-  auto load_tile = [&](int tile) {
+  auto load_tile = [&](int tile) {   // tile is wave-uniform: the decode below is scalar work
     int b = tile;
     const int tix = b % ntx; b /= ntx;
     const int tiy = b % nty; b /= nty;
     const int tiz = b % ntz;
     const int n = b / ntz;
     const int z0 = tiz * TH_TZ, y0 = tiy * TH_TY, x0 = tix * TH_TX;
+    const i64 vox0 = (i64)((n * D + z0) * H + y0) * W + x0;     // the tile's first voxel
     okmask = 0;
+    if (regular) {
+      const int faces = 64 | (z0 == 0 ? 1 : 0) | (z0 + TH_TZ >= D ? 2 : 0) | (y0 == 0 ? 4 : 0) | (y0 + TH_TY >= H ? 8 : 0) |
+                        (x0 == 0 ? 16 : 0) | (x0 + TH_TX >= W ? 32 : 0);
+      const float* tbase = thin + vox0 * CT;
+      const float* fbase = reinterpret_cast<const float*>(fat);   // element offsets below are in fat's own element type
 #pragma unroll
-    for (int k = 0; k < TE; ++k) {
-      const int e = tid + k * 256;
-      const int v = e / CT, a = e % CT;
-      const int hx = v % TH_HX;
-      const int t = v / TH_HX;
-      const int hy = t % TH_HY;
-      const int hz = t / TH_HY;
-      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-      const bool ok = e < TH_NV * CT && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      tst[k] = thin[ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * CT + a : (i64)0];
-      okmask |= (ok ? 1u : 0u) << k;
-    }
+      for (int k = 0; k < TE; ++k) {
+        const bool ok = (tface[k] & faces) == 0;
+        tst[k] = ok ? tbase[trel[k]] : thin[0];
+        okmask |= (ok ? 1u : 0u) << k;
+      }
+      (void)fbase;
 #pragma unroll
-    for (int k = 0; k < FE; ++k) {
-      const int v = (tid + k * 256) >> 3;
-      const int tx = v % TH_TX;
-      const int t = v / TH_TX;
-      const int ty = t % TH_TY;
-      const int tz = t / TH_TY;
-      const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
-      const bool ok = fq_ok && gz < D && gy < H && gx < W;
-      fst[k] = Seg3dQuad<FAT_BF>::load(fat, ok ? ((((i64)n * D + gz) * H + gy) * W + gx) * CF + cf0 + 4 * q : (i64)0);
-      okmask |= (ok ? 1u : 0u) << (TE + k);
+      for (int k = 0; k < FE; ++k) {
+        fst[k] = Seg3dQuad<FAT_BF>::load(fat, fq_ok ? vox0 * CF + frel[k] : (i64)0);
+        okmask |= (fq_ok ? 1u : 0u) << (TE + k);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < TE; ++k) {
+        const int hz = (tpos[k] >> 20) & 255, hy = (tpos[k] >> 10) & 1023, hx = tpos[k] & 1023;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = tpos[k] >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        tst[k] = thin[ok ? vox0 * CT + trel[k] : (i64)0];
+        okmask |= (ok ? 1u : 0u) << k;
+      }
+#pragma unroll
+      for (int k = 0; k < FE; ++k) {
+        const int tz = fpos[k] >> 20, ty = (fpos[k] >> 10) & 1023, tx = fpos[k] & 1023;
+        const bool ok = fq_ok && z0 + tz < D && y0 + ty < H && x0 + tx < W;
+        fst[k] = Seg3dQuad<FAT_BF>::load(fat, ok ? vox0 * CF + frel[k] : (i64)0);
+        okmask |= (ok ? 1u : 0u) << (TE + k);
+      }
     }
   };
   auto store_tile = [&]() {
@@ -1196,27 +1241,19 @@ __device__ __forceinline__ void k3_thin_wgrad_body(const float* __restrict__ thi
       *reinterpret_cast<f32x4*>(fs + ((tid + k * 256) >> 3) * 32 + 4 * q) =
           ((okmask >> (TE + k)) & 1u) ? Seg3dQuad<FAT_BF>::cvt(fst[k]) : zero;
   };
-  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int tile0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x), tstep = __builtin_amdgcn_readfirstlane((int)gridDim.x);
+  if (tile0 < ntiles) load_tile(tile0);
+  for (int tile = tile0; tile < ntiles; tile += tstep) {
     __syncthreads();
     store_tile();
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
-    // K (voxels) is split over the waves: wave w takes voxels [64w, 64w + 64)
-#pragma unroll 4
-    for (int kp = 0; kp < 32; ++kp) {
-      const int v = wave * 64 + 2 * kp + lh;
-      const int tx = v % TH_TX;
-      const int t = v / TH_TX;
-      const int ty = t % TH_TY;
-      const int tz = t / TH_TY;
-      const int ub = ((tz * TH_HY + ty) * TH_HX + tx) * CT;
-      const float bvv = fs[v * 32 + li];
+    if (tile + tstep < ntiles) load_tile(tile + tstep);
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const float a = ts[ub + roff[rb]] * rmask[rb];
-        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[rb], 0, 0, 0);
-      }
+    for (int kp = 0; kp < 32; ++kp) {
+      const int ub = ts_lane + ((kp >> 2) * TH_HX + 2 * (kp & 3)) * CT;
+      const float bvv = fs[fs_lane + kp * 64];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ts[ub + roff[rb]], bvv, acc[rb], 0, 0, 0);
     }
   }
   // reduce the 4 waves' accumulators through LDS (fixed order) and write this workgroup's slab [RB*32][32]

@@ -180,6 +180,14 @@ int seg3d_pack_weights_thin_out(const float* w, float* wq, int A, int B, int CO,
 long long seg3d_conv3d_k3_thin_out_stats_count(int D, int H, int W);
 int seg3d_conv3d_k3_thin_out_fwd(const float* x, const float* wq, const float* bias, float* y, float* stats_partial, int N,
                                  int D, int H, int W, int Cin, int Cout, int CO, void* stream);
+/* persistent form of the thin-input conv (csrc/conv_thin_f32.hip): same arithmetic and packed weights as
+ * seg3d_conv3d_k3_thin_in_fwd, a workgroup walks tiles with every tile-invariant index hoisted out of the tile loop;
+ * statistics: one slot per wave.  y is fp32, or bf16 storage when out_bf16.  replaces InputBlock.conv =
+ * nn.Conv3d(in, 16, 3, padding=1), network/module/vnet_inblock.py:9, and the input gradient of OutputBlock.conv1 */
+long long seg3d_conv3d_k3_thin_in_persistent_stats_count(int D, int H, int W, int Cout_blocks);
+int seg3d_conv3d_k3_thin_in_persistent_fwd(const float* x, const float* wp_thin, const float* bias, void* y,
+                                           float* stats_partial, int N, int D, int H, int W, int CT, int Cout, int out_bf16,
+                                           void* stream);
 /* fp32 head conv on the fp32 matrix cores (csrc/conv_thin_f32.hip; Cin in {16, 32}, Cout <= 5): x taps in the reduction
  * dimension of v_mfma_f32_16x16x4_f32, (kz, ky) taps in its output rows, the ninth tap on the VALU when 8 taps fill the
  * rows exactly (2 and 4 classes); every voxel row is read once, no LDS staging of activations.  Exact fp32 arithmetic.

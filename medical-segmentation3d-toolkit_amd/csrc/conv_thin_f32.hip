@@ -2,6 +2,8 @@
 // read ONCE (round 2; the VALU / 32x32x2 kernels of conv_thin.hip remain the general-shape fallbacks).
 //
 //   head forward  OutputBlock.conv1  Conv3d(16|32 -> num_classes <= 5, k3 p1)      network/module/vnet_outblock.py:13
+//   stem forward  InputBlock.conv    Conv3d(in_channels <= 8 -> 16, k3 p1)          network/module/vnet_inblock.py:9
+//                 (and the head's data-gradient, the same op with 2..5 input channels)  -- persistent thin-input kernel below
 //
 // Head forward.  12 GFLOP over a 453 MB input (AI 25 FLOP/B): HBM-bound in principle, but a GEMM with only num_classes
 // output columns wastes 30/32 of an MFMA tile and the LDS-tiled VALU kernel (conv_thin.hip) re-reads every 128-byte
@@ -461,5 +463,452 @@ extern "C" int seg3d_conv3d_k3_thin_out_f32mfma_fwd(const float* x, const float*
   }
 #undef SEG3D_TOF
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_thin_out_f32mfma_fwd");
+  return SEG3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// thin-input conv, persistent form (stem forward CT = in_channels, head data-gradient CT = classes; fp32)
+// ---------------------------------------------------------------------------------------------------------------
+// Same arithmetic as conv3d_k3_thin_in_kernel (conv_thin.hip): K = 27 CT folded into one MFMA reduction, weights as the ROW
+// operand in registers (packed by seg3d_pack_weights_thin_in), a lane ends up with one voxel and quads of consecutive
+// output channels.  That kernel ran one 256-voxel tile per workgroup and spent ~490 vector instructions per wave and tile
+// (index decode of the staged halo entries, per-step operand offsets, weight loads, block-wide statistics) beside 28 / 54
+// MFMAs -- and fp32 MFMA and VALU share the datapath, so it ran at 0.30 of HBM.  Here a workgroup walks tiles:
+// weights, staging coordinates (packed), face flags, relative offsets and the K steps' LDS offsets are computed once; the
+// next tile's halo loads are in flight behind the current tile's MFMAs; statistics are one slot per WAVE (no block reduce).
+#define TP_TZ 4
+#define TP_TY 8
+#define TP_TX 8
+#define TP_MT (TP_TZ * TP_TY * TP_TX)
+#define TP_HY (TP_TY + 2)
+#define TP_HX (TP_TX + 2)
+#define TP_NV ((TP_TZ + 2) * TP_HY * TP_HX)  // 600
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CT>
+__device__ __forceinline__ int thinp_koff(int k) {  // LDS float offset of GEMM-k inside the halo tile
+  const int t = k / CT, a = k % CT;
+  const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+  return t < 27 ? ((kz * TP_HY + ky) * TP_HX + kx) * CT + a : 0;
+}
+
+extern "C" long long seg3d_conv3d_k3_thin_in_persistent_stats_count(int D, int H, int W, int Cout_blocks) {
+  return 4ll * seg3d_cdiv(D, TP_TZ) * seg3d_cdiv(H, TP_TY) * seg3d_cdiv(W, TP_TX) * Cout_blocks;
+}
+
+template <int CT, bool OUT_BF>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_persistent_kernel(const float* __restrict__ x,
+                                                                                const float* __restrict__ wp,
+                                                                                const float* __restrict__ bias,
+                                                                                float* __restrict__ y, float* __restrict__ stats,
+                                                                                int N, int D, int H, int W, int Cout, int ntz,
+                                                                                int nty, int ntx, int ntiles) {
+  constexpr int KP = (27 * CT + 1) / 2;
+  constexpr int TE = (TP_NV * CT + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float xs[TP_NV * CT + 4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int cob = blockIdx.y;
+  const bool regular = (D % TP_TZ) == 0 && (H % TP_TY) == 0 && (W % TP_TX) == 0;
+
+  // weights of this lane's row for every k pair, kept in registers
+  float bw[KP];
+  {
+    const float* wsrc = wp + ((i64)cob * KP * 2 + lh) * 32 + li;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) bw[p] = wsrc[p * 64];
+  }
+  // staged halo entries of this thread (tile-invariant): packed coordinates, element offset from the tile's first voxel,
+  // halo faces (bit 0..5 = z lo, z hi, y lo, y hi, x lo, x hi; bit 6 = no such entry)
+  int tpos[TE], trel[TE], tface[TE];
+#pragma unroll
+  for (int k = 0; k < TE; ++k) {
+    const int e = tid + k * 256;
+    const int v = e / CT, a = e % CT;
+    const int hx = v % TP_HX;
+    const int t = v / TP_HX;
+    const int hy = t % TP_HY, hz = t / TP_HY;
+    const bool have = e < TP_NV * CT;
+    tpos[k] = have ? ((hz << 20) | (hy << 10) | hx) : -1;
+    trel[k] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * CT + a;
+    tface[k] = have ? ((hz == 0 ? 1 : 0) | (hz == TP_TZ + 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == TP_TY + 1 ? 8 : 0) |
+                       (hx == 0 ? 16 : 0) | (hx == TP_TX + 1 ? 32 : 0)) : 64;
+  }
+  // this lane's two voxels (row blocks wave, wave + 4): LDS base of their halo position, offset in the output tile
+  int abase[2], vrel[2], vpos[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int idx = (wave + 4 * m) * 32 + li;
+    const int tx = idx % TP_TX;
+    const int t = idx / TP_TX;
+    const int ty = t % TP_TY, tz = t / TP_TY;
+    abase[m] = ((tz * TP_HY + ty) * TP_HX + tx) * CT;
+    vrel[m] = (tz * H + ty) * W + tx;
+    vpos[m] = (tz << 20) | (ty << 10) | tx;
+  }
+  // K step p: lane half lh supplies k = 2 p + lh.  Even CT: the two halves are the two channels (a, a + 1) of one tap, i.e.
+  // LDS offsets (compile-time) + lh; odd CT: a per-lane table.
+  int koffs[(CT & 1) ? KP : 1];
+  if (CT & 1) {
+#pragma unroll
+    for (int p = 0; p < KP; ++p) koffs[p] = lh ? thinp_koff<CT>(2 * p + 1) : thinp_koff<CT>(2 * p);
+  }
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  (void)zero4;
+
+  float tst[TE];
+  unsigned okmask = 0;
+  auto load_tile = [&](int tile, int& n_out, int& z0_out, int& y0_out, int& x0_out) {   // tile is wave-uniform
+    int b = tile;
+    const int tix = b % ntx; b /= ntx;
+    const int tiy = b % nty; b /= nty;
+    const int tiz = b % ntz;
+    const int n = b / ntz;
+    const int z0 = tiz * TP_TZ, y0 = tiy * TP_TY, x0 = tix * TP_TX;
+    n_out = n; z0_out = z0; y0_out = y0; x0_out = x0;
+    const i64 vox0 = (i64)((n * D + z0) * H + y0) * W + x0;
+    okmask = 0;
+    if (regular) {
+      const int faces = 64 | (z0 == 0 ? 1 : 0) | (z0 + TP_TZ >= D ? 2 : 0) | (y0 == 0 ? 4 : 0) | (y0 + TP_TY >= H ? 8 : 0) |
+                        (x0 == 0 ? 16 : 0) | (x0 + TP_TX >= W ? 32 : 0);
+      const float* tbase = x + vox0 * CT;
+#pragma unroll
+      for (int k = 0; k < TE; ++k) {
+        const bool ok = (tface[k] & faces) == 0;
+        tst[k] = ok ? tbase[trel[k]] : x[0];
+        okmask |= (ok ? 1u : 0u) << k;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < TE; ++k) {
+        const int hz = (tpos[k] >> 20) & 255, hy = (tpos[k] >> 10) & 1023, hx = tpos[k] & 1023;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = tpos[k] >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        tst[k] = x[ok ? vox0 * CT + trel[k] : (i64)0];
+        okmask |= (ok ? 1u : 0u) << k;
+      }
+    }
+  };
+
+  const int tile0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x), tstep = __builtin_amdgcn_readfirstlane((int)gridDim.x);
+  int nn = 0, nz0 = 0, ny0 = 0, nx0 = 0;
+  if (tile0 < ntiles) load_tile(tile0, nn, nz0, ny0, nx0);
+  const int tiles_per_sample = ntz * nty * ntx;
+  const bool fast = regular && (Cout & 7) == 0;
+  const int ng = (Cout - cob * 32) >= 32 ? 4 : (Cout - cob * 32) >> 3;   // channel quads per lane (fast path)
+  f32x4 bv[4];   // this lane's bias values, quad g = channels cob * 32 + 8 g + 4 lh ..
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = cob * 32 + 8 * g + 4 * lh + j;
+      bv[g][j] = (bias && co < Cout) ? bias[co] : 0.f;
+    }
+  for (int tile = tile0; tile < ntiles; tile += tstep) {
+    const int n = nn, z0 = nz0, y0 = ny0, x0 = nx0;
+    __syncthreads();   // every wave is done reading the previous tile
+#pragma unroll
+    for (int k = 0; k < TE; ++k) {
+      const int e = tid + k * 256;
+      if (e < TP_NV * CT) xs[e] = ((okmask >> k) & 1u) ? tst[k] : 0.f;
+    }
+    __syncthreads();
+    if (tile + tstep < ntiles) load_tile(tile + tstep, nn, nz0, ny0, nx0);
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float bval;
+        if (CT & 1) bval = xs[abase[m] + koffs[p]];
+        else bval = xs[abase[m] + lh + thinp_koff<CT>(2 * p)];
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[p], bval, acc[m], 0, 0, 0);
+      }
+    }
+    // epilogue: register quad g of row block m = voxel (lane's column), channels cob * 32 + 8 g + 4 lh ..
+    float s0 = 0.f, s1 = 0.f;
+    const i64 vox0 = (i64)((n * D + z0) * H + y0) * W + x0;
+    if (fast) {   // whole tiles, Cout % 8 == 0: straight-line, ng quads per lane (wave-uniform)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float* yo = y + (OUT_BF ? 0 : (vox0 + vrel[m]) * Cout + cob * 32 + 4 * lh);
+        seg3d_bf16* yo16 = reinterpret_cast<seg3d_bf16*>(y) + (OUT_BF ? (vox0 + vrel[m]) * Cout + cob * 32 + 4 * lh : 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (g < ng) {
+            const f32x4 v4 = {acc[m][4 * g] + bv[g][0], acc[m][4 * g + 1] + bv[g][1], acc[m][4 * g + 2] + bv[g][2],
+                              acc[m][4 * g + 3] + bv[g][3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              s0 += v4[j];
+              s1 = fmaf(v4[j], v4[j], s1);
+            }
+            if (OUT_BF) {
+              uint2 pk;
+              pk.x = seg3d_pack2bf(v4[0], v4[1]);
+              pk.y = seg3d_pack2bf(v4[2], v4[3]);
+              *reinterpret_cast<uint2*>(yo16 + 8 * g) = pk;
+            } else {
+              *reinterpret_cast<f32x4*>(yo + 8 * g) = v4;
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int tz = vpos[m] >> 20, ty = (vpos[m] >> 10) & 1023, tx = vpos[m] & 1023;
+        const bool vok = z0 + tz < D && y0 + ty < H && x0 + tx < W;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co0 = cob * 32 + 8 * g + 4 * lh;
+          if (co0 >= Cout) continue;
+          float val[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool cok = co0 + j < Cout;
+            val[j] = acc[m][4 * g + j] + bv[g][j];
+            const float sv = (vok && cok) ? val[j] : 0.f;
+            s0 += sv;
+            s1 = fmaf(sv, sv, s1);
+          }
+          if (!vok) continue;
+          const i64 o = (vox0 + vrel[m]) * Cout + co0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co0 + j < Cout) {
+              if (OUT_BF) reinterpret_cast<seg3d_bf16*>(y)[o + j] = seg3d_f2bf(val[j]);
+              else y[o + j] = val[j];
+            }
+        }
+      }
+    }
+    if (stats) {   // one slot per wave
+#pragma unroll
+      for (int mm = 32; mm >= 1; mm >>= 1) {
+        s0 += __shfl_xor(s0, mm, 64);
+        s1 += __shfl_xor(s1, mm, 64);
+      }
+      if (lane == 0) {
+        const int tl = tile - n * tiles_per_sample;
+        float* dst = stats + ((((i64)n * tiles_per_sample + tl) * gridDim.y + cob) * 4 + wave) * 2;
+        dst[0] = s0;
+        dst[1] = s1;
+      }
+    }
+  }
+}
+
+// The same walk for Cout <= 16 (the stem: 16 channels) on v_mfma_f32_16x16x4_f32: the 32-row MFMA above is half empty
+// there, and since the fp32 MFMA shares the VALU datapath its 28 x 64 cycles per 64 voxels are real time (40 us of the
+// stem's 95).  Rows = the 16 output channels, a wave's 64 voxels are four 16-column groups, K steps of 4; a lane ends up
+// with 4 consecutive channels of one voxel per group, so the four lanes of a voxel store its whole 64-byte row at once.
+template <int CT, bool OUT_BF>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_persistent16_kernel(const float* __restrict__ x,
+                                                                                  const float* __restrict__ wp,
+                                                                                  const float* __restrict__ bias,
+                                                                                  float* __restrict__ y, float* __restrict__ stats,
+                                                                                  int N, int D, int H, int W, int Cout, int ntz,
+                                                                                  int nty, int ntx, int ntiles) {
+  constexpr int KP = (27 * CT + 1) / 2;     // k pairs of the packed weight image
+  constexpr int K16 = (27 * CT + 3) / 4;    // K steps of this kernel
+  constexpr int TE = (TP_NV * CT + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float xs[TP_NV * CT + 4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  const bool regular = (D % TP_TZ) == 0 && (H % TP_TY) == 0 && (W % TP_TX) == 0;
+
+  // weights: row `col` (output channel), k = 4 p + kq, taken from the pair image [k >> 1][k & 1][32]; LDS offset of that k
+  float bw[K16];
+  int koffs[K16];
+#pragma unroll
+  for (int p = 0; p < K16; ++p) {
+    const int k = 4 * p + kq;
+    bw[p] = k < 2 * KP ? wp[(k >> 1) * 64 + (k & 1) * 32 + col] : 0.f;
+    koffs[p] = kq == 0 ? thinp_koff<CT>(4 * p) : kq == 1 ? thinp_koff<CT>(4 * p + 1) : kq == 2 ? thinp_koff<CT>(4 * p + 2)
+                                                                                                 : thinp_koff<CT>(4 * p + 3);
+  }
+  int tpos[TE], trel[TE], tface[TE];
+#pragma unroll
+  for (int k = 0; k < TE; ++k) {
+    const int e = tid + k * 256;
+    const int v = e / CT, a = e % CT;
+    const int hx = v % TP_HX;
+    const int t = v / TP_HX;
+    const int hy = t % TP_HY, hz = t / TP_HY;
+    const bool have = e < TP_NV * CT;
+    tpos[k] = have ? ((hz << 20) | (hy << 10) | hx) : -1;
+    trel[k] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * CT + a;
+    tface[k] = have ? ((hz == 0 ? 1 : 0) | (hz == TP_TZ + 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == TP_TY + 1 ? 8 : 0) |
+                       (hx == 0 ? 16 : 0) | (hx == TP_TX + 1 ? 32 : 0)) : 64;
+  }
+  // this lane's four voxels: 64 wave + 16 cg + col
+  int abase[4], vrel[4], vpos[4];
+#pragma unroll
+  for (int cg = 0; cg < 4; ++cg) {
+    const int idx = wave * 64 + cg * 16 + col;
+    const int tx = idx % TP_TX;
+    const int t = idx / TP_TX;
+    const int ty = t % TP_TY, tz = t / TP_TY;
+    abase[cg] = ((tz * TP_HY + ty) * TP_HX + tx) * CT;
+    vrel[cg] = (tz * H + ty) * W + tx;
+    vpos[cg] = (tz << 20) | (ty << 10) | tx;
+  }
+
+  float tst[TE];
+  unsigned okmask = 0;
+  auto load_tile = [&](int tile, int& n_out, int& z0_out, int& y0_out, int& x0_out) {   // tile is wave-uniform
+    int b = tile;
+    const int tix = b % ntx; b /= ntx;
+    const int tiy = b % nty; b /= nty;
+    const int tiz = b % ntz;
+    const int n = b / ntz;
+    const int z0 = tiz * TP_TZ, y0 = tiy * TP_TY, x0 = tix * TP_TX;
+    n_out = n; z0_out = z0; y0_out = y0; x0_out = x0;
+    const i64 vox0 = (i64)((n * D + z0) * H + y0) * W + x0;
+    okmask = 0;
+    if (regular) {
+      const int faces = 64 | (z0 == 0 ? 1 : 0) | (z0 + TP_TZ >= D ? 2 : 0) | (y0 == 0 ? 4 : 0) | (y0 + TP_TY >= H ? 8 : 0) |
+                        (x0 == 0 ? 16 : 0) | (x0 + TP_TX >= W ? 32 : 0);
+      const float* tbase = x + vox0 * CT;
+#pragma unroll
+      for (int k = 0; k < TE; ++k) {
+        const bool ok = (tface[k] & faces) == 0;
+        tst[k] = ok ? tbase[trel[k]] : x[0];
+        okmask |= (ok ? 1u : 0u) << k;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < TE; ++k) {
+        const int hz = (tpos[k] >> 20) & 255, hy = (tpos[k] >> 10) & 1023, hx = tpos[k] & 1023;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = tpos[k] >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        tst[k] = x[ok ? vox0 * CT + trel[k] : (i64)0];
+        okmask |= (ok ? 1u : 0u) << k;
+      }
+    }
+  };
+
+  const int tile0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x), tstep = __builtin_amdgcn_readfirstlane((int)gridDim.x);
+  int nn = 0, nz0 = 0, ny0 = 0, nx0 = 0;
+  if (tile0 < ntiles) load_tile(tile0, nn, nz0, ny0, nx0);
+  const int tiles_per_sample = ntz * nty * ntx;
+  const bool chan_ok = 4 * kq < Cout;     // Cout % 4 == 0 (host-checked): the lane's channel quad is inside or outside
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias && chan_ok) bv = *reinterpret_cast<const f32x4*>(bias + 4 * kq);
+  for (int tile = tile0; tile < ntiles; tile += tstep) {
+    const int n = nn, z0 = nz0, y0 = ny0, x0 = nx0;
+    __syncthreads();   // every wave is done reading the previous tile
+#pragma unroll
+    for (int k = 0; k < TE; ++k) {
+      const int e = tid + k * 256;
+      if (e < TP_NV * CT) xs[e] = ((okmask >> k) & 1u) ? tst[k] : 0.f;
+    }
+    __syncthreads();
+    if (tile + tstep < ntiles) load_tile(tile + tstep, nn, nz0, ny0, nx0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < K16; ++p)
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg)
+        acc[cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[p], xs[abase[cg] + koffs[p]], acc[cg], 0, 0, 0);
+    float s0 = 0.f, s1 = 0.f;
+    const i64 vox0 = (i64)((n * D + z0) * H + y0) * W + x0;
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+      const int tz = vpos[cg] >> 20, ty = (vpos[cg] >> 10) & 1023, tx = vpos[cg] & 1023;
+      const bool vok = chan_ok && (regular || (z0 + tz < D && y0 + ty < H && x0 + tx < W));
+      const f32x4 v4 = acc[cg] + bv;
+      if (vok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s0 += v4[j];
+          s1 = fmaf(v4[j], v4[j], s1);
+        }
+        const i64 o = (vox0 + vrel[cg]) * Cout + 4 * kq;
+        if (OUT_BF) {
+          uint2 pk;
+          pk.x = seg3d_pack2bf(v4[0], v4[1]);
+          pk.y = seg3d_pack2bf(v4[2], v4[3]);
+          *reinterpret_cast<uint2*>(reinterpret_cast<seg3d_bf16*>(y) + o) = pk;
+        } else {
+          *reinterpret_cast<f32x4*>(y + o) = v4;
+        }
+      }
+    }
+    if (stats) {   // one slot per wave
+#pragma unroll
+      for (int mm = 32; mm >= 1; mm >>= 1) {
+        s0 += __shfl_xor(s0, mm, 64);
+        s1 += __shfl_xor(s1, mm, 64);
+      }
+      if (lane == 0) {
+        const int tl = tile - n * tiles_per_sample;
+        float* dst = stats + (((i64)n * tiles_per_sample + tl) * 4 + wave) * 2;
+        dst[0] = s0;
+        dst[1] = s1;
+      }
+    }
+  }
+}
+
+template <int CT>
+static void launch_thin_in_persistent(const float* x, const float* wp, const float* bias, float* y, float* stats, int N, int D,
+                                      int H, int W, int Cout, hipStream_t s, int out_bf16) {
+  const int ntz = seg3d_cdiv(D, TP_TZ), nty = seg3d_cdiv(H, TP_TY), ntx = seg3d_cdiv(W, TP_TX);
+  const int ntiles = N * ntz * nty * ntx;
+  const int cobs = (Cout + 31) / 32;
+  int wgs = 1024 / cobs;               // ~4 workgroups per CU over the whole grid (LDS 2.4 KB x CT, <= 128 registers)
+  if (wgs > ntiles) wgs = ntiles;
+  if (wgs < 1) wgs = 1;
+  dim3 grid((unsigned)wgs, (unsigned)cobs);
+  if (Cout <= 16 && (Cout & 3) == 0) {   // 16-row MFMA: no empty rows, whole 64-byte voxel rows per store
+    if (out_bf16)
+      hipLaunchKernelGGL((conv3d_k3_thin_in_persistent16_kernel<CT, true>), grid, dim3(256), 0, s, x, wp, bias, y, stats, N, D, H,
+                         W, Cout, ntz, nty, ntx, ntiles);
+    else
+      hipLaunchKernelGGL((conv3d_k3_thin_in_persistent16_kernel<CT, false>), grid, dim3(256), 0, s, x, wp, bias, y, stats, N, D, H,
+                         W, Cout, ntz, nty, ntx, ntiles);
+    return;
+  }
+  if (out_bf16)
+    hipLaunchKernelGGL((conv3d_k3_thin_in_persistent_kernel<CT, true>), grid, dim3(256), 0, s, x, wp, bias, y, stats, N, D, H, W,
+                       Cout, ntz, nty, ntx, ntiles);
+  else
+    hipLaunchKernelGGL((conv3d_k3_thin_in_persistent_kernel<CT, false>), grid, dim3(256), 0, s, x, wp, bias, y, stats, N, D, H, W,
+                       Cout, ntz, nty, ntx, ntiles);
+}
+
+// x [N][D][H][W][CT] (CT <= 8), wp = seg3d_pack_weights_thin_in, y [N][D][H][W][Cout] (fp32, or bf16 storage when out_bf16);
+// stats (optional): [N][seg3d_conv3d_k3_thin_in_persistent_stats_count(D, H, W, ceil(Cout / 32))][2]
+extern "C" int seg3d_conv3d_k3_thin_in_persistent_fwd(const float* x, const float* wp, const float* bias, void* y, float* stats,
+                                                      int N, int D, int H, int W, int CT, int Cout, int out_bf16, void* stream) {
+  SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_thin_in_persistent_fwd: null pointer");
+  SEG3D_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cout > 0, "seg3d_conv3d_k3_thin_in_persistent_fwd: bad dims");
+  SEG3D_REQUIRE(CT >= 1 && CT <= 8, "seg3d_conv3d_k3_thin_in_persistent_fwd: thin channel count %d not in [1, 8]", CT);
+  SEG3D_REQUIRE((i64)N * D * H * W * Cout < (1ll << 31) && (i64)N * D * H * W * CT < (1ll << 31),
+                "seg3d_conv3d_k3_thin_in_persistent_fwd: tensor exceeds 2^31 elements");
+  hipStream_t s = (hipStream_t)stream;
+  float* yf = reinterpret_cast<float*>(y);
+  switch (CT) {
+    case 1: launch_thin_in_persistent<1>(x, wp, bias, yf, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 2: launch_thin_in_persistent<2>(x, wp, bias, yf, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 3: launch_thin_in_persistent<3>(x, wp, bias, yf, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 4: launch_thin_in_persistent<4>(x, wp, bias, yf, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 5: launch_thin_in_persistent<5>(x, wp, bias, yf, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 6: launch_thin_in_persistent<6>(x, wp, bias, yf, stats, N, D, H, W, Cout, s, out_bf16); break;
+    case 7: launch_thin_in_persistent<7>(x, wp, bias, yf, stats, N, D, H, W, Cout, s, out_bf16); break;
+    default: launch_thin_in_persistent<8>(x, wp, bias, yf, stats, N, D, H, W, Cout, s, out_bf16); break;
+  }
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_thin_in_persistent_fwd");
   return SEG3D_OK;
 }

@@ -292,19 +292,23 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
         return y2.add_(addend), st
     if A <= 8 and not FORCE_DIRECT:
         # thin input (stem forward, head data-gradient): all 27*A taps folded into one MFMA K dimension
-        stats = None
-        if want_stats:
-            stats = _empty((N, E.query('seg3d_conv3d_k3_thin_stats_count', D, H, W_, (B + 31) // 32), 2), xn)
         if _is_bf16(y) and E.query('seg3d_conv3d_k3_thin_in_mfma16_supported', A, B):
+            stats = None
+            if want_stats:
+                stats = _empty((N, E.query('seg3d_conv3d_k3_thin_stats_count', D, H, W_, (B + 31) // 32), 2), xn)
             wq = torch.empty(E.query('seg3d_packed_thin_in16_elems', A, B), dtype=torch.bfloat16, device=w.device)
             E.call('seg3d_pack_weights_thin_in16', E.ptr(w), E.ptr(wq), A, B, sa, sb, flip, E.stream_ptr())
             E.call('seg3d_conv3d_k3_thin_in_mfma16_fwd', E.ptr(xn), E.ptr(wq), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H,
                    W_, A, B, E.stream_ptr())
             return y, stats
+        # fp32 arithmetic: the persistent kernel (tile-invariant index work hoisted, one statistics slot per wave)
+        stats = None
+        if want_stats:
+            stats = _empty((N, E.query('seg3d_conv3d_k3_thin_in_persistent_stats_count', D, H, W_, (B + 31) // 32), 2), xn)
         wp = _empty((E.query('seg3d_packed_thin_in_floats', A, B),), w)
         E.call('seg3d_pack_weights_thin_in', E.ptr(w), E.ptr(wp), A, B, sa, sb, flip, E.stream_ptr())
-        E.call('seg3d_conv3d_k3_thin_in_bf16out_fwd' if _is_bf16(y) else 'seg3d_conv3d_k3_thin_in_fwd', E.ptr(xn), E.ptr(wp),
-               E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H, W_, A, B, E.stream_ptr())
+        E.call('seg3d_conv3d_k3_thin_in_persistent_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, D, H,
+               W_, A, B, int(_is_bf16(y)), E.stream_ptr())
         return y, stats
     if not FORCE_DIRECT and E.query('seg3d_conv3d_k3_thin_out_f32mfma_supported', A, B):
         # thin output (head forward, Cin 16 / 32 -> <= 5 classes): fp32 matrix cores, (kz, ky) taps in the MFMA rows

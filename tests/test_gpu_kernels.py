@@ -372,6 +372,48 @@ def test_conv3d_k3_thin_in_mfma16(hip_device, shape, flip):
            out_scale=scale, stats_rel_err=rel_err(s[:, 1], (rr * rr).sum(1)))
 
 
+@pytest.mark.parametrize('shape', [(2, 1, 16, 8, 8, 16), (1, 1, 16, 5, 9, 11), (1, 2, 32, 6, 10, 18), (2, 2, 32, 4, 8, 8),
+                                   (1, 4, 16, 12, 16, 24), (1, 3, 20, 9, 5, 13), (1, 5, 48, 4, 8, 16), (3, 1, 16, 20, 24, 40),
+                                   (1, 8, 16, 4, 8, 8), (1, 1, 16, 1, 2, 3)])
+@pytest.mark.parametrize('flip', [0, 1])
+@pytest.mark.parametrize('out_bf16', [0, 1])
+def test_conv3d_k3_thin_in_persistent(hip_device, shape, flip, out_bf16):
+    """persistent thin-input conv (stem forward / head data-gradient, fp32 arithmetic) against the float64 convolution:
+    1..8 thin channels (even: immediate LDS offsets, odd: per-lane table), whole and ragged tiles, several tiles per
+    workgroup, partial channel blocks, flipped taps, fp32 and bf16-storage outputs, no-bias / no-stats calls, per-wave
+    statistics equal to those of the unrounded output"""
+    from segmentation3d import _ops, _engine as E
+    N, CT, Cout, D, H, W = shape
+    x = _t(74, 'px', (N, CT, D, H, W))
+    w = _t(75, 'pw', (Cout, CT, 3, 3, 3), std=0.2)
+    b = _t(76, 'pb', (Cout,), std=0.5)
+    xn = _ops.to_ndhwc(x.to(hip_device))
+    wd, bd = w.to(hip_device), b.to(hip_device)
+    wp = torch.full((E.query('seg3d_packed_thin_in_floats', CT, Cout),), float('nan'), device=hip_device)
+    E.call('seg3d_pack_weights_thin_in', E.ptr(wd), E.ptr(wp), CT, Cout, 27, CT * 27, flip, E.stream_ptr())
+    ydt = torch.bfloat16 if out_bf16 else torch.float32
+    y = torch.full((N, D, H, W, Cout), float('nan'), dtype=ydt, device=hip_device)
+    cnt = E.query('seg3d_conv3d_k3_thin_in_persistent_stats_count', D, H, W, (Cout + 31) // 32)
+    st = torch.full((N, cnt, 2), float('nan'), device=hip_device)
+    E.call('seg3d_conv3d_k3_thin_in_persistent_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bd), E.ptr(y), E.ptr(st), N, D, H, W, CT, Cout,
+           out_bf16, E.stream_ptr())
+    wref = w.flip(2, 3, 4) if flip else w
+    ref = F.conv3d(x.double(), wref.double(), b.double(), padding=1)
+    got = _ops.from_ndhwc(y.float()).double().cpu()
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert err < ((2.0 ** -8 + 2e-5) if out_bf16 else 2e-6) * scale, (err, scale)
+    s = st.double().sum(1).cpu()
+    rr = ref.reshape(N, -1)
+    assert float(((s[:, 0] - rr.sum(1)).abs() / rr.abs().sum(1)).max()) < 2e-5 and rel_err(s[:, 1], (rr * rr).sum(1)) < 2e-5
+    y2 = torch.full((N, D, H, W, Cout), float('nan'), dtype=ydt, device=hip_device)
+    E.call('seg3d_conv3d_k3_thin_in_persistent_fwd', E.ptr(xn), E.ptr(wp), None, E.ptr(y2), None, N, D, H, W, CT, Cout,
+           out_bf16, E.stream_ptr())
+    assert float((y2.float() + bd - y.float()).abs().max()) < (2.0 ** -7 if out_bf16 else 1e-6) * scale
+    report('thin_in_persistent_{}x{}x{}x{}_{}_{}_flip{}_bf{}'.format(N, D, H, W, CT, Cout, flip, out_bf16), max_abs_err=err,
+           out_scale=scale)
+
+
 @pytest.mark.parametrize('shape', [(2, 1, 16, 8, 8, 16), (1, 4, 16, 5, 9, 11), (1, 2, 32, 6, 10, 18)])
 def test_k3_thin_wgrad_stem_bf16_dy(hip_device, shape):
     """stem weight gradient in bf16 mode: thin = the fp32 image (hi + lo inside the kernel), fat = the bf16 dy"""

@@ -612,6 +612,7 @@ def test_gn_backward_fused_finalize_equals_two_launches(hip_device):
     gamma, beta = _t(93, 'fg', (C,)).to(hip_device), _t(94, 'fb', (C,)).to(hip_device)
     mean_rstd = torch.stack([y.reshape(N, -1).mean(1), 1.0 / (y.reshape(N, -1).var(1, unbiased=False) + 1e-5).sqrt()], 1).contiguous()
     results = []
+    was = _ops.GN_FUSED_FINALIZE
     for fused in (False, True, True, False, True):
         _ops.GN_FUSED_FINALIZE = fused
         try:
@@ -620,7 +621,7 @@ def test_gn_backward_fused_finalize_equals_two_launches(hip_device):
                                                            want_dbias=True, sinks=(None, sink, None))
             results.append((dy, dgamma, sink, dbias))
         finally:
-            _ops.GN_FUSED_FINALIZE = True
+            _ops.GN_FUSED_FINALIZE = was
     assert int(_ops._gn_ticket(hip_device).item()) == 0
     for r in results[1:]:
         for a, b in zip(results[0], r):

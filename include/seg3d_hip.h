@@ -100,6 +100,16 @@ long long seg3d_pack_job_blocks_bf16(int A, int B, int T);
 int seg3d_pack_weights_mfma_bf16_multi(const Seg3dPackJob* jobs_device, int njobs, long long total_blocks, void* stream);
 int seg3d_f32_to_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 int seg3d_bf16_to_f32(const void* src_bf16, float* dst, long long n, void* stream);
+/* Winograd F(2, 3) along x form of the same C -> C 3x3x3 convolution (csrc/conv_wino.hip): 2/3 of the fp32 MFMAs, exact
+ * fp32 transforms.  wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 36): T = 36 selects the transformed image
+ * (t = (kz * 3 + ky) * 4 + p) of the 27-tap weight.  Supported: whole 8 x 8 x 8 tiles, Cin % 8 == 0, Cout % 32 == 0; preferred
+ * (the faster choice): also >= 192 (tile, column block) items; other shapes use seg3d_conv3d_k3_mfma_fwd.  replaces nn.Conv3d(C, C, 3, padding=1),
+ * network/module/conv_gn_relu3.py:10, and its input gradient (flip = 1, transposed strides) */
+int seg3d_conv3d_k3_wino_supported(int N, int D, int H, int W, int Cin, int Cout);
+int seg3d_conv3d_k3_wino_preferred(int N, int D, int H, int W, int Cin, int Cout);
+long long seg3d_conv3d_k3_wino_stats_count(int N, int D, int H, int W, int Cin, int Cout);
+int seg3d_conv3d_k3_wino_fwd(const float* x, const float* wp_wino, const float* bias, const float* addend, float* y,
+                             float* stats_partial, int N, int D, int H, int W, int Cin, int Cout, void* stream);
 long long seg3d_conv3d_k3_bf16_stats_count(int N, int D, int H, int W, int Cin, int Cout);
 long long seg3d_conv3d_k3_bf16_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 /* 200 + 10*MA + NB = conv3d_k3_mfma2_bf16_kernel<MA, NB>; 0 = shape not supported */

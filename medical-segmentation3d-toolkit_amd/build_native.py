@@ -27,7 +27,8 @@ FLAGS = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-I', INCLUDE, 
 #   the weight-gradient kernel in AGPRs and copies all 112 in and out every tile (224 v_accvgpr_* per 448 MFMAs), and the
 #   fp32 MFMA shares the VALU datapath, so every such copy is paid in full (tools/ubench/mfma_valu.hip)
 EXTRA_FLAGS = {'conv_thin_f32.hip': ['-fno-slp-vectorize'],
-               'conv_mfma.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
+               'conv_mfma.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'],
+               'conv_wino.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def _sources():

@@ -114,6 +114,13 @@ extern "C" int seg3d_pack_weights_tapmajor(const float* w, float* wp, int A, int
   return SEG3D_OK;
 }
 
+// Winograd F(2, 3) along x (conv_wino.hip): T = 36 selects the transformed image of a 27-tap weight,
+// t = (kz * 3 + ky) * 4 + p with U_0 = g0, U_1 = (g0 + g1 + g2) / 2, U_2 = (g0 - g1 + g2) / 2, U_3 = g2 over the kx taps
+#define SEG3D_WINO_T 36
+__device__ __forceinline__ float seg3d_wino_u(float g0, float g1, float g2, int p) {
+  return p == 0 ? g0 : p == 1 ? 0.5f * ((g0 + g2) + g1) : p == 2 ? 0.5f * ((g0 + g2) - g1) : g2;
+}
+
 // MFMA pack (conv_mfma.hip): wp[bb][ab][t][h][j][r] = W(a = ab*8 + h*4 + r, b = bb*32 + j, t), zero padded.
 // One (bb, ab) chunk = T*2*32*4 floats is exactly the LDS image a workgroup stages per K-chunk, so staging is
 // a straight 16-byte copy.
@@ -131,7 +138,16 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict_
     int bb = (int)(rest / AB);
     int a = ab * 8 + h * 4 + r, b = bb * 32 + j;
     float v = 0.f;
-    if (a < A && b < B) v = w[a * sa + b * sb + (flip ? T - 1 - t : t)];
+    if (a < A && b < B) {
+      if (T == SEG3D_WINO_T) {   // t = (kz * 3 + ky) * 4 + p: Winograd F(2, 3) transform along kx of a 27-tap weight
+        const int t9 = t >> 2;
+        const float* g = w + a * sa + b * sb;
+        const float g0 = g[flip ? 26 - 3 * t9 : 3 * t9], g1 = g[flip ? 25 - 3 * t9 : 3 * t9 + 1], g2 = g[flip ? 24 - 3 * t9 : 3 * t9 + 2];
+        v = seg3d_wino_u(g0, g1, g2, t & 3);
+      } else {
+        v = w[a * sa + b * sb + (flip ? T - 1 - t : t)];
+      }
+    }
     wp[idx] = v;
   }
 }
@@ -240,7 +256,8 @@ template <> struct Seg3dPackTile<true> {
   static __device__ __forceinline__ void store(float* wp, i64 i, seg3d_bf16 v) { reinterpret_cast<seg3d_bf16*>(wp)[i] = v; }
 };
 
-template <int AW, bool BF, int TC>
+// WINO (jb.T = 36, fp32 images only): the 27 taps are read as usual, the packed chunk holds the 36 transformed "taps"
+template <int AW, bool BF, int TC, bool WINO = false>
 __device__ __forceinline__ void pack_mfma_chunk(const Seg3dPackJob& jb, int chunk,
                                                 typename Seg3dPackTile<BF>::type* __restrict__ tile) {
   typedef Seg3dPackTile<BF> TL;
@@ -282,6 +299,18 @@ __device__ __forceinline__ void pack_mfma_chunk(const Seg3dPackJob& jb, int chun
   __syncthreads();
   // packed order inside the chunk: [t][h][j][r]  with a = 4 h + r, b = j
   constexpr int HW = AW / 2;   // channels per half
+  if constexpr (WINO && !BF) {
+    const int n36 = AW * 32 * SEG3D_WINO_T;
+    for (int i = threadIdx.x; i < n36; i += 256) {
+      const int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, t36 = i / (HW * 64);
+      const int t9 = t36 >> 2;
+      const float* g = tile + ((HW * h + r) * 32 + j) * 27;
+      const float g0 = g[jb.flip ? 26 - 3 * t9 : 3 * t9], g1 = g[jb.flip ? 25 - 3 * t9 : 3 * t9 + 1],
+                  g2 = g[jb.flip ? 24 - 3 * t9 : 3 * t9 + 2];
+      jb.wp[(i64)chunk * n36 + i] = seg3d_wino_u(g0, g1, g2, t36 & 3);
+    }
+    return;
+  }
 #pragma unroll 6
   for (int i = threadIdx.x; i < n; i += 256) {
     const int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, t = i / (HW * 64);
@@ -310,6 +339,7 @@ __device__ __forceinline__ void pack_mfma_multi_body(const Seg3dPackJob* __restr
   const Seg3dPackJob jb = jobs[sjob];
   const int chunk = (int)((i64)blockIdx.x - jb.first_block);   // = bb * AB + ab
   if (jb.T == 27) pack_mfma_chunk<AW, BF, 27>(jb, chunk, tile);
+  else if (jb.T == SEG3D_WINO_T) pack_mfma_chunk<AW, BF, 27, true>(jb, chunk, tile);
   else if (jb.T == 8) pack_mfma_chunk<AW, BF, 8>(jb, chunk, tile);
   else pack_mfma_chunk<AW, BF, 0>(jb, chunk, tile);
 }

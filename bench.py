@@ -94,15 +94,16 @@ class KernelTimer(object):
         timer = self
 
         def call(name, *args):
-            if name not in ('seg3d_conv3d_k3_mfma_fwd', 'seg3d_conv3d_k3_bf16_fwd'):
+            if name not in ('seg3d_conv3d_k3_mfma_fwd', 'seg3d_conv3d_k3_bf16_fwd', 'seg3d_conv3d_k3_wino_fwd'):
                 return timer._orig(name, *args)
-            N, D, H, W, Cin, Cout = args[7:13]
+            wino = name == 'seg3d_conv3d_k3_wino_fwd'
+            N, D, H, W, Cin, Cout = args[6:12] if wino else args[7:13]
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             rc = timer._orig(name, *args)
             b.record()
-            ma = E.query('seg3d_conv3d_k3_bf16_variant' if 'bf16' in name else 'seg3d_conv3d_k3_mfma_variant',
-                         N, D, H, W, Cin, Cout)
+            ma = WINO_VARIANT if wino else E.query(
+                'seg3d_conv3d_k3_bf16_variant' if 'bf16' in name else 'seg3d_conv3d_k3_mfma_variant', N, D, H, W, Cin, Cout)
             timer.records.append(((N, D, H, W, Cin, Cout, ma), a, b, 2 if 'bf16' in name else 4))
             return rc
         E.call = call
@@ -127,8 +128,14 @@ class KernelTimer(object):
         return table
 
 
+WINO_VARIANT = 500   # the Winograd F(2,3) kernel (csrc/conv_wino.hip) in the variant column of the launch tables
+WINO_EXECUTED = 2.0 / 3.0   # it executes 4 multiplies per 2 outputs x 3 taps: 2/3 of the algorithmic FLOPs
+
+
 def variant_kernel_name(v):
     """seg3d_conv3d_k3_mfma_variant code -> kernel symbol as rocprofv3 prints it"""
+    if v == WINO_VARIANT:
+        return 'conv3d_k3_wino_kernel'
     if v >= 400:
         return 'conv3d_k3_mfma2w8_bf16_kernel<{}, {}, true>'.format((v - 400) // 10, v % 10)
     if v >= 300:   # two waves per SIMD, MA row blocks per wave
@@ -139,6 +146,17 @@ def variant_kernel_name(v):
     if v >= 100:
         return 'conv3d_k3_mfma2_kernel<{}, {}>'.format((v - 100) // 10, v % 10)
     return 'conv3d_k3_mfma_kernel<{}>'.format(v)
+
+
+def winograd_fields(variant, achieved, peak):
+    """`achieved` is priced on ALGORITHMIC FLOPs (2 x 27 x Cin x Cout per output voxel).  The Winograd kernel issues 2/3 of
+    them to the matrix cores, so its algorithmic fraction may exceed 1; the fraction of the MFMA peak its issued
+    multiply-adds reach is reported beside it."""
+    if variant != WINO_VARIANT:
+        return {}
+    return {'executed_tflops': round(achieved * WINO_EXECUTED, 2), 'frac_executed': round(achieved * WINO_EXECUTED / peak, 4),
+            'flops_note': 'Winograd F(2,3) along x: 4 multiplies per 2 outputs x 3 taps, so the matrix cores execute 2/3 of the '
+                          'algorithmic FLOPs `achieved`/`frac` are priced on; frac_executed = executed FLOPs / peak'}
 
 
 def pmc_traffic_gb(kernel_name):
@@ -154,7 +172,7 @@ def pmc_traffic_gb(kernel_name):
         return None
     with open(path) as f:
         table = json.load(f)
-    e = table.get(kernel_name)
+    e = table.get(kernel_name) or table.get(kernel_name.replace('void ', '', 1))   # non-template kernels print without 'void'
     if not e or 'FETCH_SIZE_KB_per_launch' not in e or 'WRITE_SIZE_KB_per_launch' not in e:
         return None
     return round((2.0 * e['FETCH_SIZE_KB_per_launch'] + e['WRITE_SIZE_KB_per_launch']) * 1024 / 1e9, 3)
@@ -285,6 +303,7 @@ def time_inference(net, volume_xyz, patch, stride, ncls, batch, device, two_stre
         roof = {'kernel': variant_kernel_name(dom), 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'launches_per_forward': d['launches'],
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                **winograd_fields(dom, achieved, FP32_MFMA_PEAK_TFLOPS),
                 'job': {'algorithmic_tflop_mfma_convs': round(job_tflop, 2),
                         'flop_floor_seconds': round(job_tflop / FP32_MFMA_PEAK_TFLOPS, 4),
                         'frac_of_fp32_mfma_peak': round(job_tflop / t_dev / FP32_MFMA_PEAK_TFLOPS, 4)},
@@ -447,6 +466,7 @@ def main():
                     'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                     'gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
                     'share_of_step_ms': round(d['ms'] / 2, 3),
+                    **winograd_fields(dom, achieved, peak),
                     'note': 'launch durations from 2 instrumented eager steps with the weight-gradient side stream off '
                             '(kernels back to back on one stream, garbage collector parked); value/ms_per_step are '
                             'measured with the side stream on (hipGraph replay)'}

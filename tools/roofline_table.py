@@ -19,7 +19,16 @@ else:
 variant_flops = {}
 for r in shapes:
     N, D, H, W, Ci, Co, v = r['N_D_H_W_Cin_Cout_variant']
-    name = 'conv3d_k3_mfma2_kernel<{}, {}>'.format((v - 100) // 10, v % 10) if v >= 100 else 'conv3d_k3_mfma_kernel<{}>'.format(v)
+    if v == 500:     # Winograd F(2,3): TFLOP/s below are ALGORITHMIC (the matrix cores execute 2/3 of them)
+        name = 'conv3d_k3_wino_kernel'
+    elif v >= 400:
+        name = 'conv3d_k3_mfma2w8_bf16_kernel<{}, {}, true>'.format((v - 400) // 10, v % 10)
+    elif v >= 300:
+        name = 'conv3d_k3_mfma2w8_kernel<{}, {}>'.format((v - 300) // 10, v % 10)
+    elif v >= 200:
+        name = 'conv3d_k3_mfma2_bf16_kernel<{}, {}, true>'.format((v - 200) // 10, v % 10)
+    else:
+        name = 'conv3d_k3_mfma2_kernel<{}, {}>'.format((v - 100) // 10, v % 10) if v >= 100 else 'conv3d_k3_mfma_kernel<{}>'.format(v)
     e = variant_flops.setdefault(name, [0.0, 0.0])
     e[0] += 2.0 * N * D * H * W * 27 * Ci * Co * r['launches_per_step']
     e[1] += r['avg_ms'] * r['launches_per_step']

@@ -110,6 +110,15 @@ int seg3d_conv3d_k3_wino_preferred(int N, int D, int H, int W, int Cin, int Cout
 long long seg3d_conv3d_k3_wino_stats_count(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_wino_fwd(const float* x, const float* wp_wino, const float* bias, const float* addend, float* y,
                              float* stats_partial, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+/* Winograd F(3, 2) along x form of the weight gradient of the same layers (csrc/conv_wino.hip): 36 point accumulators per
+ * (kz, ky, ci block, co block) instead of 27 taps at one voxel PAIR per K slot = 2/3 of the fp32 MFMAs; partial slabs are
+ * reduced in fixed order and turned into the three kx taps by the reduce kernel.  Supported: D, H, W multiples of 4, Cin and
+ * Cout multiples of 4; dw in the reference layout [Cout][Cin][3][3][3], written or (accumulate != 0) added to.
+ * replaces the weight gradient of nn.Conv3d(C, C, 3, padding=1), network/module/conv_gn_relu3.py:10 (autograd) */
+int seg3d_conv3d_k3_wino_wgrad_supported(int N, int D, int H, int W, int Cin, int Cout);
+long long seg3d_conv3d_k3_wino_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+int seg3d_conv3d_k3_wino_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H, int W,
+                               int Cin, int Cout, int accumulate, void* stream);
 long long seg3d_conv3d_k3_bf16_stats_count(int N, int D, int H, int W, int Cin, int Cout);
 long long seg3d_conv3d_k3_bf16_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 /* 200 + 10*MA + NB = conv3d_k3_mfma2_bf16_kernel<MA, NB>; 0 = shape not supported */

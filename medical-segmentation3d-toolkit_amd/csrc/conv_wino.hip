@@ -345,3 +345,357 @@ extern "C" int seg3d_conv3d_k3_wino_fwd(const float* x, const float* wp, const f
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino_fwd");
   return SEG3D_OK;
 }
+
+// ================================================================================================================
+// Weight gradient of the same layers with Winograd F(3, 2) along x (conv3d_k3_wgrad_wino_kernel).
+//   dW[kz][ky][kx][ci][co] = sum_v x[v + (kz, ky, kx) - 1][ci] dy[v][co].  For two output voxels that are neighbours in x
+//   (an output PAIR, g0 = dy[x0], g1 = dy[x0 + 1]) and the four inputs d0..d3 = x[x0 - 1 .. x0 + 2] of one (kz, ky) row the
+//   three kx taps are a 3-output correlation with a 2-tap filter: 4 multiplies instead of 6,
+//       D0 = d0 - d2, D1 = d1 + d2, D2 = d2 - d1, D3 = d1 - d3      (the forward kernel's input transform)
+//       E0 = g0,      E1 = g0 + g1, E2 = g0 - g1, E3 = g1           (the 1/2 of E1, E2 is applied once, after the sum)
+//       M_p = sum_pairs D_p (x) E_p                                  (four rank-1 updates per pair: the MFMA work)
+//       dW[kx=0] = M0 + (M1 + M2) / 2,  dW[1] = (M1 - M2) / 2,  dW[2] = (M1 + M2) / 2 - M3
+//   i.e. 36 accumulators [9 (kz, ky)][4 points] of [32 ci][32 co] instead of 27 taps, each fed one voxel PAIR per K slot:
+//   2/3 of the MFMAs of conv3d_k3_wgrad2_kernel (and 36 = 4 waves x 9: no idle accumulator slot, where 27 taps on 4 x 7
+//   left one).
+// Structure = conv3d_k3_wgrad2_kernel (conv_mfma.hip): one persistent workgroup per CU owns a 32 x 32 (ci, co) block pair
+//   and one spatial slab of tiles; wave w owns point p = w and keeps its 9 accumulators in registers across all tiles; the
+//   next tile's RAW x halo tile and dy tile arrive by LDS-DMA behind the MFMAs; between two tiles all waves transform RAW x
+//   once into T [p][halo row][pair][32 ci] (two barriers per tile); E_p is formed from the raw dy pair in registers (one
+//   FMA pair per 9 MFMAs).  Partial slabs [slab][pair][36][32][32] are reduced in fixed order, and turned into the three
+//   kx taps, by conv3d_k3_wgrad_wino_reduce_kernel (bitwise reproducible).
+//   LDS (4 x 4 x 8 tile): RAW x 45 KB + T 72 KB + 2 x 16 KB dy = 149 KB.
+// ================================================================================================================
+__device__ __forceinline__ int wn_mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+template <int TZ, int TY, int TX>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                        float* __restrict__ part, int N, int D, int H, int W,
+                                                                        int Cin, int Cout, int ntz, int nty, int ntx, int ntiles,
+                                                                        int slabs, int COB32) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HY = TY + 2, HX = TX + 2, PX = TX / 2;
+  constexpr int NRH = (TZ + 2) * HY;                   // halo rows
+  constexpr int NVH = NRH * HX;                        // halo voxels of the x tile
+  constexpr int MTV = TZ * TY * TX;                    // voxels of the dy tile
+  constexpr int KS = MTV / 4;                          // K steps per tile: two output pairs (four voxels) each
+  constexpr int XPC = NVH / 8, YPC = MTV / 8;          // 1-KiB DMA pieces (8 voxels x 32 channels)
+  static_assert(NVH % 8 == 0 && MTV % 8 == 0 && PX % 2 == 0, "tile shape");
+  constexpr int XS = NVH * 32;                         // floats of RAW x
+  constexpr int TS = 4 * NRH * PX * 32;                // floats of T
+  constexpr int YS = MTV * 32;                         // floats of one dy buffer
+  constexpr int GX = (XPC + 3) / 4, GY = (YPC + 3) / 4; // piece groups per wave per tile: x groups first, then dy groups
+  constexpr int NG = GX + GY;
+  static_assert(NG <= KS, "more DMA groups than K steps");
+  float* rawx = lds;
+  float* timg = lds + XS;
+  float* rawy = lds + XS + TS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = Winograd point p
+  const int li = lane & 31, lh = lane >> 5;
+  const int slab = blockIdx.x % slabs;
+  const int pg = blockIdx.x / slabs;                   // (ci block, co block)
+  const int cib = pg / COB32, cob = pg % COB32;
+  const int ci0 = cib * 32, co0 = cob * 32;
+  const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz;
+  auto fdiv = [](int v, float r) { return (int)(((float)v + 0.5f) * r); };  // exact for the small ranges used here
+  // E_p = g0' + e1 g1:  p = 0: g0, 1: g0 + g1, 2: g0 - g1, 3: g1 (g0' read one voxel on, e1 = 0)
+  const float e1 = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
+  const int g0off = wave == 3 ? 32 : 0;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // DMA pieces of this wave: group g < GX is x piece min(wave + 4 g, XPC - 1), group GX + g' is dy piece
+  // min(wave + 4 g', YPC - 1) (a slot past the end repeats the last piece: same source, same destination -- no branch);
+  // lane -> voxel 8 p + (lane >> 3), channels 4 (lane & 7)..+3.
+  // A piece's source is  tile origin (uniform)  +  a tile-invariant per-lane offset, and it is zero padding exactly when its
+  // halo face lies outside the volume (whole tiles only, host-checked).
+  const int lv = lane >> 3, lq = lane & 7;
+  int prel[NG], pflag[NG];  // float offset from the tile-origin voxel; face bits (bit 6: channel slice out of range)
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g < GX) {
+      const int p = wave + 4 * g < XPC ? wave + 4 * g : XPC - 1;
+      const int v = p * 8 + lv;
+      const int t = fdiv(v, 1.0f / (float)HX);
+      const int hx = v - t * HX;
+      const int hz = fdiv(t, 1.0f / (float)HY);
+      const int hy = t - hz * HY;
+      prel[g] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + ci0 + 4 * lq;
+      pflag[g] = (hz == 0 ? 1 : 0) | (hz == TZ + 1 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == TY + 1 ? 8 : 0) |
+                 (hx == 0 ? 16 : 0) | (hx == TX + 1 ? 32 : 0) | (ci0 + 4 * lq < Cin ? 0 : 64);
+    } else {
+      const int p = wave + 4 * (g - GX) < YPC ? wave + 4 * (g - GX) : YPC - 1;
+      const int v = p * 8 + lv;
+      const int co = co0 + 4 * lq;
+      prel[g] = (((v / (TX * TY)) * H + (v / TX) % TY) * W + v % TX) * Cout + co;
+      pflag[g] = co < Cout ? 0 : 64;
+    }
+  }
+  int tn = 0, tz0 = 0, ty0 = 0, tx0 = 0;  // origin of the tile being fetched
+  auto set_tile = [&](int tile) {
+    int b = tile;
+    int q = fdiv(b, rNTX);
+    const int tix = b - q * ntx;
+    b = q;
+    q = fdiv(b, rNTY);
+    const int tiy = b - q * nty;
+    b = q;
+    q = fdiv(b, rNTZ);
+    const int tiz = b - q * ntz;
+    tn = q;
+    tz0 = tiz * TZ, ty0 = tiy * TY, tx0 = tix * TX;
+  };
+  auto issue_piece = [&](int g, float* ydst, const float* xbase, const float* ybase, int faces) {
+    const float* base = g < GX ? xbase : ybase;            // compile-time choice (g is an unrolled loop index)
+    float* dst;
+    if (g < GX) dst = rawx + (wave + 4 * g < XPC ? wave + 4 * g : XPC - 1) * 256;
+    else dst = ydst + (wave + 4 * (g - GX) < YPC ? wave + 4 * (g - GX) : YPC - 1) * 256;
+    const float* src = (pflag[g] & faces) ? wn_zero16 : base + prel[g];
+    wn_glds16(src, dst);
+  };
+  auto transform = [&]() {   // RAW x -> T[p][row][pair][32]
+    constexpr int ITEMS = NRH * PX * 8;
+#pragma unroll
+    for (int r = 0; r < (ITEMS + 255) / 256; ++r) {
+      const int i = tid + 256 * r;
+      if (i < ITEMS) {
+        const int c4 = i & 7, t = i >> 3;
+        const int row = t / PX, px = t - row * PX;
+        const float* src = rawx + (row * HX + 2 * px) * 32 + 4 * c4;
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(src + 32);
+        const f32x4 d2 = *reinterpret_cast<const f32x4*>(src + 64);
+        const f32x4 d3 = *reinterpret_cast<const f32x4*>(src + 96);
+        float* dst = timg + (row * PX + px) * 32 + 4 * c4;
+        *reinterpret_cast<f32x4*>(dst) = d0 - d2;
+        *reinterpret_cast<f32x4*>(dst + NRH * PX * 32) = d1 + d2;
+        *reinterpret_cast<f32x4*>(dst + 2 * NRH * PX * 32) = d2 - d1;
+        *reinterpret_cast<f32x4*>(dst + 3 * NRH * PX * 32) = d1 - d3;
+      }
+    }
+  };
+  auto tile_faces = [&]() {
+    return 64 | (tz0 == 0 ? 1 : 0) | (tz0 + TZ >= D ? 2 : 0) | (ty0 == 0 ? 4 : 0) | (ty0 + TY >= H ? 8 : 0) |
+           (tx0 == 0 ? 16 : 0) | (tx0 + TX >= W ? 32 : 0);
+  };
+
+  // tile walk: XCD-contiguous when the slab count allows (as the forward kernels)
+  int tile = slab, tstride = slabs, tlimit = ntiles;
+  if ((slabs & 7) == 0) {
+    const int per_xcd = (ntiles + 7) >> 3, xcd = slab & 7;
+    tile = xcd * per_xcd + (slab >> 3);
+    tstride = slabs >> 3;
+    tlimit = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+  }
+  int parity = 0;
+  if (tile < tlimit) {
+    set_tile(tile);
+    const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
+    const int faces = tile_faces();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) issue_piece(g, rawy, x + origin * Cin, dy + origin * Cout, faces);
+    __syncthreads();
+    transform();
+    __syncthreads();
+  }
+  for (; tile < tlimit; tile += tstride) {
+    const float* ycur = rawy + parity * YS;
+    float* ynxt = rawy + (parity ^ 1) * YS;
+    const bool more = tile + tstride < tlimit;
+    if (more) set_tile(tile + tstride);
+    const int faces = tile_faces();
+    const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
+    const float* xbase = x + origin * Cin;
+    const float* ybase = dy + origin * Cout;
+    // K step k: output pairs 2k (lane half 0) and 2k + 1 (half 1), neighbours in one tile row
+    const float* ta = timg + wave * (NRH * PX * 32) + lane;       // + ((row + kz HY + ky) PX + px0) 32
+    const float* yb = ycur + lh * 64 + li;                        // + (first voxel of pair 2k) 32; g1 one voxel on
+    auto aoff = [](int k, int j) {
+      const int q0 = 2 * k;
+      const int z = q0 / (TY * PX), yy = (q0 / PX) % TY, px0 = q0 % PX;
+      return (((z + j / 3) * HY + yy + j % 3) * PX + px0) * 32;
+    };
+    float a1[9], g1a, g1b;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) a1[j] = ta[aoff(0, j)];
+    g1a = yb[g0off];
+    g1b = yb[32];
+    // The next tile is fetched behind the first NG K steps, unconditionally: after its last tile a workgroup fetches that
+    // tile once more into the idle buffers (no branch in the MFMA loop; the barrier below drains it).
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      float a[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) a[j] = a1[j];
+      const float b = fmaf(e1, g1b, g1a);
+      if (k + 1 < KS) {   // operands of step k + 1 are read while step k is multiplied
+#pragma unroll
+        for (int j = 0; j < 9; ++j) a1[j] = ta[aoff(k + 1, j)];
+        g1a = yb[(k + 1) * 128 + g0off];
+        g1b = yb[(k + 1) * 128 + 32];
+      }
+      if (k < NG) issue_piece(k, ynxt, xbase, ybase, faces);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b, acc[j], 0, 0, 0);
+    }
+    __syncthreads();     // own DMAs landed (vmcnt(0)), everyone done with T
+    if (more) {
+      transform();       // the next tile's RAW x -> T
+      __syncthreads();
+    }
+    parity ^= 1;
+  }
+
+  // part[slab][pair = cib * COB32 + cob][(kz, ky) * 4 + p][ci row][co col]
+  float* dst = part + ((i64)slab * (COB32 * ((Cin + 31) / 32)) + cib * COB32 + cob) * 36 * 1024;
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(j * 4 + wave) * 1024 + wn_mfma_row(r, lh) * 32 + li] = acc[j][r];
+}
+
+// dw[a*sa + b*sb + (kz,ky)*3 + kx] from  M_p = sum_slab part[slab][a/32][b/32][(kz,ky)*4 + p][a%32][b%32]:
+//   kx 0: M0 + (M1 + M2)/2,  kx 1: (M1 - M2)/2,  kx 2: (M1 + M2)/2 - M3.
+// A lane owns four consecutive b of one (pair, (kz, ky), a); the G waves of a workgroup take the slabs k = g, g + G, ..;
+// partial sums are combined through LDS in a fixed order.
+template <int G>
+__global__ __launch_bounds__(64 * G) void conv3d_k3_wgrad_wino_reduce_kernel(const float* __restrict__ part,
+                                                                               float* __restrict__ dw, int slabs, int A, int B,
+                                                                               int BB32, int npairs, i64 sa, i64 sb,
+                                                                               int accumulate) {
+  __shared__ f32x4 red[G * 64 * 4];
+  const i64 totalq = (i64)npairs * 9 * 256;                     // (pair, (kz, ky), a, b quad)
+  const i64 qidx = (i64)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  f32x4 s[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) s[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const i64 slabq = (i64)npairs * 36 * 256;                     // float4 quads per slab
+  if (qidx < totalq) {
+    const i64 r9 = qidx >> 8;                                   // pair * 9 + (kz, ky)
+    const f32x4* p0 = reinterpret_cast<const f32x4*>(part) + r9 * 4 * 256 + (qidx & 255);
+    for (int k = g; k < slabs; k += G) {
+      const f32x4* q = p0 + (i64)k * slabq;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s[p] += q[p * 256];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) red[threadIdx.x * 4 + p] = s[p];
+  __syncthreads();
+  if (g == 0 && qidx < totalq) {
+#pragma unroll
+    for (int j = 1; j < G; ++j)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s[p] += red[(j * 64 + threadIdx.x) * 4 + p];
+    const f32x4 hs = (s[1] + s[2]) * 0.5f, hd = (s[1] - s[2]) * 0.5f;
+    const f32x4 w0 = s[0] + hs, w1 = hd, w2 = hs - s[3];
+    const int b32 = (int)((qidx & 7) * 4), a32 = (int)((qidx >> 3) & 31);
+    const i64 r9 = qidx >> 8;
+    const int t9 = (int)(r9 % 9);
+    const int pair = (int)(r9 / 9);
+    const int a = (pair / BB32) * 32 + a32, b = (pair % BB32) * 32 + b32;
+    if (a < A) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (b + j < B) {
+          float* d = dw + a * sa + (b + j) * sb + t9 * 3;
+          if (accumulate) {
+            d[0] += w0[j];
+            d[1] += w1[j];
+            d[2] += w2[j];
+          } else {
+            d[0] = w0[j];
+            d[1] = w1[j];
+            d[2] = w2[j];
+          }
+        }
+    }
+  }
+}
+
+struct WnWgradPlan {
+  int tx;      // tile 4 x 4 x tx, tx = 8 or 4
+  int slabs;
+};
+
+static WnWgradPlan wn_wgrad_plan(int N, int D, int H, int W, int Cin, int Cout) {
+  WnWgradPlan p;
+  p.tx = (W % 8 == 0) ? 8 : 4;
+  const i64 ntiles = (i64)N * (D / 4) * (H / 4) * (W / p.tx);
+  const int npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
+  i64 slabs = 256 / npairs;  // one resident workgroup per CU over the whole grid
+  if (slabs > (ntiles + 1) / 2) slabs = (ntiles + 1) / 2;  // small levels: >= 2 tiles per workgroup
+  if (slabs < 1) slabs = 1;
+  p.slabs = (int)slabs;
+  return p;
+}
+
+// shapes the Winograd weight gradient takes: whole 4 x 4 x 4 tiles, channels in fours
+extern "C" int seg3d_conv3d_k3_wino_wgrad_supported(int N, int D, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  if ((D % 4) || (H % 4) || (W % 4) || (Cin & 3) || (Cout & 3)) return 0;
+  if ((long long)N * D * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;
+  if ((long long)N * (D / 4) * (H / 4) * (W / 4) >= SEG3D_FDIV_MAX) return 0;
+  return 1;
+}
+
+extern "C" long long seg3d_conv3d_k3_wino_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
+  const int npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
+  return (long long)wn_wgrad_plan(N, D, H, W, Cin, Cout).slabs * npairs * 36 * 1024;
+}
+
+template <int TZ, int TY, int TX>
+static int wn_launch_wgrad(const float* x, const float* dy, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
+                           int slabs, hipStream_t s) {
+  const int ntz = D / TZ, nty = H / TY, ntx = W / TX;
+  const int ntiles = N * ntz * nty * ntx;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_wino_kernel<TZ, TY, TX>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) {
+      seg3d_set_error("conv3d_k3_wgrad_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SEG3D_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
+  constexpr int NRH = (TZ + 2) * (TY + 2);
+  const size_t lds = (size_t)(NRH * (TX + 2) * 32 + 4 * NRH * (TX / 2) * 32 + 2 * TZ * TY * TX * 32) * 4;
+  hipLaunchKernelGGL((conv3d_k3_wgrad_wino_kernel<TZ, TY, TX>), dim3((unsigned)(slabs * CIB32 * COB32)), dim3(256), lds, s, x, dy,
+                     workspace, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, COB32);
+  return SEG3D_OK;
+}
+
+// x [N][D][H][W][Cin], dy [N][D][H][W][Cout]; dw in the reference Conv3d layout [Cout][Cin][3][3][3] (written, or added to
+// when accumulate != 0); workspace = seg3d_conv3d_k3_wino_wgrad_workspace_floats floats
+extern "C" int seg3d_conv3d_k3_wino_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H,
+                                          int W, int Cin, int Cout, int accumulate, void* stream) {
+  SEG3D_REQUIRE(x && dy && dw && workspace, "seg3d_conv3d_k3_wino_wgrad: null pointer");
+  SEG3D_REQUIRE(seg3d_conv3d_k3_wino_wgrad_supported(N, D, H, W, Cin, Cout),
+                "seg3d_conv3d_k3_wino_wgrad: shape not supported (whole 4^3 tiles, Cin %% 4 == 0, Cout %% 4 == 0)");
+  const WnWgradPlan plan = wn_wgrad_plan(N, D, H, W, Cin, Cout);
+  const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32, npairs = CIB32 * COB32;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = plan.tx == 8 ? wn_launch_wgrad<4, 4, 8>(x, dy, workspace, N, D, H, W, Cin, Cout, plan.slabs, s)
+                              : wn_launch_wgrad<4, 4, 4>(x, dy, workspace, N, D, H, W, Cin, Cout, plan.slabs, s);
+  if (rc != SEG3D_OK) return rc;
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino_wgrad");
+  const i64 totalq = (i64)npairs * 9 * 256;
+  const unsigned grid = (unsigned)((totalq + 63) / 64);
+  if (plan.slabs >= 32)
+    hipLaunchKernelGGL(conv3d_k3_wgrad_wino_reduce_kernel<8>, dim3(grid), dim3(512), 0, s, workspace, dw, plan.slabs, Cin, Cout,
+                       COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
+  else
+    hipLaunchKernelGGL(conv3d_k3_wgrad_wino_reduce_kernel<4>, dim3(grid), dim3(256), 0, s, workspace, dw, plan.slabs, Cin, Cout,
+                       COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino_wgrad(reduce)");
+  return SEG3D_OK;
+}

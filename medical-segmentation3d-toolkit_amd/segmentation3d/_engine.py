@@ -90,6 +90,9 @@ _SIGNATURES = {
     'seg3d_conv3d_k3_wino_preferred': (_c_int, [_c_int] * 6),
     'seg3d_conv3d_k3_wino_stats_count': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_wino_fwd': (_c_int, [_c_p] * 6 + [_c_int] * 6 + [_c_p]),
+    'seg3d_conv3d_k3_wino_wgrad_supported': (_c_int, [_c_int] * 6),
+    'seg3d_conv3d_k3_wino_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),
+    'seg3d_conv3d_k3_wino_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 7 + [_c_p]),
     'seg3d_conv3d_k3_thin_out_f32mfma_supported': (_c_int, [_c_int] * 2),
     'seg3d_thin_out_f32mfma_packed_floats': (_c_ll, [_c_int] * 2),
     'seg3d_pack_weights_thin_out_f32mfma': (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_ll, _c_ll, _c_int, _c_p]),

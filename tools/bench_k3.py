@@ -15,7 +15,7 @@ def timed(fn, iters):
     return a.elapsed_time(c) / iters
 
 def main():
-    shapes = [tuple(int(v) for v in sys.argv[1:6])] if len(sys.argv) >= 6 else [(4, 96, 96, 96, 32), (8, 96, 96, 96, 32), (4, 48, 48, 48, 64), (8, 48, 48, 48, 64), (4, 24, 24, 24, 128), (8, 24, 24, 24, 128), (4, 48, 48, 48, 32), (4, 24, 24, 24, 64)]
+    shapes = [tuple(int(v) for v in sys.argv[1:6])] if len(sys.argv) >= 6 else [(4, 96, 96, 96, 32), (8, 96, 96, 96, 32), (4, 48, 48, 48, 64), (8, 48, 48, 48, 64), (4, 24, 24, 24, 128), (8, 24, 24, 24, 128), (4, 48, 48, 48, 32), (4, 24, 24, 24, 64), (4, 12, 12, 12, 128), (4, 12, 12, 12, 256)]
     iters = int(sys.argv[6]) if len(sys.argv) > 6 else 5
     dev = torch.device('cuda:0')
     for N, D, H, W, C in shapes:
@@ -35,6 +35,17 @@ def main():
             E.call('seg3d_pack_weights_mfma', E.ptr(w), E.ptr(wq), C, C, 36, 27, C * 27, 0, E.stream_ptr())
             st2 = torch.empty(N, E.query('seg3d_conv3d_k3_wino_stats_count', N, D, H, W, C, C), 2, device=dev)
             ms2 = timed(lambda: E.call('seg3d_conv3d_k3_wino_fwd', E.ptr(x), E.ptr(wq), E.ptr(b), None, E.ptr(y), E.ptr(st2), N, D, H, W, C, C, E.stream_ptr()), iters)
+            line += '   winograd {:8.3f} ms {:6.1f} TF (algorithmic)  x{:.2f}'.format(ms2, fl / ms2 / 1e9, ms / ms2)
+        print(line, flush=True)
+        # weight gradient: 27-tap kernel vs Winograd F(3,2)
+        dyv = torch.randn(N, D, H, W, C, device=dev)
+        dw = torch.empty(C, C, 3, 3, 3, device=dev)
+        wsg = torch.empty(E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W, C, C), device=dev)
+        ms = timed(lambda: E.call('seg3d_conv3d_k3_mfma_wgrad', E.ptr(x), E.ptr(dyv), E.ptr(dw), E.ptr(wsg), N, D, H, W, C, C, 0, E.stream_ptr()), iters)
+        line = '    wgrad direct {:8.3f} ms {:6.1f} TF'.format(ms, fl / ms / 1e9)
+        if E.query('seg3d_conv3d_k3_wino_wgrad_supported', N, D, H, W, C, C):
+            wsq = torch.empty(E.query('seg3d_conv3d_k3_wino_wgrad_workspace_floats', N, D, H, W, C, C), device=dev)
+            ms2 = timed(lambda: E.call('seg3d_conv3d_k3_wino_wgrad', E.ptr(x), E.ptr(dyv), E.ptr(dw), E.ptr(wsq), N, D, H, W, C, C, 0, E.stream_ptr()), iters)
             line += '   winograd {:8.3f} ms {:6.1f} TF (algorithmic)  x{:.2f}'.format(ms2, fl / ms2 / 1e9, ms / ms2)
         print(line, flush=True)
 

@@ -94,15 +94,16 @@ class KernelTimer(object):
         timer = self
 
         def call(name, *args):
-            if name not in ('seg3d_conv3d_k3_mfma_fwd', 'seg3d_conv3d_k3_bf16_fwd', 'seg3d_conv3d_k3_wino_fwd'):
+            if name not in ('seg3d_conv3d_k3_mfma_fwd', 'seg3d_conv3d_k3_bf16_fwd', 'seg3d_conv3d_k3_wino_fwd',
+                            'seg3d_conv3d_k3_wino2d_fwd'):
                 return timer._orig(name, *args)
-            wino = name == 'seg3d_conv3d_k3_wino_fwd'
+            wino = name in ('seg3d_conv3d_k3_wino_fwd', 'seg3d_conv3d_k3_wino2d_fwd')
             N, D, H, W, Cin, Cout = args[6:12] if wino else args[7:13]
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             rc = timer._orig(name, *args)
             b.record()
-            ma = WINO_VARIANT if wino else E.query(
+            ma = (WINO2D_VARIANT if '2d' in name else WINO_VARIANT) if wino else E.query(
                 'seg3d_conv3d_k3_bf16_variant' if 'bf16' in name else 'seg3d_conv3d_k3_mfma_variant', N, D, H, W, Cin, Cout)
             timer.records.append(((N, D, H, W, Cin, Cout, ma), a, b, 2 if 'bf16' in name else 4))
             return rc
@@ -130,12 +131,16 @@ class KernelTimer(object):
 
 WINO_VARIANT = 500   # the Winograd F(2,3) kernel (csrc/conv_wino.hip) in the variant column of the launch tables
 WINO_EXECUTED = 2.0 / 3.0   # it executes 4 multiplies per 2 outputs x 3 taps: 2/3 of the algorithmic FLOPs
+WINO2D_VARIANT = 600   # the Winograd F(2x2,3x3) kernel (csrc/conv_wino2d.hip)
+WINO2D_EXECUTED = 4.0 / 9.0   # 16 multiplies per 4 outputs x 9 (ky, kx) taps
 
 
 def variant_kernel_name(v):
     """seg3d_conv3d_k3_mfma_variant code -> kernel symbol as rocprofv3 prints it"""
     if v == WINO_VARIANT:
         return 'conv3d_k3_wino_kernel'
+    if v == WINO2D_VARIANT:
+        return 'conv3d_k3_wino2d_kernel'
     if v >= 400:
         return 'conv3d_k3_mfma2w8_bf16_kernel<{}, {}, true>'.format((v - 400) // 10, v % 10)
     if v >= 300:   # two waves per SIMD, MA row blocks per wave
@@ -152,11 +157,14 @@ def winograd_fields(variant, achieved, peak):
     """`achieved` is priced on ALGORITHMIC FLOPs (2 x 27 x Cin x Cout per output voxel).  The Winograd kernel issues 2/3 of
     them to the matrix cores, so its algorithmic fraction may exceed 1; the fraction of the MFMA peak its issued
     multiply-adds reach is reported beside it."""
-    if variant != WINO_VARIANT:
+    if variant not in (WINO_VARIANT, WINO2D_VARIANT):
         return {}
-    return {'executed_tflops': round(achieved * WINO_EXECUTED, 2), 'frac_executed': round(achieved * WINO_EXECUTED / peak, 4),
-            'flops_note': 'Winograd F(2,3) along x: 4 multiplies per 2 outputs x 3 taps, so the matrix cores execute 2/3 of the '
-                          'algorithmic FLOPs `achieved`/`frac` are priced on; frac_executed = executed FLOPs / peak'}
+    ex = WINO_EXECUTED if variant == WINO_VARIANT else WINO2D_EXECUTED
+    what = ('F(2,3) along x: 4 multiplies per 2 outputs x 3 taps, so the matrix cores execute 2/3' if variant == WINO_VARIANT
+            else 'F(2x2,3x3) over (y, x): 16 multiplies per 4 outputs x 9 taps, so the matrix cores execute 4/9')
+    return {'executed_tflops': round(achieved * ex, 2), 'frac_executed': round(achieved * ex / peak, 4),
+            'flops_note': 'Winograd ' + what + ' of the algorithmic FLOPs `achieved`/`frac` are priced on; '
+                          'frac_executed = executed FLOPs / peak'}
 
 
 def pmc_traffic_gb(kernel_name):

@@ -120,6 +120,19 @@ extern "C" int seg3d_pack_weights_tapmajor(const float* w, float* wp, int A, int
 __device__ __forceinline__ float seg3d_wino_u(float g0, float g1, float g2, int p) {
   return p == 0 ? g0 : p == 1 ? 0.5f * ((g0 + g2) + g1) : p == 2 ? 0.5f * ((g0 + g2) - g1) : g2;
 }
+// Winograd F(2x2, 3x3) over (y, x) (conv_wino2d.hip): T = 48 selects U = G g G^T per kz, t = kz * 16 + py * 4 + px;
+// g = the 27 taps of one (a, b) with stride 1 (flip: read back to front)
+#define SEG3D_WINO2D_T 48
+__device__ __forceinline__ float seg3d_wino2d_u(const float* g, int flip, int t48) {
+  const int kz = t48 >> 4, py = (t48 >> 2) & 3, px = t48 & 3;
+  float r[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int i = (kz * 3 + ky) * 3;
+    r[ky] = seg3d_wino_u(g[flip ? 26 - i : i], g[flip ? 25 - i : i + 1], g[flip ? 24 - i : i + 2], px);
+  }
+  return seg3d_wino_u(r[0], r[1], r[2], py);
+}
 
 // MFMA pack (conv_mfma.hip): wp[bb][ab][t][h][j][r] = W(a = ab*8 + h*4 + r, b = bb*32 + j, t), zero padded.
 // One (bb, ab) chunk = T*2*32*4 floats is exactly the LDS image a workgroup stages per K-chunk, so staging is
@@ -144,6 +157,8 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict_
         const float* g = w + a * sa + b * sb;
         const float g0 = g[flip ? 26 - 3 * t9 : 3 * t9], g1 = g[flip ? 25 - 3 * t9 : 3 * t9 + 1], g2 = g[flip ? 24 - 3 * t9 : 3 * t9 + 2];
         v = seg3d_wino_u(g0, g1, g2, t & 3);
+      } else if (T == SEG3D_WINO2D_T) {
+        v = seg3d_wino2d_u(w + a * sa + b * sb, flip, t);
       } else {
         v = w[a * sa + b * sb + (flip ? T - 1 - t : t)];
       }
@@ -256,8 +271,8 @@ template <> struct Seg3dPackTile<true> {
   static __device__ __forceinline__ void store(float* wp, i64 i, seg3d_bf16 v) { reinterpret_cast<seg3d_bf16*>(wp)[i] = v; }
 };
 
-// WINO (jb.T = 36, fp32 images only): the 27 taps are read as usual, the packed chunk holds the 36 transformed "taps"
-template <int AW, bool BF, int TC, bool WINO = false>
+// WINO (jb.T = 36 / 48, fp32 images only): the 27 taps are read as usual, the packed chunk holds the WINO transformed "taps"
+template <int AW, bool BF, int TC, int WINO = 0>
 __device__ __forceinline__ void pack_mfma_chunk(const Seg3dPackJob& jb, int chunk,
                                                 typename Seg3dPackTile<BF>::type* __restrict__ tile) {
   typedef Seg3dPackTile<BF> TL;
@@ -299,15 +314,19 @@ __device__ __forceinline__ void pack_mfma_chunk(const Seg3dPackJob& jb, int chun
   __syncthreads();
   // packed order inside the chunk: [t][h][j][r]  with a = 4 h + r, b = j
   constexpr int HW = AW / 2;   // channels per half
-  if constexpr (WINO && !BF) {
-    const int n36 = AW * 32 * SEG3D_WINO_T;
-    for (int i = threadIdx.x; i < n36; i += 256) {
-      const int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, t36 = i / (HW * 64);
-      const int t9 = t36 >> 2;
+  if constexpr (WINO != 0 && !BF) {
+    const int nw = AW * 32 * WINO;
+    for (int i = threadIdx.x; i < nw; i += 256) {
+      const int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, tw = i / (HW * 64);
       const float* g = tile + ((HW * h + r) * 32 + j) * 27;
-      const float g0 = g[jb.flip ? 26 - 3 * t9 : 3 * t9], g1 = g[jb.flip ? 25 - 3 * t9 : 3 * t9 + 1],
-                  g2 = g[jb.flip ? 24 - 3 * t9 : 3 * t9 + 2];
-      jb.wp[(i64)chunk * n36 + i] = seg3d_wino_u(g0, g1, g2, t36 & 3);
+      if constexpr (WINO == SEG3D_WINO_T) {
+        const int t9 = tw >> 2;
+        const float g0 = g[jb.flip ? 26 - 3 * t9 : 3 * t9], g1 = g[jb.flip ? 25 - 3 * t9 : 3 * t9 + 1],
+                    g2 = g[jb.flip ? 24 - 3 * t9 : 3 * t9 + 2];
+        jb.wp[(i64)chunk * nw + i] = seg3d_wino_u(g0, g1, g2, tw & 3);
+      } else {
+        jb.wp[(i64)chunk * nw + i] = seg3d_wino2d_u(g, jb.flip, tw);
+      }
     }
     return;
   }
@@ -339,7 +358,8 @@ __device__ __forceinline__ void pack_mfma_multi_body(const Seg3dPackJob* __restr
   const Seg3dPackJob jb = jobs[sjob];
   const int chunk = (int)((i64)blockIdx.x - jb.first_block);   // = bb * AB + ab
   if (jb.T == 27) pack_mfma_chunk<AW, BF, 27>(jb, chunk, tile);
-  else if (jb.T == SEG3D_WINO_T) pack_mfma_chunk<AW, BF, 27, true>(jb, chunk, tile);
+  else if (jb.T == SEG3D_WINO_T) pack_mfma_chunk<AW, BF, 27, SEG3D_WINO_T>(jb, chunk, tile);
+  else if (jb.T == SEG3D_WINO2D_T) pack_mfma_chunk<AW, BF, 27, SEG3D_WINO2D_T>(jb, chunk, tile);
   else if (jb.T == 8) pack_mfma_chunk<AW, BF, 8>(jb, chunk, tile);
   else pack_mfma_chunk<AW, BF, 0>(jb, chunk, tile);
 }

@@ -25,6 +25,7 @@ _KINDS = {'k3': (3, 1, 27, False), 'k2s2': (2, 2, 8, False), 'k1': (1, 1, 1, Fal
 FORCE_DIRECT = False
 # C -> C 3x3x3 forward / data-gradient at the big levels: Winograd F(2, 3) along x (False: the direct implicit GEMM everywhere)
 WINOGRAD = True
+WINOGRAD2D = True    # F(2x2, 3x3) over (y, x) where it is preferred, else F(2, 3) along x
 
 # bf16 mode (BASELINE config 5): activations between fused units and the gradients handed to the conv kernels are bf16,
 # packed k3 weights are bf16 (fp32 master weights), accumulation / conv outputs / GroupNorm statistics / losses fp32.
@@ -278,6 +279,15 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
                    W_, A, B, CO, E.stream_ptr())
             return y, stats
         xn = _to_f32(xn)       # shapes outside the bf16 kernels (not produced by vnet / vbnet): widen and continue
+    if _use_mfma(A, B) and WINOGRAD and WINOGRAD2D and E.query('seg3d_conv3d_k3_wino2d_preferred', N, D, H, W_, A, B):
+        # the big levels: Winograd F(2x2, 3x3) over (y, x), 4/9 of the fp32 MFMAs (csrc/conv_wino2d.hip); T = 48 image
+        wp = _pack_mfma(w, A, B, 48, sa, sb, flip)
+        stats = None
+        if want_stats:
+            stats = _empty((N, E.query('seg3d_conv3d_k3_wino2d_stats_count', N, D, H, W_, A, B), 2), xn)
+        E.call('seg3d_conv3d_k3_wino2d_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(addend), E.ptr(y), E.ptr(stats), N, D, H,
+               W_, A, B, E.stream_ptr())
+        return y, stats
     if _use_mfma(A, B) and WINOGRAD and E.query('seg3d_conv3d_k3_wino_preferred', N, D, H, W_, A, B):
         # the big levels: Winograd F(2, 3) along x, 2/3 of the fp32 MFMAs (csrc/conv_wino.hip); T = 36 = transformed image
         wp = _pack_mfma(w, A, B, 36, sa, sb, flip)

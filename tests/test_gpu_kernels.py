@@ -130,16 +130,19 @@ def test_conv3d_k3_bench_variants_full_size(hip_device, shape, variant, winograd
 @pytest.mark.parametrize('shape', [(1, 8, 32, 16, 24, 32), (2, 32, 32, 8, 16, 48), (1, 64, 96, 16, 16, 16), (3, 16, 64, 8, 8, 64),
                                    (1, 128, 128, 8, 16, 16)])
 @pytest.mark.parametrize('flip', [0, 1])
-def test_conv3d_k3_winograd(hip_device, shape, flip):
-    """Winograd F(2, 3) along x (csrc/conv_wino.hip) through the C ABI against the float64 convolution: several K chunks and
+@pytest.mark.parametrize('form', ['wino', 'wino2d'])
+def test_conv3d_k3_winograd(hip_device, shape, flip, form):
+    """Winograd F(2, 3) along x (csrc/conv_wino.hip, T = 36 image) and F(2x2, 3x3) over (y, x) (csrc/conv_wino2d.hip, T = 48
+    image) through the C ABI against the float64 convolution: several K chunks and
     column blocks, more items than workgroups and fewer, flipped taps (the data-gradient form), fused addend, no-bias /
     no-stats calls, per-wave statistics of its own output; and against the direct MFMA kernel on the same input"""
     from segmentation3d import _ops, _engine as E
     N, Cin, Cout, D, H, W = shape
-    assert E.query('seg3d_conv3d_k3_wino_supported', N, D, H, W, Cin, Cout) == 1
-    assert E.query('seg3d_conv3d_k3_wino_supported', N, D, H, W + 4, Cin, Cout) == 0       # not whole tiles
-    assert E.query('seg3d_conv3d_k3_wino_supported', N, D, H, W, Cin + 4, Cout) == 0
-    assert E.query('seg3d_conv3d_k3_wino_preferred', 1, 8, 8, 8, Cin, Cout) == 0           # too few items: split-K kernel
+    T = 36 if form == 'wino' else 48
+    assert E.query('seg3d_conv3d_k3_{}_supported'.format(form), N, D, H, W, Cin, Cout) == 1
+    assert E.query('seg3d_conv3d_k3_{}_supported'.format(form), N, D, H, W + 4, Cin, Cout) == 0       # not whole tiles
+    assert E.query('seg3d_conv3d_k3_{}_supported'.format(form), N, D, H, W, Cin + 4, Cout) == 0
+    assert E.query('seg3d_conv3d_k3_{}_preferred'.format(form), 1, 8, 8, 8, Cin, Cout) == 0           # too few items: split-K kernel
     x = _t(31, 'wx', (N, Cin, D, H, W))
     w = _t(32, 'ww', (Cout, Cin, 3, 3, 3), std=(2.0 / (Cin * 27)) ** 0.5)
     b = _t(33, 'wb', (Cout,), std=0.1)
@@ -147,11 +150,11 @@ def test_conv3d_k3_winograd(hip_device, shape, flip):
     xn = _ops.to_ndhwc(x.to(hip_device))
     an = _ops.to_ndhwc(ad.to(hip_device))
     wd, bd = w.to(hip_device), b.to(hip_device)
-    wp = torch.full((E.query('seg3d_packed_mfma_floats', Cin, Cout, 36),), float('nan'), device=hip_device)
-    E.call('seg3d_pack_weights_mfma', E.ptr(wd), E.ptr(wp), Cin, Cout, 36, 27, Cin * 27, flip, E.stream_ptr())
+    wp = torch.full((E.query('seg3d_packed_mfma_floats', Cin, Cout, T),), float('nan'), device=hip_device)
+    E.call('seg3d_pack_weights_mfma', E.ptr(wd), E.ptr(wp), Cin, Cout, T, 27, Cin * 27, flip, E.stream_ptr())
     y = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
-    st = torch.full((N, E.query('seg3d_conv3d_k3_wino_stats_count', N, D, H, W, Cin, Cout), 2), float('nan'), device=hip_device)
-    E.call('seg3d_conv3d_k3_wino_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bd), E.ptr(an), E.ptr(y), E.ptr(st), N, D, H, W, Cin, Cout,
+    st = torch.full((N, E.query('seg3d_conv3d_k3_{}_stats_count'.format(form), N, D, H, W, Cin, Cout), 2), float('nan'), device=hip_device)
+    E.call('seg3d_conv3d_k3_{}_fwd'.format(form), E.ptr(xn), E.ptr(wp), E.ptr(bd), E.ptr(an), E.ptr(y), E.ptr(st), N, D, H, W, Cin, Cout,
            E.stream_ptr())
     wref = w.flip(2, 3, 4) if flip else w
     ref = F.conv3d(x.double(), wref.double(), b.double(), padding=1) + ad.double()
@@ -167,14 +170,14 @@ def test_conv3d_k3_winograd(hip_device, shape, flip):
     E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(xn), E.ptr(wp27), E.ptr(bd), E.ptr(an), E.ptr(yd), None, E.ptr(ws), N, D, H, W, Cin,
            Cout, E.stream_ptr())
     err_direct = float((_ops.from_ndhwc(yd).double().cpu() - ref).abs().max())
-    report('winograd_{}_flip{}'.format('_'.join(map(str, shape)), flip), max_abs_err=err, direct_kernel_err=err_direct,
+    report('{}_{}_flip{}'.format(form, '_'.join(map(str, shape)), flip), max_abs_err=err, direct_kernel_err=err_direct,
            out_scale=scale)
     assert err < 1e-5 * scale and err < 4.0 * err_direct + 1e-6 * scale, (err, err_direct, scale)
     s = st.double().sum(1).cpu()
     rr = got.reshape(N, -1)
     assert float(((s[:, 0] - rr.sum(1)).abs() / rr.abs().sum(1)).max()) < 1e-5 and rel_err(s[:, 1], (rr * rr).sum(1)) < 1e-5
     y2 = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
-    E.call('seg3d_conv3d_k3_wino_fwd', E.ptr(xn), E.ptr(wp), None, None, E.ptr(y2), None, N, D, H, W, Cin, Cout, E.stream_ptr())
+    E.call('seg3d_conv3d_k3_{}_fwd'.format(form), E.ptr(xn), E.ptr(wp), None, None, E.ptr(y2), None, N, D, H, W, Cin, Cout, E.stream_ptr())
     assert float((y2 + bd + an - y).abs().max()) < 2e-6 * scale
 
 

@@ -36,6 +36,12 @@ def main():
             st2 = torch.empty(N, E.query('seg3d_conv3d_k3_wino_stats_count', N, D, H, W, C, C), 2, device=dev)
             ms2 = timed(lambda: E.call('seg3d_conv3d_k3_wino_fwd', E.ptr(x), E.ptr(wq), E.ptr(b), None, E.ptr(y), E.ptr(st2), N, D, H, W, C, C, E.stream_ptr()), iters)
             line += '   winograd {:8.3f} ms {:6.1f} TF (algorithmic)  x{:.2f}'.format(ms2, fl / ms2 / 1e9, ms / ms2)
+        if E.query('seg3d_conv3d_k3_wino2d_supported', N, D, H, W, C, C):
+            wq2 = torch.empty(E.query('seg3d_packed_mfma_floats', C, C, 48), device=dev)
+            E.call('seg3d_pack_weights_mfma', E.ptr(w), E.ptr(wq2), C, C, 48, 27, C * 27, 0, E.stream_ptr())
+            st3 = torch.empty(N, E.query('seg3d_conv3d_k3_wino2d_stats_count', N, D, H, W, C, C), 2, device=dev)
+            ms3 = timed(lambda: E.call('seg3d_conv3d_k3_wino2d_fwd', E.ptr(x), E.ptr(wq2), E.ptr(b), None, E.ptr(y), E.ptr(st3), N, D, H, W, C, C, E.stream_ptr()), iters)
+            line += '   winograd2d {:8.3f} ms {:6.1f} TF (algorithmic)  x{:.2f}'.format(ms3, fl / ms3 / 1e9, ms / ms3)
         print(line, flush=True)
         # weight gradient: 27-tap kernel vs Winograd F(3,2)
         dyv = torch.randn(N, D, H, W, C, device=dev)

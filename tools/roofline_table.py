@@ -19,7 +19,9 @@ else:
 variant_flops = {}
 for r in shapes:
     N, D, H, W, Ci, Co, v = r['N_D_H_W_Cin_Cout_variant']
-    if v == 500:     # Winograd F(2,3): TFLOP/s below are ALGORITHMIC (the matrix cores execute 2/3 of them)
+    if v == 600:     # Winograd F(2x2,3x3): TFLOP/s below are ALGORITHMIC (the matrix cores execute 4/9 of them)
+        name = 'conv3d_k3_wino2d_kernel'
+    elif v == 500:   # Winograd F(2,3): algorithmic as well (2/3 executed)
         name = 'conv3d_k3_wino_kernel'
     elif v >= 400:
         name = 'conv3d_k3_mfma2w8_bf16_kernel<{}, {}, true>'.format((v - 400) // 10, v % 10)

@@ -129,6 +129,14 @@ int seg3d_conv3d_k3_wino_wgrad_supported(int N, int D, int H, int W, int Cin, in
 long long seg3d_conv3d_k3_wino_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_wino_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H, int W,
                                int Cin, int Cout, int accumulate, void* stream);
+/* Winograd F(3x3, 2x2) over (y, x) form of the same weight gradient (csrc/conv_wino2d.hip): 48 accumulators [3 kz][16 points]
+ * instead of 27 taps at one output QUAD per K slot = 4/9 of the fp32 MFMAs of the 27-tap kernel; same arguments, shapes and
+ * layouts as seg3d_conv3d_k3_wino_wgrad */
+int seg3d_conv3d_k3_wino2d_wgrad_supported(int N, int D, int H, int W, int Cin, int Cout);
+int seg3d_conv3d_k3_wino2d_wgrad_preferred(int N, int D, int H, int W, int Cin, int Cout);   /* else the F(3, 2) form */
+long long seg3d_conv3d_k3_wino2d_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+int seg3d_conv3d_k3_wino2d_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H, int W,
+                                 int Cin, int Cout, int accumulate, void* stream);
 long long seg3d_conv3d_k3_bf16_stats_count(int N, int D, int H, int W, int Cin, int Cout);
 long long seg3d_conv3d_k3_bf16_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
 /* 200 + 10*MA + NB = conv3d_k3_mfma2_bf16_kernel<MA, NB>; 0 = shape not supported */

@@ -26,6 +26,7 @@
 // levels (12^3, 6^3: split-K territory) stay on conv_mfma.hip.
 #include "seg3d_common.h"
 #include "seg3d_hip.h"
+#include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -51,6 +52,17 @@ __device__ __attribute__((aligned(16))) float wn_zero16[4];   // DMA source for 
 __device__ __forceinline__ void wn_glds16(const float* src, float* lds_dst_wave_uniform) {
   __builtin_amdgcn_global_load_lds(src, lds_dst_wave_uniform, 16, 0, 0);
 }
+// The same LDS-DMA as inline assembly, for kernels with ONE wave per SIMD: while a builtin DMA is outstanding hipcc's
+// wait-count pass treats it as a pending FLAT access and turns every LDS wait of the loop into lgkmcnt(0)
+// (tools/ubench/waitcnt_dma.hip), a full drain of the operand reads issued for the following steps.  The compiler does not
+// see this load: the kernel waits for it itself (wn_dma_wait) before the barrier that publishes the data, and uses M0 for
+// nothing else.
+typedef __attribute__((address_space(3))) float wn_lds_float;
+__device__ __forceinline__ void wn_glds16_asm(const float* src, float* lds_dst_wave_uniform) {
+  const unsigned off = (unsigned)(uintptr_t)(wn_lds_float*)lds_dst_wave_uniform;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(off) : "memory");
+}
+__device__ __forceinline__ void wn_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __global__ __launch_bounds__(512, 1) void conv3d_k3_wino_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                  const float* __restrict__ bias, float* __restrict__ y,
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino_kernel(const floa
     if (g < GX) dst = rawx + (wave + 4 * g < XPC ? wave + 4 * g : XPC - 1) * 256;
     else dst = ydst + (wave + 4 * (g - GX) < YPC ? wave + 4 * (g - GX) : YPC - 1) * 256;
     const float* src = (pflag[g] & faces) ? wn_zero16 : base + prel[g];
-    wn_glds16(src, dst);
+    wn_glds16_asm(src, dst);
   };
   auto transform = [&]() {   // RAW x -> T[p][row][pair][32]
     constexpr int ITEMS = NRH * PX * 8;
@@ -500,6 +512,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino_kernel(const floa
     const int faces = tile_faces();
 #pragma unroll
     for (int g = 0; g < NG; ++g) issue_piece(g, rawy, x + origin * Cin, dy + origin * Cout, faces);
+    wn_dma_wait();
     __syncthreads();
     transform();
     __syncthreads();
@@ -541,10 +554,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino_kernel(const floa
         g1b = yb[(k + 1) * 128 + 32];
       }
       if (k < NG) issue_piece(k, ynxt, xbase, ybase, faces);
+      __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from sinking the reads above down to their first use
 #pragma unroll
       for (int j = 0; j < 9; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b, acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();     // own DMAs landed (vmcnt(0)), everyone done with T
+    wn_dma_wait();       // own DMAs landed
+    __syncthreads();     // everyone done with T
     if (more) {
       transform();       // the next tile's RAW x -> T
       __syncthreads();

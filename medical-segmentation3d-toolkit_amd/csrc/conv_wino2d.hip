@@ -354,3 +354,376 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_fwd");
   return SEG3D_OK;
 }
+
+// ================================================================================================================
+// Weight gradient of the same layers with Winograd F(3x3, 2x2) over (y, x) (conv3d_k3_wgrad_wino2d_kernel), the transpose
+// of the kernel above.  For an output QUAD (g = dy at (y0..y0+1, x0..x0+1) of plane z) and the 4 x 4 input patch d of plane
+// z + kz - 1 the nine (ky, kx) taps of one kz are a 3 x 3-output correlation with a 2 x 2 filter: 16 rank-1 updates
+// instead of 36,
+//     V = B^T d B  (as above)        E = G' g G'^T,  G' = [1 0; 1 1; 1 -1; 0 1]  (the 1/2 factors move to the output)
+//     M_p = sum_quads V_p (x) E_p    dW[kz] = A'^T M A',  A'^T = [1 1/2 1/2 0; 0 1/2 -1/2 0; 0 1/2 1/2 -1]
+// i.e. 48 accumulators [3 kz][16 points] of [32 ci][32 co] instead of 27 taps, fed one QUAD per K slot: 4/9 of the MFMAs
+// of conv3d_k3_wgrad2_kernel (2/3 of conv3d_k3_wgrad_wino_kernel's).
+// Structure = conv3d_k3_wgrad_wino_kernel: one persistent workgroup per CU owns a 32 x 32 (ci, co) block pair and one slab
+// of 4 x 4 x 4 tiles; wave w owns the point row py = w: 12 accumulators [kz][px] in registers across all tiles; the next
+// tile's RAW x halo tile (6^3 voxels) and dy tile arrive by (inline-assembly) LDS-DMA behind the first K steps, branch-free;
+// between two tiles 192 threads transform RAW x into T[p][z][quad][32 ci] (two barriers per tile); E is formed from the raw
+// dy quad in registers (4 FMAs / adds per 12 MFMAs).  Partial slabs [slab][pair][48][32][32] are reduced in fixed order,
+// and turned into the 27 taps, by conv3d_k3_wgrad_wino2d_reduce_kernel (bitwise reproducible).
+// A tile is only 96 MFMAs per wave (2.6 us): too short to cover a DMA issued in the same tile, so tiles are fetched TWO
+// ahead (RAW x double-, dy triple-buffered; the wait before the barrier is vmcnt(pieces of one tile), not 0).
+// LDS: 2 x 27 KB RAW x + T 48 KB + 3 x 8 KB dy = 126 KB.
+// ================================================================================================================
+__device__ __forceinline__ int w2_mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+#define G2_XV 216                                 // halo voxels of the x tile (6^3)
+#define G2_XS (G2_XV * 32)                        // floats of RAW x
+#define G2_TS (16 * 24 * 32)                      // floats of T: [16 p][6 z x 4 quads][32 ci]
+#define G2_YS (64 * 32)                           // floats of one dy tile
+#define G2_LDS_FLOATS (2 * G2_XS + G2_TS + 3 * G2_YS)   // RAW x twice, T, three dy tiles: 129 KB
+#define G2_XPC 27                                 // 1-KiB DMA pieces of RAW x
+#define G2_YPC 8
+#define G2_GX 7                                   // piece groups per wave: x
+#define G2_GY 2                                   // ... dy
+#define G2_NG (G2_GX + G2_GY)
+#define G2_KS 8                                   // K steps per tile: 16 quads, two per step
+
+__global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                         float* __restrict__ part, int N, int D, int H, int W,
+                                                                         int Cin, int Cout, int ntz, int nty, int ntx, int ntiles,
+                                                                         int slabs, int COB32) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* rawx = lds;                        // [2][216][32]
+  float* timg = lds + 2 * G2_XS;
+  float* rawy = lds + 2 * G2_XS + G2_TS;    // [3][64][32]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = point row py
+  const int li = lane & 31, lh = lane >> 5;
+  const int slab = blockIdx.x % slabs;
+  const int pg = blockIdx.x / slabs;                   // (ci block, co block)
+  const int cib = pg / COB32, cob = pg % COB32;
+  const int ci0 = cib * 32, co0 = cob * 32;
+  const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz;
+  auto fdiv = [](int v, float r) { return (int)(((float)v + 0.5f) * r); };  // exact for the small ranges used here
+  // row combination of the dy quad for py = wave:  r_j = g0j' + e1 g1j   (py 0: g0j, 1: g0j + g1j, 2: g0j - g1j, 3: g1j --
+  // there g0j' is read one row down and e1 = 0)
+  const float e1 = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
+  const int g0off = wave == 3 ? 4 * 32 : 0;            // one y row of the 4 x 4 x 4 dy tile = 4 voxels
+
+  f32x16 acc[12];   // [kz][px]
+#pragma unroll
+  for (int j = 0; j < 12; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // DMA pieces of this wave (as conv3d_k3_wgrad_wino_kernel): group g < GX is x piece min(wave + 4 g, XPC - 1), group
+  // GX + g' is dy piece min(wave + 4 g', YPC - 1); lane -> voxel 8 p + (lane >> 3), channels 4 (lane & 7)..+3
+  const int lv = lane >> 3, lq = lane & 7;
+  int prel[G2_NG], pflag[G2_NG];
+#pragma unroll
+  for (int g = 0; g < G2_NG; ++g) {
+    if (g < G2_GX) {
+      const int p = wave + 4 * g < G2_XPC ? wave + 4 * g : G2_XPC - 1;
+      const int v = p * 8 + lv;
+      const int t = fdiv(v, 1.0f / 6.0f);
+      const int hx = v - t * 6;
+      const int hz = fdiv(t, 1.0f / 6.0f);
+      const int hy = t - hz * 6;
+      prel[g] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + ci0 + 4 * lq;
+      pflag[g] = (hz == 0 ? 1 : 0) | (hz == 5 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == 5 ? 8 : 0) | (hx == 0 ? 16 : 0) |
+                 (hx == 5 ? 32 : 0) | (ci0 + 4 * lq < Cin ? 0 : 64);
+    } else {
+      const int p = wave + 4 * (g - G2_GX) < G2_YPC ? wave + 4 * (g - G2_GX) : G2_YPC - 1;
+      const int v = p * 8 + lv;
+      const int co = co0 + 4 * lq;
+      prel[g] = (((v >> 4) * H + ((v >> 2) & 3)) * W + (v & 3)) * Cout + co;
+      pflag[g] = co < Cout ? 0 : 64;
+    }
+  }
+  int tn = 0, tz0 = 0, ty0 = 0, tx0 = 0;  // origin of the tile being fetched
+  auto set_tile = [&](int tile) {
+    int b = tile;
+    int q = fdiv(b, rNTX);
+    const int tix = b - q * ntx;
+    b = q;
+    q = fdiv(b, rNTY);
+    const int tiy = b - q * nty;
+    b = q;
+    q = fdiv(b, rNTZ);
+    const int tiz = b - q * ntz;
+    tn = q;
+    tz0 = tiz * 4, ty0 = tiy * 4, tx0 = tix * 4;
+  };
+  auto issue_piece = [&](int g, float* xdst, float* ydst, const float* xbase, const float* ybase, int faces) {
+    const float* base = g < G2_GX ? xbase : ybase;            // compile-time choice (g is an unrolled loop index)
+    float* dst;
+    if (g < G2_GX) dst = xdst + (wave + 4 * g < G2_XPC ? wave + 4 * g : G2_XPC - 1) * 256;
+    else dst = ydst + (wave + 4 * (g - G2_GX) < G2_YPC ? wave + 4 * (g - G2_GX) : G2_YPC - 1) * 256;
+    const float* src = (pflag[g] & faces) ? w2_zero16 : base + prel[g];
+    w2_glds16(src, dst);
+  };
+  // transform item of this thread (tid < 192): (z, quad, channel quad)
+  const int t_c4 = tid & 7, t_q = (tid >> 3) & 3, t_z = tid >> 5;
+  const int t_src = ((t_z * 6 + 2 * (t_q >> 1)) * 6 + 2 * (t_q & 1)) * 32 + 4 * t_c4;
+  const int t_dst = (t_z * 4 + t_q) * 32 + 4 * t_c4;
+  auto transform = [&](const float* rx) {   // RAW x -> T: V = B^T d B per (z, quad), 16 points
+    if (tid < 192) {
+      f32x4 dx[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* s = rx + t_src + r * (6 * 32);
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(s);
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(s + 32);
+        const f32x4 d2 = *reinterpret_cast<const f32x4*>(s + 64);
+        const f32x4 d3 = *reinterpret_cast<const f32x4*>(s + 96);
+        dx[r][0] = d0 - d2;
+        dx[r][1] = d1 + d2;
+        dx[r][2] = d2 - d1;
+        dx[r][3] = d1 - d3;
+      }
+      float* dst = timg + t_dst;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        *reinterpret_cast<f32x4*>(dst + (0 * 4 + px) * (24 * 32)) = dx[0][px] - dx[2][px];
+        *reinterpret_cast<f32x4*>(dst + (1 * 4 + px) * (24 * 32)) = dx[1][px] + dx[2][px];
+        *reinterpret_cast<f32x4*>(dst + (2 * 4 + px) * (24 * 32)) = dx[2][px] - dx[1][px];
+        *reinterpret_cast<f32x4*>(dst + (3 * 4 + px) * (24 * 32)) = dx[1][px] - dx[3][px];
+      }
+    }
+  };
+  auto tile_faces = [&]() {
+    return 64 | (tz0 == 0 ? 1 : 0) | (tz0 + 4 >= D ? 2 : 0) | (ty0 == 0 ? 4 : 0) | (ty0 + 4 >= H ? 8 : 0) |
+           (tx0 == 0 ? 16 : 0) | (tx0 + 4 >= W ? 32 : 0);
+  };
+
+  // tile walk: XCD-contiguous when the slab count allows (as the forward kernels)
+  int tile = slab, tstride = slabs, tlimit = ntiles;
+  if ((slabs & 7) == 0) {
+    const int per_xcd = (ntiles + 7) >> 3, xcd = slab & 7;
+    tile = xcd * per_xcd + (slab >> 3);
+    tstride = slabs >> 3;
+    tlimit = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+  }
+  auto fetch = [&](int t, float* xdst, float* ydst) {   // all pieces of tile t at once (prologue)
+    set_tile(t);
+    const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
+    const int faces = tile_faces();
+#pragma unroll
+    for (int g = 0; g < G2_NG; ++g) issue_piece(g, xdst, ydst, x + origin * Cin, dy + origin * Cout, faces);
+  };
+  int xi = 0, yi = 0;   // buffers of the current tile: RAW x (already transformed) xi, dy yi
+  if (tile < tlimit) {
+    fetch(tile, rawx, rawy);
+    fetch(tile + tstride < tlimit ? tile + tstride : tile, rawx + G2_XS, rawy + G2_YS);
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G2_NG) : "memory");   // the first tile landed, the second may be in flight
+    __syncthreads();
+    transform(rawx);
+    __syncthreads();
+  }
+  for (; tile < tlimit; tile += tstride) {
+    const float* ycur = rawy + yi * G2_YS;
+    const int y2 = yi == 0 ? 2 : yi - 1;                 // (yi + 2) % 3
+    float* ynxt2 = rawy + y2 * G2_YS;                    // dy buffer of the tile after next
+    float* xnxt2 = rawx + xi * G2_XS;                    // RAW x of the current tile is dead (transformed): reuse it
+    const bool more = tile + tstride < tlimit;
+    // the tile after next -- past the end: this tile once more, into idle buffers (keeps the loop and the DMA count uniform)
+    set_tile(tile + 2 * tstride < tlimit ? tile + 2 * tstride : tile);
+    const int faces = tile_faces();
+    const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
+    const float* xbase = x + origin * Cin;
+    const float* ybase = dy + origin * Cout;
+    // K step k: quads 2k (lane half 0) and 2k + 1 (half 1) = (z, qy) = (k >> 1, k & 1), qx = lane half
+    const float* ta = timg + (wave * 4) * (24 * 32) + lane;        // + (px * 24 + (z + kz) * 4 + 2 qy) * 32
+    const float* yb = ycur + lh * 64 + li;                         // + ((z * 4 + 2 qy) * 4) * 32; j: + 32, i: + 128
+    auto aoff = [](int k, int kz, int px) { return (px * 24 + ((k >> 1) + kz) * 4 + 2 * (k & 1)) * 32; };
+    auto yoff = [](int k) { return (((k >> 1) * 4 + 2 * (k & 1)) * 4) * 32; };
+    float a1[12], g00, g01, g10, g11;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) a1[j] = ta[aoff(0, j >> 2, j & 3)];
+    g00 = yb[yoff(0) + g0off];
+    g01 = yb[yoff(0) + g0off + 32];
+    g10 = yb[yoff(0) + 128];
+    g11 = yb[yoff(0) + 128 + 32];
+#pragma unroll
+    for (int k = 0; k < G2_KS; ++k) {
+      float a[12], e[4];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) a[j] = a1[j];
+      const float r0 = fmaf(e1, g10, g00), r1 = fmaf(e1, g11, g01);
+      e[0] = r0;
+      e[1] = r0 + r1;
+      e[2] = r0 - r1;
+      e[3] = r1;
+      if (k + 1 < G2_KS) {   // operands of step k + 1 are read while step k is multiplied
+#pragma unroll
+        for (int j = 0; j < 12; ++j) a1[j] = ta[aoff(k + 1, j >> 2, j & 3)];
+        g00 = yb[yoff(k + 1) + g0off];
+        g01 = yb[yoff(k + 1) + g0off + 32];
+        g10 = yb[yoff(k + 1) + 128];
+        g11 = yb[yoff(k + 1) + 128 + 32];
+      }
+#pragma unroll
+      for (int g = 0; g < G2_NG; ++g)
+        if (g % G2_KS == k) issue_piece(g, xnxt2, ynxt2, xbase, ybase, faces);
+      __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from sinking the reads above down to their first use
+#pragma unroll
+      for (int j = 0; j < 12; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], e[j & 3], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G2_NG) : "memory");   // the NEXT tile landed (fetched one tile ago)
+    __syncthreads();     // everyone done with T
+    xi ^= 1;
+    yi = yi == 2 ? 0 : yi + 1;
+    if (more) {
+      transform(rawx + xi * G2_XS);   // the next tile's RAW x -> T
+      __syncthreads();
+    }
+  }
+  w2_dma_wait();   // nothing in flight when the workgroup's LDS is released
+
+  // part[slab][pair = cib * COB32 + cob][kz * 16 + py * 4 + px][ci row][co col]
+  float* dst = part + ((i64)slab * (COB32 * ((Cin + 31) / 32)) + cib * COB32 + cob) * 48 * 1024;
+#pragma unroll
+  for (int j = 0; j < 12; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      dst[((j >> 2) * 16 + wave * 4 + (j & 3)) * 1024 + w2_mfma_row(r, lh) * 32 + li] = acc[j][r];
+}
+
+// dw[a*sa + b*sb + kz*9 + ky*3 + kx] from  M[py][px] = sum_slab part[slab][a/32][b/32][kz*16 + py*4 + px][a%32][b%32]:
+//   dW[kz] = A'^T M A',  A'^T = [1 1/2 1/2 0; 0 1/2 -1/2 0; 0 1/2 1/2 -1].
+// A lane owns four consecutive b of one (pair, kz, a); the G waves of a workgroup take the slabs k = g, g + G, ..; partial
+// sums are combined through LDS in a fixed order.
+template <int G>
+__global__ __launch_bounds__(64 * G) void conv3d_k3_wgrad_wino2d_reduce_kernel(const float* __restrict__ part,
+                                                                                 float* __restrict__ dw, int slabs, int A, int B,
+                                                                                 int BB32, int npairs, i64 sa, i64 sb,
+                                                                                 int accumulate) {
+  __shared__ f32x4 red[G * 64 * 16];
+  const i64 totalq = (i64)npairs * 3 * 256;                     // (pair, kz, a, b quad)
+  const i64 qidx = (i64)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  f32x4 s[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) s[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const i64 slabq = (i64)npairs * 48 * 256;                     // float4 quads per slab
+  if (qidx < totalq) {
+    const i64 r3 = qidx >> 8;                                   // pair * 3 + kz
+    const f32x4* p0 = reinterpret_cast<const f32x4*>(part) + r3 * 16 * 256 + (qidx & 255);
+    for (int k = g; k < slabs; k += G) {
+      const f32x4* q = p0 + (i64)k * slabq;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) s[p] += q[p * 256];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 16; ++p) red[(p * G + g) * 64 + (threadIdx.x & 63)] = s[p];
+  __syncthreads();
+  if (g == 0 && qidx < totalq) {
+#pragma unroll
+    for (int j = 1; j < G; ++j)
+#pragma unroll
+      for (int p = 0; p < 16; ++p) s[p] += red[(p * G + j) * 64 + threadIdx.x];
+    // rows (py -> ky), then columns (px -> kx)
+    f32x4 rw[3][4];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const f32x4 hs = (s[4 + px] + s[8 + px]) * 0.5f, hd = (s[4 + px] - s[8 + px]) * 0.5f;
+      rw[0][px] = s[px] + hs;
+      rw[1][px] = hd;
+      rw[2][px] = hs - s[12 + px];
+    }
+    f32x4 wv[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const f32x4 hs = (rw[ky][1] + rw[ky][2]) * 0.5f, hd = (rw[ky][1] - rw[ky][2]) * 0.5f;
+      wv[ky][0] = rw[ky][0] + hs;
+      wv[ky][1] = hd;
+      wv[ky][2] = hs - rw[ky][3];
+    }
+    const int b32 = (int)((qidx & 7) * 4), a32 = (int)((qidx >> 3) & 31);
+    const i64 r3 = qidx >> 8;
+    const int kz = (int)(r3 % 3);
+    const int pair = (int)(r3 / 3);
+    const int a = (pair / BB32) * 32 + a32, b = (pair % BB32) * 32 + b32;
+    if (a < A) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (b + j < B) {
+          float* d = dw + a * sa + (b + j) * sb + kz * 9;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) d[t] = accumulate ? d[t] + wv[t / 3][t % 3][j] : wv[t / 3][t % 3][j];
+        }
+    }
+  }
+}
+
+static int g2_slabs(int N, int D, int H, int W, int Cin, int Cout) {
+  const i64 ntiles = (i64)N * (D / 4) * (H / 4) * (W / 4);
+  const int npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
+  i64 slabs = 256 / npairs;  // one resident workgroup per CU over the whole grid
+  if (slabs > (ntiles + 1) / 2) slabs = (ntiles + 1) / 2;  // small levels: >= 2 tiles per workgroup
+  if (slabs < 1) slabs = 1;
+  return (int)slabs;
+}
+
+// shapes the F(3x3, 2x2) weight gradient takes: whole 4 x 4 x 4 tiles, channels in fours
+extern "C" int seg3d_conv3d_k3_wino2d_wgrad_supported(int N, int D, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  if ((D % 4) || (H % 4) || (W % 4) || (Cin & 3) || (Cout & 3)) return 0;
+  if ((long long)N * D * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;
+  if ((long long)N * (D / 4) * (H / 4) * (W / 4) >= SEG3D_FDIV_MAX) return 0;
+  return 1;
+}
+
+// ... and where it is the faster choice (else F(3, 2) along x, conv_wino.hip): enough tiles per workgroup to amortise its
+// 48 partial accumulators, or few slabs to reduce
+extern "C" int seg3d_conv3d_k3_wino2d_wgrad_preferred(int N, int D, int H, int W, int Cin, int Cout) {
+  if (!seg3d_conv3d_k3_wino2d_wgrad_supported(N, D, H, W, Cin, Cout)) return 0;
+  const int slabs = g2_slabs(N, D, H, W, Cin, Cout);
+  const long long ntiles = (long long)N * (D / 4) * (H / 4) * (W / 4);
+  return ntiles >= 40ll * slabs || (slabs <= 8 && ntiles >= 16ll * slabs);
+}
+
+extern "C" long long seg3d_conv3d_k3_wino2d_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
+  const int npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
+  return (long long)g2_slabs(N, D, H, W, Cin, Cout) * npairs * 48 * 1024;
+}
+
+// x [N][D][H][W][Cin], dy [N][D][H][W][Cout]; dw in the reference Conv3d layout [Cout][Cin][3][3][3] (written, or added to
+// when accumulate != 0); workspace = seg3d_conv3d_k3_wino2d_wgrad_workspace_floats floats
+extern "C" int seg3d_conv3d_k3_wino2d_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int D, int H,
+                                            int W, int Cin, int Cout, int accumulate, void* stream) {
+  SEG3D_REQUIRE(x && dy && dw && workspace, "seg3d_conv3d_k3_wino2d_wgrad: null pointer");
+  SEG3D_REQUIRE(seg3d_conv3d_k3_wino2d_wgrad_supported(N, D, H, W, Cin, Cout),
+                "seg3d_conv3d_k3_wino2d_wgrad: shape not supported (whole 4^3 tiles, Cin %% 4 == 0, Cout %% 4 == 0)");
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_wino2d_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) {
+      seg3d_set_error("conv3d_k3_wgrad_wino2d: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SEG3D_ERR_LAUNCH;
+    }
+    configured = true;
+  }
+  const int slabs = g2_slabs(N, D, H, W, Cin, Cout);
+  const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32, npairs = CIB32 * COB32;
+  const int ntz = D / 4, nty = H / 4, ntx = W / 4;
+  const int ntiles = N * ntz * nty * ntx;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_kernel, dim3((unsigned)(slabs * npairs)), dim3(256), (size_t)G2_LDS_FLOATS * 4, s, x,
+                     dy, workspace, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, COB32);
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_wgrad");
+  const i64 totalq = (i64)npairs * 3 * 256;
+  const unsigned grid = (unsigned)((totalq + 63) / 64);
+  if (slabs >= 16)
+    hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_reduce_kernel<4>, dim3(grid), dim3(256), 0, s, workspace, dw, slabs, Cin, Cout,
+                       COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
+  else
+    hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_reduce_kernel<2>, dim3(grid), dim3(128), 0, s, workspace, dw, slabs, Cin, Cout,
+                       COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
+  SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_wgrad(reduce)");
+  return SEG3D_OK;
+}

@@ -588,11 +588,12 @@ def conv_wgrad(xn, dyn, w_shape, kind, out=None):
         xn, dyn = _to_f32(xn), _to_f32(dyn)     # remaining mixed cases: widen, then the fp32 kernels
         if _use_mfma(Cin, Cout) and Cout % 4 == 0 and WINOGRAD and \
                 E.query('seg3d_conv3d_k3_wino_wgrad_supported', N, D, H, W_, Cin, Cout):
-            # Winograd F(3, 2) along x: 2/3 of the MFMAs of the 27-tap kernel
-            nfl = E.query('seg3d_conv3d_k3_wino_wgrad_workspace_floats', N, D, H, W_, Cin, Cout)
+            # Winograd F(3x3, 2x2) over (y, x) (4/9 of the MFMAs of the 27-tap kernel) or F(3, 2) along x (2/3)
+            form = 'wino2d' if WINOGRAD2D and E.query('seg3d_conv3d_k3_wino2d_wgrad_preferred', N, D, H, W_, Cin, Cout) else 'wino'
+            nfl = E.query('seg3d_conv3d_k3_{}_wgrad_workspace_floats'.format(form), N, D, H, W_, Cin, Cout)
             ws = _empty((nfl,), xn)
             dw = _empty(w_shape, xn) if out is None else out
-            E.call('seg3d_conv3d_k3_wino_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(dw), E.ptr(ws), N, D, H, W_, Cin, Cout,
+            E.call('seg3d_conv3d_k3_{}_wgrad'.format(form), E.ptr(xn), E.ptr(dyn), E.ptr(dw), E.ptr(ws), N, D, H, W_, Cin, Cout,
                    int(out is not None), E.stream_ptr())
             return dw
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:

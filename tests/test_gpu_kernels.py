@@ -183,15 +183,16 @@ def test_conv3d_k3_winograd(hip_device, shape, flip, form):
 
 @pytest.mark.parametrize('shape', [(1, 32, 32, 8, 8, 16), (2, 16, 48, 4, 8, 8), (1, 64, 32, 12, 12, 12), (3, 8, 40, 8, 4, 24),
                                    (1, 32, 32, 16, 48, 32), (2, 96, 64, 4, 4, 4)])
-def test_conv3d_k3_winograd_wgrad(hip_device, shape):
-    """Winograd F(3, 2) weight gradient (csrc/conv_wino.hip) through the C ABI against the float64 weight gradient: both
+@pytest.mark.parametrize('form', ['wino', 'wino2d'])
+def test_conv3d_k3_winograd_wgrad(hip_device, shape, form):
+    """Winograd F(3, 2) along x (csrc/conv_wino.hip) and F(3x3, 2x2) over (y, x) (csrc/conv_wino2d.hip) weight gradients through the C ABI against the float64 weight gradient: both
     tile shapes (W % 8 == 0 and W % 4 == 0), partial 32-channel blocks, one and several tiles per workgroup, several block
     pairs, batch > 1; the accumulate flag; and against the 27-tap MFMA kernel on the same input"""
     from segmentation3d import _ops, _engine as E
     N, Cin, Cout, D, H, W = shape
-    assert E.query('seg3d_conv3d_k3_wino_wgrad_supported', N, D, H, W, Cin, Cout) == 1
-    assert E.query('seg3d_conv3d_k3_wino_wgrad_supported', N, D, H, W + 2, Cin, Cout) == 0     # not whole tiles
-    assert E.query('seg3d_conv3d_k3_wino_wgrad_supported', N, D, H, W, Cin + 2, Cout) == 0
+    assert E.query('seg3d_conv3d_k3_{}_wgrad_supported'.format(form), N, D, H, W, Cin, Cout) == 1
+    assert E.query('seg3d_conv3d_k3_{}_wgrad_supported'.format(form), N, D, H, W + 2, Cin, Cout) == 0     # not whole tiles
+    assert E.query('seg3d_conv3d_k3_{}_wgrad_supported'.format(form), N, D, H, W, Cin + 2, Cout) == 0
     x = _t(41, 'gx', (N, Cin, D, H, W))
     dy = _t(42, 'gdy', (N, Cout, D, H, W))
     xd = x.double().requires_grad_(False)
@@ -199,25 +200,25 @@ def test_conv3d_k3_winograd_wgrad(hip_device, shape):
     F.conv3d(xd, wz, None, padding=1).backward(dy.double())
     ref = wz.grad
     xn, dyn = _ops.to_ndhwc(x.to(hip_device)), _ops.to_ndhwc(dy.to(hip_device))
-    ws = torch.full((E.query('seg3d_conv3d_k3_wino_wgrad_workspace_floats', N, D, H, W, Cin, Cout),), float('nan'), device=hip_device)
+    ws = torch.full((E.query('seg3d_conv3d_k3_{}_wgrad_workspace_floats'.format(form), N, D, H, W, Cin, Cout),), float('nan'), device=hip_device)
     dw = torch.full((Cout, Cin, 3, 3, 3), float('nan'), device=hip_device)
-    E.call('seg3d_conv3d_k3_wino_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(dw), E.ptr(ws), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
+    E.call('seg3d_conv3d_k3_{}_wgrad'.format(form), E.ptr(xn), E.ptr(dyn), E.ptr(dw), E.ptr(ws), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
     scale = float(ref.abs().max())
     err = float((dw.double().cpu() - ref).abs().max())
     ws27 = torch.empty((E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W, Cin, Cout),), device=hip_device)
     dw27 = torch.empty((Cout, Cin, 3, 3, 3), device=hip_device)
     E.call('seg3d_conv3d_k3_mfma_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(dw27), E.ptr(ws27), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
     err_direct = float((dw27.double().cpu() - ref).abs().max())
-    report('winograd_wgrad_{}'.format('_'.join(map(str, shape))), max_abs_err=err, direct_kernel_err=err_direct, out_scale=scale)
+    report('{}_wgrad_{}'.format(form, '_'.join(map(str, shape))), max_abs_err=err, direct_kernel_err=err_direct, out_scale=scale)
     assert err < 1e-5 * scale and err < 4.0 * err_direct + 1e-6 * scale, (err, err_direct, scale)
     # accumulate: dw += gradient, bitwise the same gradient as the plain call
     base = _t(43, 'gbase', (Cout, Cin, 3, 3, 3)).to(hip_device)
     acc = base.clone()
-    E.call('seg3d_conv3d_k3_wino_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(acc), E.ptr(ws), N, D, H, W, Cin, Cout, 1, E.stream_ptr())
+    E.call('seg3d_conv3d_k3_{}_wgrad'.format(form), E.ptr(xn), E.ptr(dyn), E.ptr(acc), E.ptr(ws), N, D, H, W, Cin, Cout, 1, E.stream_ptr())
     assert torch.equal(acc, base + dw)
     # run to run: bitwise reproducible
     dw2 = torch.empty_like(dw)
-    E.call('seg3d_conv3d_k3_wino_wgrad', E.ptr(xn), E.ptr(dyn), E.ptr(dw2), E.ptr(ws), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
+    E.call('seg3d_conv3d_k3_{}_wgrad'.format(form), E.ptr(xn), E.ptr(dyn), E.ptr(dw2), E.ptr(ws), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
     assert torch.equal(dw, dw2)
 
 

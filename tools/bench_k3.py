@@ -53,6 +53,10 @@ def main():
             wsq = torch.empty(E.query('seg3d_conv3d_k3_wino_wgrad_workspace_floats', N, D, H, W, C, C), device=dev)
             ms2 = timed(lambda: E.call('seg3d_conv3d_k3_wino_wgrad', E.ptr(x), E.ptr(dyv), E.ptr(dw), E.ptr(wsq), N, D, H, W, C, C, 0, E.stream_ptr()), iters)
             line += '   winograd {:8.3f} ms {:6.1f} TF (algorithmic)  x{:.2f}'.format(ms2, fl / ms2 / 1e9, ms / ms2)
+        if E.query('seg3d_conv3d_k3_wino2d_wgrad_supported', N, D, H, W, C, C):
+            wsq2 = torch.empty(E.query('seg3d_conv3d_k3_wino2d_wgrad_workspace_floats', N, D, H, W, C, C), device=dev)
+            ms3 = timed(lambda: E.call('seg3d_conv3d_k3_wino2d_wgrad', E.ptr(x), E.ptr(dyv), E.ptr(dw), E.ptr(wsq2), N, D, H, W, C, C, 0, E.stream_ptr()), iters)
+            line += '   winograd2d {:8.3f} ms {:6.1f} TF (algorithmic)  x{:.2f}'.format(ms3, fl / ms3 / 1e9, ms / ms3)
         print(line, flush=True)
 
 main()

@@ -15,14 +15,18 @@
 // arrive by LDS-DMA; packed weight images are straight copies), with
 //   * tile 8 x 8 x 8 voxels = 128 output quads; FOUR waves (one per SIMD, 512 registers): wave w owns the z planes 2w,
 //     2w + 1 = 32 quads x 32 output channels, i.e. 16 point accumulators of 16 registers;
-//   * K chunks of FOUR input channels (the weight image of a chunk is 48 x 512 B = 24 KB, two buffers; chunks of 8 would
-//     need 210 KB): per chunk the RAW halo tile [10 x 10 x 10 voxels][4] lands by DMA while the previous chunk is
-//     multiplied, then 160 threads transform it into T[p = 16][z = 10][quad = 16][4] (two barriers per chunk);
-//   * 48 steps of 2 MFMAs per chunk: (kz, point), operands one ds_read_b64 each (a wave's 32 quads of one (p, z pair) are
-//     512 contiguous bytes of T; the weight image is [t][co][4]);
+//   * K chunks of FOUR input channels (the weight image of a chunk is 48 x 512 B = 24 KB; chunks of 8 would not fit);
+//   * everything a chunk needs arrives or is made INSIDE the previous chunk's MFMA loop, one barrier per chunk: while chunk c
+//     is multiplied, the weights of chunk c + 1 and the RAW halo tile [10 x 10 x 10 voxels][4] of chunk c + 2 land by
+//     LDS-DMA (steps 0-9), and the RAW tile of chunk c + 1 is transformed into the second T buffer
+//     T[p = 16][z = 10][quad = 16][4] in eight stages spread over steps 12-33 (40 (z, quad) items per wave, packed fp32
+//     adds: 64 vector instructions per wave and chunk beside 96 MFMAs).  The first version transformed between two barriers
+//     with the matrix cores idle: 1 800 of 12 000 cycles per chunk (tools/ubench/wino2d_stamp.hip);
+//   * 48 steps of 2 MFMAs per chunk: (kz, point), operands one ds_read_b64 each, read two steps ahead (a wave's 32 quads
+//     of one (p, z pair) are 512 contiguous bytes of T; the weight image is [t][co][4]);
 //   * the weight image is the T = 48 pack of seg3d_pack_weights_mfma: t = kz * 16 + py * 4 + px, laid out per 8-channel chunk
 //     [t][half][32 co][4] -- a 4-channel K chunk is one half;
-//   * LDS: RAW 16 KB + T 40 KB + 2 x 24 KB weights = 104 KB.
+//   * LDS: 2 x 16 KB RAW + 2 x 40 KB T + 2 x 24 KB weights = 160 KB, all of it.
 #include "seg3d_common.h"
 #include "seg3d_hip.h"
 #include <stdint.h>
@@ -39,7 +43,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define W2_T (16 * W2_H * W2_NQ * 4)              // floats of the transformed image: 10240
 #define W2_W (48 * 128)                           // floats of one K chunk's weight image: [48][32][4]
 #define W2_NW 4
-#define W2_LDS_FLOATS (W2_RAW + W2_T + 2 * W2_W)  // 26624 floats = 106496 bytes
+#define W2_LDS_FLOATS (2 * W2_RAW + 2 * W2_T + 2 * W2_W)  // 40960 floats = 163840 bytes: all of the CU's LDS
 #define W2_XPW 4                                  // raw pieces per wave (16 / 4)
 #define W2_WPW 6                                  // weight pieces per wave (24 / 4)
 
@@ -56,6 +60,28 @@ __device__ __forceinline__ void w2_glds16(const float* src, float* lds_dst_wave_
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(off) : "memory");
 }
 __device__ __forceinline__ void w2_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// a - b on two packed floats in one instruction (hipcc selects v_pk_add_f32 for additions but two v_sub_f32 for this)
+__device__ __forceinline__ f32x2 w2_pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 w2_pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+#ifdef W2_STAMPS   // diagnostic build only (tools/ubench/wino2d_stamp.hip): s_memtime stamps of the first chunks of a few workgroups
+__device__ long long* w2_stamp_buf;
+#define W2_STAMP(chunk, k)                                                                                        \
+  do {                                                                                                            \
+    if (blockIdx.x < 8 && (chunk) < 64 && (threadIdx.x & 63) == 0)                                                \
+      w2_stamp_buf[((blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (chunk)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define W2_STAMP(chunk, k)
+#endif
 
 __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                    const float* __restrict__ bias, float* __restrict__ y,
@@ -63,9 +89,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
                                                                    int Cout, int ntz, int nty, int ntx, int ncog, int nitems,
                                                                    const float* __restrict__ addend) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* raw = lds;                       // [NV][4] (+ padding)
-  float* timg = lds + W2_RAW;             // [16][10][16][4]
-  float* wbuf = lds + W2_RAW + W2_T;      // [2][48][32][4]
+  float* raw = lds;                               // [2][NV][4] (+ padding)
+  float* timg = lds + 2 * W2_RAW;                 // [2][16][10][16][4]
+  float* wbuf = lds + 2 * W2_RAW + 2 * W2_T;      // [2][48][32][4]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,18 +122,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
   const int zz = li >> 4, qq = li & 15, qy = qq >> 2, qx = qq & 3;
   const int abase = li * 4 + 2 * lh;                                      // weights: [t][co = li][4], channels 2 lh, 2 lh + 1
   const int bbase = ((2 * wave + zz) * W2_NQ + qq) * 4 + 2 * lh;          // T: + (p * 10 + kz) * 64
-  // transform item of this thread (tid < 160): (z, quad)
-  const int t_z = tid >> 4, t_q = tid & 15;
+  // transform item of this lane: 160 (z, quad) items, 40 per wave (lanes >= 40 repeat item 39 of their wave: same values to
+  // the same addresses -- no branch)
+  const int t_i = wave * 40 + (lane < 40 ? lane : 39);
+  const int t_z = t_i >> 4, t_q = t_i & 15;
   const int t_src = ((t_z * W2_H + 2 * (t_q >> 2)) * W2_H + 2 * (t_q & 3)) * 4;
   const int t_dst = (t_z * W2_NQ + t_q) * 4;
 
-  // ---- work item state ----
-  int it_n = 0, it_z0 = 0, it_y0 = 0, it_x0 = 0, it_cog = 0, it_tile = 0;
-  const float* xsrc[W2_XPW];
-  int xadv = 0;
-  auto setup_item = [&](int item) {
+  auto decode = [&](int item, int& n, int& z0, int& y0, int& x0, int& cog, int& tile) {
     const int tile_all = fdiv(item, rNCOG);
-    it_cog = item - tile_all * ncog;
+    cog = item - tile_all * ncog;
     int b = tile_all;
     int q = fdiv(b, rNTX);
     const int tix = b - q * ntx;
@@ -117,57 +141,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
     b = q;
     q = fdiv(b, rNTZ);
     const int tiz = b - q * ntz;
-    it_n = q;
-    it_tile = (tiz * nty + tiy) * ntx + tix;
-    it_z0 = tiz * W2_TS, it_y0 = tiy * W2_TS, it_x0 = tix * W2_TS;
-    xadv = 0;
-#pragma unroll
-    for (int j = 0; j < W2_XPW; ++j) {
-      xsrc[j] = w2_zero16;
-      const int hp = hpos[j];
-      const int gz = it_z0 + ((hp >> 20) & 1023) - 1, gy = it_y0 + ((hp >> 10) & 1023) - 1, gx = it_x0 + (hp & 1023) - 1;
-      if (hp >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        xsrc[j] = x + (i64)(((it_n * D + gz) * H + gy) * W + gx) * Cin;
-        xadv |= 1 << j;
-      }
-    }
+    n = q;
+    tile = (tiz * nty + tiy) * ntx + tix;
+    z0 = tiz * W2_TS, y0 = tiy * W2_TS, x0 = tix * W2_TS;
   };
-  auto dma_x = [&](int j) {  // issues the piece into RAW, then steps its source to the next K chunk
-    w2_glds16(xsrc[j], raw + (wave + W2_NW * j) * 256);
-    xsrc[j] += ((xadv >> j) & 1) * 4;
-  };
-  // weight image of K chunk sc of column block cog: half (sc & 1) of the packed 8-channel chunk sc >> 1
-  auto wsrc_of = [&](int cog, int sc) { return wp + ((i64)cog * AB + (sc >> 1)) * (48 * 256) + (sc & 1) * 128; };
-  auto dma_w = [&](int j, const float* wsrc, float* wdst) {
-    const int piece = wave + W2_NW * j;   // two images per piece
-    w2_glds16(wsrc + (2 * piece + (lane >> 5)) * 256 + (lane & 31) * 4, wdst + piece * 256);
-  };
-  auto transform = [&]() {   // RAW -> T: V = B^T d B per (z, quad), 16 points
-    if (tid < W2_H * W2_NQ) {
-      f32x4 dx[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* s = raw + t_src + r * (W2_H * 4);
-        const f32x4 d0 = *reinterpret_cast<const f32x4*>(s);
-        const f32x4 d1 = *reinterpret_cast<const f32x4*>(s + 4);
-        const f32x4 d2 = *reinterpret_cast<const f32x4*>(s + 8);
-        const f32x4 d3 = *reinterpret_cast<const f32x4*>(s + 12);
-        dx[r][0] = d0 - d2;
-        dx[r][1] = d1 + d2;
-        dx[r][2] = d2 - d1;
-        dx[r][3] = d1 - d3;
-      }
-      float* dst = timg + t_dst;
-#pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        *reinterpret_cast<f32x4*>(dst + (0 * 4 + px) * (W2_H * W2_NQ * 4)) = dx[0][px] - dx[2][px];
-        *reinterpret_cast<f32x4*>(dst + (1 * 4 + px) * (W2_H * W2_NQ * 4)) = dx[1][px] + dx[2][px];
-        *reinterpret_cast<f32x4*>(dst + (2 * 4 + px) * (W2_H * W2_NQ * 4)) = dx[2][px] - dx[1][px];
-        *reinterpret_cast<f32x4*>(dst + (3 * 4 + px) * (W2_H * W2_NQ * 4)) = dx[1][px] - dx[3][px];
-      }
-    }
-  };
-
   // item walk: XCD-contiguous eighths of the item list (as conv_mfma.hip)
   int item = blockIdx.x, istride = G, ilimit = nitems;
   if ((G & 7) == 0) {
@@ -177,22 +154,120 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
     ilimit = (xcd + 1) * per_xcd < nitems ? (xcd + 1) * per_xcd : nitems;
   }
   if (item >= ilimit) return;
-  setup_item(item);
-  {  // the only exposed DMA prologue of this workgroup: K chunk 0 of its first item
-    const float* w0 = wsrc_of(it_cog, 0);
+
+  // ---- fetch cursors ----
+  // While K chunk c is multiplied, the weights of chunk c + 1 and the RAW tile of chunk c + 2 arrive by DMA and the RAW tile
+  // of chunk c + 1 (landed during chunk c - 1) is transformed into the second T buffer -- all inside the MFMA loop, one
+  // barrier per chunk.  Each stream has its own cursor over the (item, chunk) sequence of this workgroup; past the last
+  // chunk of the last item a cursor wraps to that item's chunk 0 (harmless refetch: the loop stays uniform, no branch).
+  int fx_item = item, fx_sc = 0;   // RAW cursor
+  const float* xsrc[W2_XPW];
+  int xadv = 0;
+  auto fx_setup = [&](int it) {   // DMA sources of chunk 0 of item `it`
+    int n, z0, y0, x0, cog, tile;
+    decode(it, n, z0, y0, x0, cog, tile);
+    xadv = 0;
 #pragma unroll
-    for (int j = 0; j < W2_XPW; ++j) dma_x(j);
+    for (int j = 0; j < W2_XPW; ++j) {
+      xsrc[j] = w2_zero16;
+      const int hp = hpos[j];
+      const int gz = z0 + ((hp >> 20) & 1023) - 1, gy = y0 + ((hp >> 10) & 1023) - 1, gx = x0 + (hp & 1023) - 1;
+      if (hp >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        xsrc[j] = x + (i64)(((n * D + gz) * H + gy) * W + gx) * Cin;
+        xadv |= 1 << j;
+      }
+    }
+  };
+  auto fx_advance = [&]() {
+    ++fx_sc;
+    if (fx_sc == NSC) {
+      fx_sc = 0;
+      if (fx_item + istride < ilimit) fx_item += istride;
+      fx_setup(fx_item);
+    }
+  };
+  auto dma_x = [&](int j, float* rdst) {  // issues the piece into RAW, then steps its source to the next K chunk
+    w2_glds16(xsrc[j], rdst + (wave + W2_NW * j) * 256);
+    xsrc[j] += ((xadv >> j) & 1) * 4;
+  };
+  int fw_item = item, fw_sc = 0;   // weight cursor
+  // weight image of K chunk sc of column block cog: half (sc & 1) of the packed 8-channel chunk sc >> 1
+  auto fw_src = [&]() {
+    const int cog = fw_item - fdiv(fw_item, rNCOG) * ncog;
+    return wp + ((i64)cog * AB + (fw_sc >> 1)) * (48 * 256) + (fw_sc & 1) * 128;
+  };
+  auto fw_advance = [&]() {
+    ++fw_sc;
+    if (fw_sc == NSC) {
+      fw_sc = 0;
+      if (fw_item + istride < ilimit) fw_item += istride;
+    }
+  };
+  auto dma_w = [&](int j, const float* wsrc, float* wdst) {
+    const int piece = wave + W2_NW * j;   // two images per piece
+    w2_glds16(wsrc + (2 * piece + (lane >> 5)) * 256 + (lane & 31) * 4, wdst + piece * 256);
+  };
+  // RAW -> T: V = B^T d B per (z, quad), 16 points, in stages that the MFMA loop interleaves: four row stages (read one row
+  // of the 4 x 4 patch, x pass) and four column stages (y pass of one px, four stores); packed fp32 math
+  f32x4 rd[2][4];
+  f32x2 dxl[4][4], dxh[4][4];   // [row][px], channel pairs (0, 1) and (2, 3)
+  auto tr_read = [&](const float* rw, int r) {
+    const float* sp = rw + t_src + r * (W2_H * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rd[r & 1][k] = *reinterpret_cast<const f32x4*>(sp + 4 * k);
+  };
+  auto tr_x = [&](int r) {
+    const f32x4* d = rd[r & 1];
+    const f32x2 d0l = {d[0][0], d[0][1]}, d0h = {d[0][2], d[0][3]}, d1l = {d[1][0], d[1][1]}, d1h = {d[1][2], d[1][3]};
+    const f32x2 d2l = {d[2][0], d[2][1]}, d2h = {d[2][2], d[2][3]}, d3l = {d[3][0], d[3][1]}, d3h = {d[3][2], d[3][3]};
+    dxl[r][0] = w2_pk_sub(d0l, d2l), dxh[r][0] = w2_pk_sub(d0h, d2h);
+    dxl[r][1] = w2_pk_add(d1l, d2l), dxh[r][1] = w2_pk_add(d1h, d2h);
+    dxl[r][2] = w2_pk_sub(d2l, d1l), dxh[r][2] = w2_pk_sub(d2h, d1h);
+    dxl[r][3] = w2_pk_sub(d1l, d3l), dxh[r][3] = w2_pk_sub(d1h, d3h);
+  };
+  auto tr_y = [&](float* tdst, int px) {
+    float* dst = tdst + t_dst + px * (W2_H * W2_NQ * 4);
+    const f32x2 v0l = w2_pk_sub(dxl[0][px], dxl[2][px]), v0h = w2_pk_sub(dxh[0][px], dxh[2][px]);
+    const f32x2 v1l = w2_pk_add(dxl[1][px], dxl[2][px]), v1h = w2_pk_add(dxh[1][px], dxh[2][px]);
+    const f32x2 v2l = w2_pk_sub(dxl[2][px], dxl[1][px]), v2h = w2_pk_sub(dxh[2][px], dxh[1][px]);
+    const f32x2 v3l = w2_pk_sub(dxl[1][px], dxl[3][px]), v3h = w2_pk_sub(dxh[1][px], dxh[3][px]);
+    *reinterpret_cast<f32x4*>(dst + 0 * 4 * (W2_H * W2_NQ * 4)) = f32x4{v0l[0], v0l[1], v0h[0], v0h[1]};
+    *reinterpret_cast<f32x4*>(dst + 1 * 4 * (W2_H * W2_NQ * 4)) = f32x4{v1l[0], v1l[1], v1h[0], v1h[1]};
+    *reinterpret_cast<f32x4*>(dst + 2 * 4 * (W2_H * W2_NQ * 4)) = f32x4{v2l[0], v2l[1], v2h[0], v2h[1]};
+    *reinterpret_cast<f32x4*>(dst + 3 * 4 * (W2_H * W2_NQ * 4)) = f32x4{v3l[0], v3l[1], v3h[0], v3h[1]};
+  };
+
+  fx_setup(item);
+  {  // the exposed prologue of this workgroup: RAW of its chunks 0 and 1, weights of chunk 0; chunk 0 transformed stand-alone
+#pragma unroll
+    for (int j = 0; j < W2_XPW; ++j) dma_x(j, raw);
+    fx_advance();
+    const float* w0 = fw_src();
 #pragma unroll
     for (int j = 0; j < W2_WPW; ++j) dma_w(j, w0, wbuf);
+    fw_advance();
+#pragma unroll
+    for (int j = 0; j < W2_XPW; ++j) dma_x(j, raw + W2_RAW);
+    fx_advance();
   }
   w2_dma_wait();
   __syncthreads();   // publishes RAW / weights
-  transform();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    tr_read(raw, r);
+    tr_x(r);
+  }
+#pragma unroll
+  for (int px = 0; px < 4; ++px) tr_y(timg, px);
   __syncthreads();
 
-  int parity = 0;
+  int ci_ = 0;   // parity of the current chunk: T, W buffers ci_; RAW of the next chunk in raw[ci_ ^ 1]
+#ifdef W2_STAMPS
+  int gchunk = 0;
+#endif
   for (;;) {
-    const int cur_n = it_n, cur_z0 = it_z0, cur_y0 = it_y0, cur_x0 = it_x0, cur_cog = it_cog, cur_tile = it_tile;
+    int cur_n, cur_z0, cur_y0, cur_x0, cur_cog, cur_tile;
+    decode(item, cur_n, cur_z0, cur_y0, cur_x0, cur_cog, cur_tile);
     const int next_item = item + istride;
     const bool more_items = next_item < ilimit;
 
@@ -202,24 +277,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
     for (int sc = 0; sc < NSC; ++sc) {
-      const float* ws = wbuf + parity * W2_W;
-      float* wnext_dst = wbuf + (parity ^ 1) * W2_W;
-      const bool last = sc + 1 == NSC;
-      const float* wnext;
-      if (last) {
-        // DMA sources now belong to the next item; after the very last item they are reset to this one's chunk 0 (a
-        // harmless refetch into the idle buffers, so that the unrolled loop below needs no branch)
-        setup_item(more_items ? next_item : item);
-        wnext = wsrc_of(it_cog, 0);
-      } else {
-        wnext = wsrc_of(cur_cog, sc + 1);
-      }
+      const float* ws = wbuf + ci_ * W2_W;
+      const float* tcur = timg + ci_ * W2_T;
+      float* wdst1 = wbuf + (ci_ ^ 1) * W2_W;           // weights of the next chunk
+      float* tdst1 = timg + (ci_ ^ 1) * W2_T;           // T of the next chunk
+      const float* rsrc1 = raw + (ci_ ^ 1) * W2_RAW;    // RAW of the next chunk (landed)
+      float* rdst2 = raw + ci_ * W2_RAW;                // RAW of the chunk after next (RAW of this chunk is dead)
+      const float* wsrc1 = fw_src();
       // operands of step st + 2 are read while step st is multiplied (one wave per SIMD: nothing else hides the LDS latency);
-      // the scheduling barriers keep hipcc from sinking the reads down to their first use
+      // the scheduling barriers keep hipcc from moving the reads, the DMA issue and the transform stages
       auto lda = [&](int s1) { return *reinterpret_cast<const f32x2*>(ws + s1 * 128 + abase); };
       auto ldb = [&](int s1) {
-        return *reinterpret_cast<const f32x2*>(timg + ((s1 & 15) * W2_H + (s1 >> 4)) * (W2_NQ * 4) + bbase);
+        return *reinterpret_cast<const f32x2*>(tcur + ((s1 & 15) * W2_H + (s1 >> 4)) * (W2_NQ * 4) + bbase);
       };
+      W2_STAMP(gchunk, 0);
       f32x2 aw0 = lda(0), bv0 = ldb(0), aw1 = lda(1), bv1 = ldb(1);
 #pragma unroll
       for (int st = 0; st < 48; ++st) {
@@ -228,10 +299,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
           aw2 = lda(st + 2);
           bv2 = ldb(st + 2);
         }
-        // the next K chunk (of this item, or chunk 0 of the next item; after the very last chunk: a harmless refetch)
-        // arrives behind the first ten steps -- unconditionally, so that the unrolled loop has no branch
-        if (st < W2_XPW) dma_x(st);
-        else if (st - W2_XPW < W2_WPW) dma_w(st - W2_XPW, wnext, wnext_dst);
+        // steps 0-9: DMA issue (weights first, they are needed first); steps 12-21: row stages; 24-33: column stages
+        if (st < W2_WPW) dma_w(st, wsrc1, wdst1);
+        else if (st - W2_WPW < W2_XPW) dma_x(st - W2_WPW, rdst2);
+        if (st >= 12 && st <= 18 && (st & 1) == 0) tr_read(rsrc1, (st - 12) >> 1);
+        if (st >= 15 && st <= 21 && (st & 1) == 1) tr_x((st - 15) >> 1);
+        if (st >= 24 && st <= 33 && (st - 24) % 3 == 0) tr_y(tdst1, (st - 24) / 3);
         __builtin_amdgcn_sched_barrier(0);
         // A = weights, B = quads: D[co][quad], a lane owns quad (lane & 31) and channels 8 g + 4 (lane >> 5) + c
         acc[st & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw0[0], bv0[0], acc[st & 15], 0, 0, 0);
@@ -242,13 +315,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
         aw1 = aw2;
         bv1 = bv2;
       }
+      W2_STAMP(gchunk, 1);
+      fw_advance();
+      fx_advance();
       w2_dma_wait();     // own DMAs landed
-      __syncthreads();   // everyone is done with T and this weight buffer
-      if (!last || more_items) {
-        transform();     // the next chunk's RAW -> T
-        __syncthreads();
-      }
-      parity ^= 1;
+      W2_STAMP(gchunk, 2);
+      __syncthreads();   // next T complete, everyone is done with this T / weight buffer
+      W2_STAMP(gchunk, 3);
+      ci_ ^= 1;
+#ifdef W2_STAMPS
+      ++gchunk;
+#endif
     }
 
     // ---- output transform Y = A^T M A + epilogue: bias (+ addend), dwordx4 stores, per-wave GroupNorm partial sums ----
@@ -302,9 +379,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
         dst[1] = s1;
       }
     }
+    W2_STAMP(gchunk - 1, 6);
     if (!more_items) break;
     item = next_item;
   }
+  w2_dma_wait();   // nothing in flight when the workgroup's LDS is released
 }
 
 // shapes this kernel takes: whole 8 x 8 x 8 tiles, channel blocks of 8 / 32

@@ -2,10 +2,10 @@
 usage: python tools/pmc_summary.py <counter_collection.csv> [name filter]"""
 import csv, collections, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-flt = sys.argv[2] if len(sys.argv) > 2 else 'mfma'
+flt = sys.argv[2] if len(sys.argv) > 2 else 'conv'   # every convolution kernel (MFMA, Winograd, thin, stride-2)
 agg = collections.OrderedDict()
 for r in rows:
-    k = (r['Kernel_Name'][:48], r['Grid_Size'])
+    k = (r['Kernel_Name'].split('(')[0][:64], r['Grid_Size'])
     agg.setdefault(k, collections.defaultdict(list))[r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
     if flt not in k[0]:

@@ -84,20 +84,29 @@ BENCH_VARIANT_CASES = [
 ]
 
 
-@pytest.mark.parametrize('winograd', [False, True])
+@pytest.mark.parametrize('form', ['direct', 'wino', 'wino2d'])
 @pytest.mark.parametrize('shape,variant', BENCH_VARIANT_CASES)
-def test_conv3d_k3_bench_variants_full_size(hip_device, shape, variant, winograd, monkeypatch):
+def test_conv3d_k3_bench_variants_full_size(hip_device, shape, variant, form, monkeypatch):
     """forward, data-gradient (fused addend included) and weight-gradient of the C -> C 3x3x3 convolution at the FULL sizes
-    of the headline configuration against stock torch CPU ops, asserting which kernel instantiation ran: the direct
-    implicit-GEMM instantiations (winograd = False: variant codes 321 / 131 / 311) and the Winograd F(2, 3) kernel that the
-    default path uses for forward and data-gradient at these levels"""
+    of the headline configuration against stock torch CPU ops, asserting which kernels ran: the direct implicit-GEMM
+    instantiations (variant codes 321 / 131 / 311), the Winograd F(2, 3) / F(3, 2) kernels, and the F(2x2, 3x3) / F(3x3, 2x2)
+    kernels the default path uses at these levels (the entry points called through the C ABI are recorded and checked)"""
     from segmentation3d import _ops, _engine as E
     N, C, D, H, W = shape
     assert E.query('seg3d_conv3d_k3_mfma_variant', N, D, H, W, C, C) == variant
-    if winograd and not E.query('seg3d_conv3d_k3_wino_preferred', N, D, H, W, C, C):
+    if form != 'direct' and not E.query('seg3d_conv3d_k3_{}_preferred'.format(form), N, D, H, W, C, C):
         pytest.skip('fewer than 192 items: the default path keeps the direct kernel here')
-    monkeypatch.setattr(_ops, 'WINOGRAD', winograd)
-    name = 'bench_variant_{}{}_{}'.format(variant, '_wino' if winograd else '', '_'.join(map(str, shape)))
+    monkeypatch.setattr(_ops, 'WINOGRAD', form != 'direct')
+    monkeypatch.setattr(_ops, 'WINOGRAD2D', form == 'wino2d')
+    called = []
+    orig_call = E.call
+
+    def spy(fn, *a):
+        called.append(fn)
+        return orig_call(fn, *a)
+    monkeypatch.setattr(E, 'call', spy)
+    winograd = form != 'direct'
+    name = 'bench_variant_{}_{}_{}'.format(variant, form, '_'.join(map(str, shape)))
     torch.set_num_threads(max(torch.get_num_threads(), 16))
     x = _t(15, name + 'x', (N, C, D, H, W)).requires_grad_(True)
     w = _t(16, name + 'w', (C, C, 3, 3, 3), std=(2.0 / (C * 27)) ** 0.5).requires_grad_(True)
@@ -125,6 +134,16 @@ def test_conv3d_k3_bench_variants_full_size(hip_device, shape, variant, winograd
     report(name, **e)
     assert e['out'] < 1e-4 and e['dx'] < 1e-4 and e['dw'] < 2e-4 and e['dw_acc'] < 2e-4, e
     assert e['stat_sum'] < 1e-5 and e['stat_sq'] < 1e-5, e
+    fwd_name = {'direct': 'seg3d_conv3d_k3_mfma_fwd', 'wino': 'seg3d_conv3d_k3_wino_fwd', 'wino2d': 'seg3d_conv3d_k3_wino2d_fwd'}[form]
+    assert called.count(fwd_name) == 2, called                        # forward + data-gradient
+    wg = [c for c in called if c.endswith('_wgrad')]
+    if form == 'direct':
+        assert wg == ['seg3d_conv3d_k3_mfma_wgrad'] * 2, wg
+    elif form == 'wino':
+        assert wg == ['seg3d_conv3d_k3_wino_wgrad'] * 2, wg
+    else:   # F(3x3, 2x2) where a workgroup gets enough tiles, else F(3, 2)
+        want = 'seg3d_conv3d_k3_wino2d_wgrad' if E.query('seg3d_conv3d_k3_wino2d_wgrad_preferred', N, D, H, W, C, C) else 'seg3d_conv3d_k3_wino_wgrad'
+        assert wg == [want] * 2, wg
 
 
 @pytest.mark.parametrize('shape', [(1, 8, 32, 16, 24, 32), (2, 32, 32, 8, 16, 48), (1, 64, 96, 16, 16, 16), (3, 16, 64, 8, 8, 64),

@@ -224,12 +224,15 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restri
 
   if (pair_ok) {
     for (i64 v = v0 + vl; v < v1; v += VL) {
-      const int xq = (int)(v % Wq);
-      i64 r = v / Wq;
-      const int yq = (int)(r % Hq);
-      r /= Hq;
-      const int zq = (int)(r % Dq);
-      const int n = (int)(r / Dq);
+      int xq = 0, yq = 0, zq = 0, n = 0;
+      if constexpr (KS != 1) {   // (a 1x1x1 tap reads P at the same voxel: no coordinates, no 64-bit divisions)
+        xq = (int)(v % Wq);
+        i64 r = v / Wq;
+        yq = (int)(r % Hq);
+        r /= Hq;
+        zq = (int)(r % Dq);
+        n = (int)(r / Dq);
+      }
       float4 qv;
       {
         const float* qp = Q + v * CB + 4 * bq;
@@ -251,8 +254,11 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restri
           for (int kx = 0; kx < KS; ++kx) {
             const int zp = zq * STRIDE + kz - PAD, yp = yq * STRIDE + ky - PAD, xp = xq * STRIDE + kx - PAD;
             float pv = 0.f;
-            if (zp >= 0 && zp < Dp && yp >= 0 && yp < Hp && xp >= 0 && xp < Wp_)
+            if constexpr (KS == 1 && STRIDE == 1 && PAD == 0) {
+              pv = P[v * CA + a];
+            } else if (zp >= 0 && zp < Dp && yp >= 0 && yp < Hp && xp >= 0 && xp < Wp_) {
               pv = P[((((i64)n * Dp + zp) * Hp + yp) * Wp_ + xp) * CA + a];
+            }
             const int t = (kz * KS + ky) * KS + kx;
             acc[t].x = fmaf(pv, qv.x, acc[t].x);
             acc[t].y = fmaf(pv, qv.y, acc[t].y);

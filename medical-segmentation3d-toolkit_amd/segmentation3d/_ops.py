@@ -311,6 +311,20 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
     if addend is not None:   # the special-case kernels below have no fused addend: add afterwards (device op)
         y2, st = _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats)
         return y2.add_(addend), st
+    if 3 <= A <= 8 and not FORCE_DIRECT and WINOGRAD and WINOGRAD2D and not _is_bf16(xn) and not _is_bf16(y) and \
+            E.query('seg3d_conv3d_k3_wino2d_preferred', N, D, H, W_, 8, B):
+        # 3..8 thin channels onto a big level (the data-gradient of a 3..8-class head): zero-pad the thin side to 8 channels
+        # and run the Winograd kernel -- the thin-input kernel folds all 27*A taps into the MFMA K dimension, which pays
+        # for A <= 2 only (5 classes at 4 x 96^3: 0.75 ms there, 0.3 ms this way); the T = 48 pack zero-fills rows a >= A
+        x8 = torch.zeros((N, D, H, W_, 8), dtype=torch.float32, device=xn.device)
+        E.call('seg3d_copy_channels', E.ptr(xn), E.ptr(x8), N * D * H * W_, A, A, 0, 8, 0, E.stream_ptr())
+        wp = _pack_mfma(w, A, B, 48, sa, sb, flip)
+        stats = None
+        if want_stats:
+            stats = _empty((N, E.query('seg3d_conv3d_k3_wino2d_stats_count', N, D, H, W_, 8, B), 2), xn)
+        E.call('seg3d_conv3d_k3_wino2d_fwd', E.ptr(x8), E.ptr(wp), E.ptr(bias), E.ptr(addend), E.ptr(y), E.ptr(stats), N, D, H,
+               W_, 8, B, E.stream_ptr())
+        return y, stats
     if A <= 8 and not FORCE_DIRECT:
         # thin input (stem forward, head data-gradient): all 27*A taps folded into one MFMA K dimension
         if _is_bf16(y) and E.query('seg3d_conv3d_k3_thin_in_mfma16_supported', A, B):

@@ -534,6 +534,26 @@ def test_conv3d_k3_thin_in_persistent(hip_device, shape, flip, out_bf16):
            out_scale=scale)
 
 
+@pytest.mark.parametrize('ncls', [3, 5, 7])
+def test_head_dgrad_thin_channels_on_winograd(hip_device, ncls, monkeypatch):
+    """data-gradient of a 3..7-class head (network/module/vnet_outblock.py:13) on a level big enough for the Winograd kernel:
+    _ops zero-pads the thin side to 8 channels and runs conv3d_k3_wino2d_kernel (recorded and asserted) -- against torch"""
+    from segmentation3d import _ops, _engine as E
+    N, C, D = 1, 32, 48
+    dy = _t(81, 'hdy', (N, ncls, D, D, D))
+    w = _t(82, 'hw', (ncls, C, 3, 3, 3), std=0.1)
+    x = torch.zeros((N, C, D, D, D), dtype=torch.float64, requires_grad=True)
+    F.conv3d(x, w.double(), None, padding=1).backward(dy.double())
+    called = []
+    orig_call = E.call
+    monkeypatch.setattr(E, 'call', lambda fn, *a: (called.append(fn), orig_call(fn, *a))[1])
+    dx = _ops.conv_dgrad(_ops.to_ndhwc(dy.to(hip_device)), w.to(hip_device), 'k3')
+    assert 'seg3d_conv3d_k3_wino2d_fwd' in called and 'seg3d_conv3d_k3_thin_in_persistent_fwd' not in called, called
+    err = rel_err(_ops.from_ndhwc(dx), x.grad)
+    report('head_dgrad_{}cls_wino2d'.format(ncls), rel_err=err)
+    assert err < 1e-5, err
+
+
 @pytest.mark.parametrize('shape', [(2, 1, 16, 8, 8, 16), (1, 4, 16, 5, 9, 11), (1, 2, 32, 6, 10, 18)])
 def test_k3_thin_wgrad_stem_bf16_dy(hip_device, shape):
     """stem weight gradient in bf16 mode: thin = the fp32 image (hi + lo inside the kernel), fat = the bf16 dy"""

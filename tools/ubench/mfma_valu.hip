@@ -9,10 +9,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// FILL: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_mov_b32, 3 v_mov_b32_dpp, 4 v_add_u32, 5 v_cndmask_b32, 6 ds_write_b32, 7 s_add_u32
+// FILL: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_mov_b32, 3 v_mov_b32_dpp, 4 v_add_u32, 5 v_cndmask_b32, 6 ds_write_b32, 7 s_add_u32,
+//       8 ds_read_b64, 9 ds_read_b128 (results waited for at the end of the loop only)
 template <int KIND, int V, int FILL = 0>
 __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int iters) {
-  __shared__ float lds[512];
+  __shared__ float lds[1024];
   const int tid = threadIdx.x;
   float a = 1.0f + tid * 1e-3f, b = 0.5f - tid * 1e-3f;
   f32x4 c4[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -46,6 +47,8 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, int iters) 
         if (FILL == 5) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[v & 7]) : "v"(m));
         if (FILL == 6) asm volatile("ds_write_b32 %0, %1" : : "v"(tid * 4), "v"(m) : "memory");
         if (FILL == 7) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sv));
+        if (FILL == 8) asm volatile("ds_read_b64 %0, %1" : "=v"(p2[v & 3]) : "v"(tid * 8) : "memory");
+        if (FILL == 9) asm volatile("ds_read_b128 %0, %1" : "=v"(ab) : "v"(tid * 16) : "memory");
       }
     }
   }
@@ -77,7 +80,7 @@ static void run(const char* name, int wgs_per_cu, float* out, long long* cyc) {
   hipEventElapsedTime(&ms, e0, e1);
   long long h[8];
   hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
-  static const char* fills[] = {"v_fma_f32", "v_pk_fma_f32", "v_mov_b32", "v_mov_b32_dpp", "v_add_u32", "v_cndmask_b32", "ds_write_b32", "s_add_u32"};
+  static const char* fills[] = {"v_fma_f32", "v_pk_fma_f32", "v_mov_b32", "v_mov_b32_dpp", "v_add_u32", "v_cndmask_b32", "ds_write_b32", "s_add_u32", "ds_read_b64", "ds_read_b128"};
   printf("%-14s + %-14s V=%2d waves/SIMD=%d  %8.1f cycles per (MFMA + V fma) group (s_memtime, wave 0 of block 0)  %7.3f ms\n", name, fills[FILL], V,
          wgs_per_cu, (double)h[0] / (iters * 16.0), ms);
 }
@@ -101,5 +104,7 @@ int main() {
   run<0, 4, 7>("f32 16x16x4", 1, out, cyc);
   run<1, 8, 1>("f32 32x32x2", 1, out, cyc); run<1, 8, 2>("f32 32x32x2", 1, out, cyc); run<1, 8, 4>("f32 32x32x2", 1, out, cyc);
   run<1, 8, 6>("f32 32x32x2", 1, out, cyc); run<1, 8, 7>("f32 32x32x2", 1, out, cyc);
+  run<1, 1, 8>("f32 32x32x2", 1, out, cyc); run<1, 2, 8>("f32 32x32x2", 1, out, cyc); run<1, 4, 8>("f32 32x32x2", 1, out, cyc);
+  run<1, 1, 9>("f32 32x32x2", 1, out, cyc); run<1, 2, 9>("f32 32x32x2", 1, out, cyc); run<1, 1, 6>("f32 32x32x2", 1, out, cyc);
   return 0;
 }

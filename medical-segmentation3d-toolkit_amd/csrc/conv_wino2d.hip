@@ -546,9 +546,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
   const int t_c4 = tid & 7, t_q = (tid >> 3) & 3, t_z = tid >> 5;
   const int t_src = ((t_z * 6 + 2 * (t_q >> 1)) * 6 + 2 * (t_q & 1)) * 32 + 4 * t_c4;
   const int t_dst = (t_z * 4 + t_q) * 32 + 4 * t_c4;
-  auto transform = [&](const float* rx) {   // RAW x -> T: V = B^T d B per (z, quad), 16 points
+  auto transform = [&](const float* rx) {   // RAW x -> T: V = B^T d B per (z, quad), 16 points; packed fp32 adds
     if (tid < 192) {
-      f32x4 dx[4][4];
+      f32x2 dxl[4][4], dxh[4][4];   // [row][px], channel pairs (0, 1) and (2, 3)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float* s = rx + t_src + r * (6 * 32);
@@ -556,18 +556,24 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
         const f32x4 d1 = *reinterpret_cast<const f32x4*>(s + 32);
         const f32x4 d2 = *reinterpret_cast<const f32x4*>(s + 64);
         const f32x4 d3 = *reinterpret_cast<const f32x4*>(s + 96);
-        dx[r][0] = d0 - d2;
-        dx[r][1] = d1 + d2;
-        dx[r][2] = d2 - d1;
-        dx[r][3] = d1 - d3;
+        const f32x2 d0l = {d0[0], d0[1]}, d0h = {d0[2], d0[3]}, d1l = {d1[0], d1[1]}, d1h = {d1[2], d1[3]};
+        const f32x2 d2l = {d2[0], d2[1]}, d2h = {d2[2], d2[3]}, d3l = {d3[0], d3[1]}, d3h = {d3[2], d3[3]};
+        dxl[r][0] = w2_pk_sub(d0l, d2l), dxh[r][0] = w2_pk_sub(d0h, d2h);
+        dxl[r][1] = w2_pk_add(d1l, d2l), dxh[r][1] = w2_pk_add(d1h, d2h);
+        dxl[r][2] = w2_pk_sub(d2l, d1l), dxh[r][2] = w2_pk_sub(d2h, d1h);
+        dxl[r][3] = w2_pk_sub(d1l, d3l), dxh[r][3] = w2_pk_sub(d1h, d3h);
       }
       float* dst = timg + t_dst;
 #pragma unroll
       for (int px = 0; px < 4; ++px) {
-        *reinterpret_cast<f32x4*>(dst + (0 * 4 + px) * (24 * 32)) = dx[0][px] - dx[2][px];
-        *reinterpret_cast<f32x4*>(dst + (1 * 4 + px) * (24 * 32)) = dx[1][px] + dx[2][px];
-        *reinterpret_cast<f32x4*>(dst + (2 * 4 + px) * (24 * 32)) = dx[2][px] - dx[1][px];
-        *reinterpret_cast<f32x4*>(dst + (3 * 4 + px) * (24 * 32)) = dx[1][px] - dx[3][px];
+        const f32x2 v0l = w2_pk_sub(dxl[0][px], dxl[2][px]), v0h = w2_pk_sub(dxh[0][px], dxh[2][px]);
+        const f32x2 v1l = w2_pk_add(dxl[1][px], dxl[2][px]), v1h = w2_pk_add(dxh[1][px], dxh[2][px]);
+        const f32x2 v2l = w2_pk_sub(dxl[2][px], dxl[1][px]), v2h = w2_pk_sub(dxh[2][px], dxh[1][px]);
+        const f32x2 v3l = w2_pk_sub(dxl[1][px], dxl[3][px]), v3h = w2_pk_sub(dxh[1][px], dxh[3][px]);
+        *reinterpret_cast<f32x4*>(dst + (0 * 4 + px) * (24 * 32)) = f32x4{v0l[0], v0l[1], v0h[0], v0h[1]};
+        *reinterpret_cast<f32x4*>(dst + (1 * 4 + px) * (24 * 32)) = f32x4{v1l[0], v1l[1], v1h[0], v1h[1]};
+        *reinterpret_cast<f32x4*>(dst + (2 * 4 + px) * (24 * 32)) = f32x4{v2l[0], v2l[1], v2h[0], v2h[1]};
+        *reinterpret_cast<f32x4*>(dst + (3 * 4 + px) * (24 * 32)) = f32x4{v3l[0], v3l[1], v3h[0], v3h[1]};
       }
     }
   };

@@ -763,6 +763,132 @@ __global__ __launch_bounds__(256, 2) void k2_wgrad_mfma_kernel(const void* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same weight gradient for CA <= 16 (fp32; the two stride-2 layers of the top level: P = the 16-channel tensor).  With
+// 32 MFMA rows for 16 channels half of every MFMA was idle; here the two taps of a wave share one MFMA -- rows
+// (tap & 1) * 16 + a -- so a tile is 32 MFMAs per wave instead of 64, the P tile is staged as [voxel][16] (half the LDS and
+// half the staging loads, none of them masked), and the voxel-pair loop is fully unrolled (constant LDS offsets; the
+// rolled loop spent ~10 vector instructions of index arithmetic per pair beside 2 MFMAs).  Same partial layout and reduce
+// kernel (rows a >= 16 of a slab are never written and never used).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k2_wgrad_pair_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                                 float* __restrict__ part, int N, int Dq, int Hq, int Wq, int CA,
+                                                                 int CB, int ntz, int nty, int ntx, int ntiles, int BB32) {
+  __shared__ __attribute__((aligned(16))) float ps[K2W_NV * 16];
+  __shared__ __attribute__((aligned(16))) float qs[K2W_MT * 32];
+  const int Dp = 2 * Dq, Hp = 2 * Hq, Wp = 2 * Wq;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int b0 = (blockIdx.y % BB32) * 32;
+  // this lane's MFMA row: tap 2 wave + (li >> 4), channel li & 15
+  const int tap = wave * 2 + (li >> 4);
+  const int aoff = ((((tap >> 2) * K2W_HY + ((tap >> 1) & 1)) * K2W_HX + (tap & 1)) + 2 * lh) * 16 + (li & 15);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int q4 = tid & 3, q8 = tid & 7;
+  const bool pq_ok = 4 * q4 < CA;
+  const bool qq_ok = b0 + 4 * q8 < CB;
+  constexpr int PE = (K2W_NV * 4) / 256, QE = (K2W_MT * 8) / 256;   // 8 + 2 16-byte loads per thread and tile
+  f32x4 pst[PE], qst[QE];
+  unsigned okmask = 0;
+  int prel[PE], qrel[QE];
+#pragma unroll
+  for (int e = 0; e < PE; ++e) {
+    const int v = (tid + e * 256) >> 2;
+    const int hx = v % K2W_HX, hy = (v / K2W_HX) % K2W_HY, hz = v / (K2W_HX * K2W_HY);
+    prel[e] = ((hz * Hp + hy) * Wp + hx) * CA + 4 * q4;
+  }
+#pragma unroll
+  for (int e = 0; e < QE; ++e) {
+    const int v = (tid + e * 256) >> 3;
+    const int tx = v % K2W_TX, ty = (v / K2W_TX) % K2W_TY, tz = v / (K2W_TX * K2W_TY);
+    qrel[e] = ((tz * Hq + ty) * Wq + tx) * CB + b0 + 4 * q8;
+  }
+  const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz;
+  auto load_tile = [&](int tile) {
+    int b = tile;
+    int qd = seg3d_fdiv(b, rNTX);
+    const int tix = b - qd * ntx; b = qd;
+    qd = seg3d_fdiv(b, rNTY);
+    const int tiy = b - qd * nty; b = qd;
+    qd = seg3d_fdiv(b, rNTZ);
+    const int tiz = b - qd * ntz;
+    const int n = qd;
+    const int z0 = tiz * K2W_TZ, y0 = tiy * K2W_TY, x0 = tix * K2W_TX;
+    if (z0 + K2W_TZ <= Dq && y0 + K2W_TY <= Hq && x0 + K2W_TX <= Wq) {  // whole tile inside the volume
+      const i64 pbase = ((((i64)n * Dp + 2 * z0) * Hp + 2 * y0) * Wp + 2 * x0) * CA;
+      const i64 qbase = ((((i64)n * Dq + z0) * Hq + y0) * Wq + x0) * CB;
+      const unsigned pm = pq_ok ? (1u << PE) - 1u : 0u, qm = qq_ok ? ((1u << QE) - 1u) << PE : 0u;
+#pragma unroll
+      for (int e = 0; e < PE; ++e) pst[e] = *reinterpret_cast<const f32x4*>(P + (pq_ok ? pbase + prel[e] : (i64)0));
+#pragma unroll
+      for (int e = 0; e < QE; ++e) qst[e] = *reinterpret_cast<const f32x4*>(Q + (qq_ok ? qbase + qrel[e] : (i64)0));
+      okmask = pm | qm;
+      return;
+    }
+    okmask = 0;
+#pragma unroll
+    for (int e = 0; e < PE; ++e) {
+      const int v = (tid + e * 256) >> 2;
+      const int hx = v % K2W_HX;
+      const int t = v / K2W_HX;
+      const int hy = t % K2W_HY;
+      const int hz = t / K2W_HY;
+      const int gz = 2 * z0 + hz, gy = 2 * y0 + hy, gx = 2 * x0 + hx;
+      const bool ok = pq_ok && gz < Dp && gy < Hp && gx < Wp;
+      pst[e] = *reinterpret_cast<const f32x4*>(P + (ok ? ((((i64)n * Dp + gz) * Hp + gy) * Wp + gx) * CA + 4 * q4 : (i64)0));
+      okmask |= (ok ? 1u : 0u) << e;
+    }
+#pragma unroll
+    for (int e = 0; e < QE; ++e) {
+      const int v = (tid + e * 256) >> 3;
+      const int tx = v % K2W_TX;
+      const int t = v / K2W_TX;
+      const int ty = t % K2W_TY;
+      const int tz = t / K2W_TY;
+      const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
+      const bool ok = qq_ok && gz < Dq && gy < Hq && gx < Wq;
+      qst[e] = *reinterpret_cast<const f32x4*>(Q + (ok ? ((((i64)n * Dq + gz) * Hq + gy) * Wq + gx) * CB + b0 + 4 * q8 : (i64)0));
+      okmask |= (ok ? 1u : 0u) << (PE + e);
+    }
+  };
+  auto store_tile = [&]() {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < PE; ++e)
+      *reinterpret_cast<f32x4*>(ps + ((tid + e * 256) >> 2) * 16 + 4 * q4) = ((okmask >> e) & 1u) ? pst[e] : zero;
+#pragma unroll
+    for (int e = 0; e < QE; ++e)
+      *reinterpret_cast<f32x4*>(qs + ((tid + e * 256) >> 3) * 32 + 4 * q8) = ((okmask >> (PE + e)) & 1u) ? qst[e] : zero;
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    const float* pa = ps + aoff;
+    const float* qb = qs + lh * 32 + li;
+#pragma unroll
+    for (int kp = 0; kp < K2W_MT / 2; ++kp) {   // voxels 2 kp (lane half 0) and 2 kp + 1: neighbours in one row
+      const int v = 2 * kp;
+      const int tx = v % K2W_TX, ty = (v / K2W_TX) % K2W_TY, tz = v / (K2W_TX * K2W_TY);
+      const float a = pa[(((2 * tz) * K2W_HY + 2 * ty) * K2W_HX + 2 * tx) * 16];
+      const float bvv = qb[v * 32];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc, 0, 0, 0);
+    }
+  }
+  float* dst = part + ((i64)blockIdx.x * gridDim.y + blockIdx.y) * 8 * 1024;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = k2_row(r, lh);
+    dst[(wave * 2 + (row >> 4)) * 1024 + (row & 15) * 32 + li] = acc[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // pair-reduce weight gradient on the bf16 matrix cores (bf16 mode): the tiles stay bf16 in LDS ([voxel][32 channels],
 // 64-byte rows, written by the same register-staged pipeline without widening), and ds_read_b64_tr_b16 -- the transposing
 // LDS read, four rows with independent addresses per 16-lane group -- turns them into the K-major MFMA operands
@@ -963,9 +1089,10 @@ __global__ __launch_bounds__(256) void k2_wgrad_reduce_kernel(const float* __res
   }
 }
 
-static int k2_wgrad_slabs(int N, int Dq, int Hq, int Wq, int npairs) {
+static int k2_wgrad_slabs(int N, int Dq, int Hq, int Wq, int npairs, int CA) {
   const int ntiles = N * seg3d_cdiv(Dq, K2W_TZ) * seg3d_cdiv(Hq, K2W_TY) * seg3d_cdiv(Wq, K2W_TX);
-  int slabs = 512 / npairs;
+  (void)CA;
+  int slabs = 512 / npairs;   // 2 workgroups per CU (4 of the paired-tap kernel measured slower: twice the slabs to reduce)
   if (slabs > (ntiles + 3) / 4) slabs = (ntiles + 3) / 4;
   if (slabs < 1) slabs = 1;
   return slabs;
@@ -973,7 +1100,7 @@ static int k2_wgrad_slabs(int N, int Dq, int Hq, int Wq, int npairs) {
 
 extern "C" long long seg3d_k2_mfma_wgrad_workspace_floats(int N, int Dq, int Hq, int Wq, int CA, int CB) {
   const int npairs = ((CA + 31) / 32) * ((CB + 31) / 32);
-  return (long long)k2_wgrad_slabs(N, Dq, Hq, Wq, npairs) * npairs * 8 * 1024;
+  return (long long)k2_wgrad_slabs(N, Dq, Hq, Wq, npairs, CA) * npairs * 8 * 1024;
 }
 
 // P [N][2Dq][2Hq][2Wq][CA], Q [N][Dq][Hq][Wq][CB];  dw[a*sa + b*sb + t] (t < 8) receives the gradient
@@ -988,7 +1115,7 @@ static int k2_wgrad_launch(const void* P, const void* Q, int bf16, float* dw, fl
   const int ntz = seg3d_cdiv(Dq, K2W_TZ), nty = seg3d_cdiv(Hq, K2W_TY), ntx = seg3d_cdiv(Wq, K2W_TX);
   const int ntiles = N * ntz * nty * ntx;
   SEG3D_REQUIRE((i64)N * ntz * nty * ntx < SEG3D_FDIV_MAX, "seg3d_k2_mfma_wgrad: more than 2^22 tiles");
-  const int slabs = k2_wgrad_slabs(N, Dq, Hq, Wq, npairs);
+  const int slabs = k2_wgrad_slabs(N, Dq, Hq, Wq, npairs, CA);
   hipStream_t s = (hipStream_t)stream;
   if (bf16 && (CA & 7) == 0 && (CB & 7) == 0)
     hipLaunchKernelGGL(k2_wgrad_bf16_mfma_kernel, dim3(slabs, npairs), dim3(256), 0, s,
@@ -997,6 +1124,9 @@ static int k2_wgrad_launch(const void* P, const void* Q, int bf16, float* dw, fl
   else if (bf16)
     hipLaunchKernelGGL(k2_wgrad_mfma_kernel<true>, dim3(slabs, npairs), dim3(256), 0, s, P, Q, workspace, N, Dq, Hq, Wq, CA,
                        CB, ntz, nty, ntx, ntiles, BB32);
+  else if (CA <= 16)   // two taps per MFMA (rows (tap & 1) * 16 + a)
+    hipLaunchKernelGGL(k2_wgrad_pair_kernel, dim3(slabs, npairs), dim3(256), 0, s, reinterpret_cast<const float*>(P),
+                       reinterpret_cast<const float*>(Q), workspace, N, Dq, Hq, Wq, CA, CB, ntz, nty, ntx, ntiles, BB32);
   else
     hipLaunchKernelGGL(k2_wgrad_mfma_kernel<false>, dim3(slabs, npairs), dim3(256), 0, s, P, Q, workspace, N, Dq, Hq, Wq, CA,
                        CB, ntz, nty, ntx, ntiles, BB32);

@@ -140,3 +140,41 @@ def test_two_rank_sharded_sliding_window_matches_single_rank(hip_device, tmp_pat
         assert float((r[k]['probs'] - probs.cpu()).abs().max()) < 1e-6
         assert float((r[k]['mask'] != mask.cpu()).float().mean()) < 1e-4
     assert torch.equal(r[0]['probs'], r[1]['probs']) and torch.equal(r[0]['mask'], r[1]['mask'])
+
+
+def _rccl_worker(rank, world, port, out):
+    from conftest import PKG  # noqa: F401  (sys.path)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # "nccl" IS RCCL on ROCm
+    from segmentation3d.core.seg_train import TrainStep
+    step = TrainStep('vnet', 1, 2, 'Dice', [0.5, 0.5], device=dev, seed=0, distributed=True)   # reducer even for one rank
+    assert step.reducer is not None
+    x, t = _data()
+    losses = [float(step(x.to(dev), t.to(dev))) for _ in range(3)]
+    torch.cuda.synchronize()
+    flat = step.opt._flat[0]
+    torch.save({'grads': flat['grads'].cpu(), 'params': flat['params'].cpu(), 'losses': losses,
+                'overlapped': step.reducer.launched_in_backward, 'backend': dist.get_backend()}, out.format(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_step_equals_local_step(hip_device, tmp_path):
+    """the real RCCL backend on the one test GPU (one rank: RCCL refuses two ranks on one device): process-group init with
+    device_id, the bucketed all-reduce launched from the gradient hooks on the flat buffer, the weight-gradient side-stream
+    joins -- three steps must reproduce the single-process steps exactly (a one-rank sum is the identity)"""
+    port, out = _free_port(), str(tmp_path / 'rccl{}.pt')
+    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    r = torch.load(out.format(0), weights_only=True)
+    assert r['backend'] == 'nccl' and r['overlapped'] == 4
+    from segmentation3d.core.seg_train import TrainStep
+    ref = TrainStep('vnet', 1, 2, 'Dice', [0.5, 0.5], device=hip_device, seed=0, distributed=False)
+    x, t = _data()
+    losses = [float(ref(x.to(hip_device), t.to(hip_device))) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert losses == r['losses'], (losses, r['losses'])
+    assert torch.equal(ref.opt._flat[0]['params'].cpu(), r['params'])

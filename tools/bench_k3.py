@@ -1,4 +1,5 @@
-"""micro-benchmark: direct implicit-GEMM kernel vs Winograd F(2,3) kernel for one C -> C 3x3x3 layer shape
+"""micro-benchmark: direct implicit-GEMM kernel vs the Winograd F(2,3) and F(2x2,3x3) kernels (forward and weight gradient)
+for one C -> C 3x3x3 layer shape, or a list of the network's shapes
 usage: python tools/bench_k3.py N D H W C [iters]"""
 import os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

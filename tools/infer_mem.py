@@ -1,3 +1,6 @@
+"""whole-volume inference jobs back to back with the caching allocator's statistics after each (driver allocations /
+frees per job, reserved bytes): found the ~100 hipMalloc / hipFree calls per job behind the slow inference readings.
+usage: python tools/infer_mem.py [patches per replay]"""
 import os, sys, time, json
 import torch
 REPO = '/root/repo' if os.path.isdir('/root/repo/tools') else os.environ.get('GRAFT_REPO_ROOT', '.')

@@ -143,6 +143,39 @@ template <> struct GnQuad<true> {
 };
 #endif
 
+// (voxel, channel quad, sample) of a grid-stride loop over [total_vox][CQ] quads WITHOUT per-element divisions: idx / CQ and
+// v / S are 64-bit divisions (~70 vector instructions each, two per 16 bytes moved); the walker divides once per thread and
+// then advances by the constant stride with adds and compares
+struct GnWalker {
+  i64 v;       // voxel (row of the [total_vox][C] tensor)
+  i64 vs;      // voxel within its sample
+  int q, n;    // channel quad, sample
+  i64 dv;      // stride / CQ
+  int dq;      // stride % CQ
+  __device__ __forceinline__ GnWalker(i64 idx, i64 stride, int CQ, i64 S) {
+    v = idx / CQ;
+    q = (int)(idx - v * CQ);
+    n = (int)(v / S);
+    vs = v - (i64)n * S;
+    dv = stride / CQ;
+    dq = (int)(stride - dv * CQ);
+  }
+  __device__ __forceinline__ void step(int CQ, i64 S) {
+    q += dq;
+    i64 adv = dv;
+    if (q >= CQ) {
+      q -= CQ;
+      ++adv;
+    }
+    v += adv;
+    vs += adv;
+    while (vs >= S) {
+      vs -= S;
+      ++n;
+    }
+  }
+};
+
 // ---- apply: out = act(gamma*(y-mean)*rstd + beta (+ res)) -------------------------------------------------------
 // RES_BF / OUT_BF (bf16 mode): the residual / the output are bf16 activations; y, statistics and the arithmetic fp32
 template <bool VEC, bool RES_BF, bool OUT_BF, bool Y_BF = false>
@@ -155,10 +188,11 @@ __device__ __forceinline__ void gn_apply_body(const float* __restrict__ y, const
   if (VEC) {
     const int CQ = C >> 2;
     const i64 total = total_vox * CQ;
-    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
-      const i64 v = idx / CQ;
-      const int q = (int)(idx - v * CQ);
-      const int n = (int)(v / S);
+    const i64 stride = (i64)gridDim.x * 256;
+    GnWalker wk((i64)blockIdx.x * 256 + threadIdx.x, stride, CQ, S);
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride, wk.step(CQ, S)) {
+      const i64 v = wk.v;
+      const int q = wk.q, n = wk.n;
       const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
       const seg3d_f32x4 yq = GnQuad<Y_BF>::cvt(GnQuad<Y_BF>::load(y, idx * 4));   // y: bf16 storage when Y_BF
       const float4 yv = make_float4(yq[0], yq[1], yq[2], yq[3]);
@@ -657,10 +691,11 @@ __device__ __forceinline__ void gn_bwd_apply_body(const void* __restrict__ dout_
   if (VEC) {
     const int CQ = C >> 2;
     const i64 total = total_vox * CQ;
-    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (i64)gridDim.x * 256) {
-      const i64 v = idx / CQ;
-      const int q = (int)(idx - v * CQ);
-      const int n = (int)(v / S);
+    const i64 stride = (i64)gridDim.x * 256;
+    GnWalker wk((i64)blockIdx.x * 256 + threadIdx.x, stride, CQ, S);
+    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride, wk.step(CQ, S)) {
+      const i64 v = wk.v;
+      const int q = wk.q, n = wk.n;
       const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
       const float s1 = s12[2 * n], s2 = s12[2 * n + 1];
       const seg3d_f32x4 gq = GnQuad<ACT_BF>::cvt(GnQuad<ACT_BF>::load(dout_v, v * ldd + 4 * q));

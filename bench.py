@@ -61,6 +61,12 @@ def parse():
                     help='one GPU: issue the ~420 launches of a step eagerly instead of replaying the step from one '
                          'hipGraph (core/seg_train.TrainStep use_graph; same kernels, bit-identical losses).  With several '
                          'GPUs the step is always eager: the gradient all-reduce stays outside hipGraphs')
+    ap.add_argument('--step-mode', default='auto', choices=['auto', 'graph', 'eager'],
+                    help='one GPU: how the ~420 launches of a step are issued.  graph = replay of the captured hipGraph; eager '
+                         '= plain launches (what every rank does with several GPUs); auto (default) = both are timed for a few '
+                         'steps after the capture and the faster one runs the warm-up and the timed steps (same kernels, same '
+                         'losses: on a fast host the eager launches overlap the weight-gradient side stream better, on a slow '
+                         'host or with short kernels -- bf16 mode -- the replay wins)')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='enqueue weight-gradient kernels on the main stream (no second HIP stream): use this under '
                          'rocprofv3 --kernel-trace, which serialises concurrent dispatches and distorts their durations')
@@ -380,7 +386,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    args.graph = (world == 1) and not args.no_graph
+    if args.no_graph:
+        args.step_mode = 'eager'
+    args.graph = (world == 1) and args.step_mode != 'eager'
     from segmentation3d.core.seg_train import TrainStep
     from segmentation3d import _ops as _ops_mode
     _ops_mode.set_activation_dtype(args.dtype)
@@ -405,9 +413,33 @@ def main():
             if step._graph is not None or not step.use_graph:
                 break
             step(x, t)
+    run = step
+    probe = None
+    freeze = os.environ.get('SEG3D_BENCH_GC_FREEZE', '1') != '0'
+    if step.use_graph and args.step_mode == 'auto':
+        # time a few steps both ways (after the capture, before the warm-up) and keep the faster issue mode
+        if freeze:
+            import gc
+            gc.collect()
+            gc.freeze()
+        probe = {}
+        for name, fn in (('graph', step), ('eager', step._eager), ('graph', step), ('eager', step._eager)):
+            for _ in range(2):
+                fn(x, t)
+            sync()
+            tp = time.perf_counter()
+            for _ in range(6):
+                fn(x, t)
+            sync()
+            ms = 1e3 * (time.perf_counter() - tp) / 6
+            probe[name] = min(probe.get(name, 1e9), ms)
+        if probe['eager'] < probe['graph']:
+            run = step._eager
+        probe = {k: round(v, 3) for k, v in probe.items()}
+    graph_used = bool(step.use_graph and run is step)
     for _ in range(args.warmup):
-        loss = step(x, t)
-    if not step.use_graph and os.environ.get('SEG3D_BENCH_GC_FREEZE', '1') != '0':
+        loss = run(x, t)
+    if not graph_used and freeze:
         # eager steps (the multi-GPU path): the objects that live for the whole run leave the collector's young generations,
         # so the collections triggered by a step's short-lived autograd objects stay short (standard training-loop practice)
         import gc
@@ -416,7 +448,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step(x, t)
+        loss = run(x, t)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -477,7 +509,7 @@ def main():
                     **winograd_fields(dom, achieved, peak),
                     'note': 'launch durations from 2 instrumented eager steps with the weight-gradient side stream off '
                             '(kernels back to back on one stream, garbage collector parked); value/ms_per_step are '
-                            'measured with the side stream on (hipGraph replay)'}
+                            'measured with the side stream on'}
         # the whole step against the FLOP floor: algorithmic FLOPs of the MFMA convolutions (forward + data-gradient measured
         # live above, weight gradients = one more forward's worth; SURVEY.md 8d: 541.6 GFLOP per 96^3 patch of vnet(1,2))
         step_tflop = 1.5 * sum(e['flops'] for e in table.values()) / 2 / 1e12
@@ -529,7 +561,8 @@ def main():
                        'global_batch': world * args.batch, 'patch': args.patch,
                        'parallelism': 'dp{} (one process per GPU, bucketed {} all-reduce overlapped with backward)'.format(
                            world, collective_lib) if world > 1 else 'single GPU',
-                       'wgrad_overlap': not args.no_wgrad_overlap, 'train_step_hipgraph': bool(args.graph and world == 1)},
+                       'wgrad_overlap': not args.no_wgrad_overlap, 'train_step_hipgraph': graph_used,
+                       'step_mode': args.step_mode, 'step_mode_probe_ms': probe},
             'final_loss': round(final_loss, 6),
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'infer': infer,
         }

@@ -1164,3 +1164,51 @@ def test_connected_components_and_bounding_box(hip_device):
     assert np.array_equal(got, numpy_ref.connected_component_filter(tie, [1], 'largest')) and got[1, 1, 3] == 1 and got[4, 4, 1] == 0
     for sel in (None, [2], [1, 3], [9]):
         assert image_tools.get_bounding_box_device(md, sel) == numpy_ref.get_bounding_box(mask, sel), sel
+
+
+def test_winograd_kernels_random_shapes_against_direct_kernels(hip_device):
+    """40 random supported shapes (batch 1-5, extents in whole tiles, channel counts incl. partial 32-blocks, item counts that
+    are / are not multiples of 8 or exceed the workgroup count): the F(2x2,3x3) / F(2,3) forward kernels and the F(3x3,2x2) /
+    F(3,2) weight gradients against the direct MFMA kernels on the same device tensors (relative error of the difference)"""
+    from segmentation3d import _engine as E
+    g = torch.Generator().manual_seed(2024)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+    worst = {}
+    for case in range(40):
+        N = ri(1, 5)
+        D, H, W = 8 * ri(1, 3), 8 * ri(1, 4), 8 * ri(1, 5)
+        Cin, Cout = 8 * ri(1, 9), 32 * ri(1, 3)
+        x = torch.randn((N, D, H, W, Cin), generator=g).to(hip_device)
+        w = (torch.randn((Cout, Cin, 3, 3, 3), generator=g) * (2.0 / (Cin * 27)) ** 0.5).to(hip_device)
+        b = torch.randn((Cout,), generator=g).to(hip_device)
+        dy = torch.randn((N, D, H, W, Cout), generator=g).to(hip_device)
+        wp27 = torch.empty((E.query('seg3d_packed_mfma_floats', Cin, Cout, 27),), device=hip_device)
+        E.call('seg3d_pack_weights_mfma', E.ptr(w), E.ptr(wp27), Cin, Cout, 27, 27, Cin * 27, 0, E.stream_ptr())
+        yd = torch.empty((N, D, H, W, Cout), device=hip_device)
+        ws = torch.empty((max(1, E.query('seg3d_conv3d_k3_mfma_fwd_workspace_floats', N, D, H, W, Cin, Cout)),), device=hip_device)
+        E.call('seg3d_conv3d_k3_mfma_fwd', E.ptr(x), E.ptr(wp27), E.ptr(b), None, E.ptr(yd), None, E.ptr(ws), N, D, H, W, Cin, Cout,
+               E.stream_ptr())
+        for form, T in (('wino', 36), ('wino2d', 48)):
+            assert E.query('seg3d_conv3d_k3_{}_supported'.format(form), N, D, H, W, Cin, Cout) == 1
+            wp = torch.empty((E.query('seg3d_packed_mfma_floats', Cin, Cout, T),), device=hip_device)
+            E.call('seg3d_pack_weights_mfma', E.ptr(w), E.ptr(wp), Cin, Cout, T, 27, Cin * 27, 0, E.stream_ptr())
+            y = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
+            E.call('seg3d_conv3d_k3_{}_fwd'.format(form), E.ptr(x), E.ptr(wp), E.ptr(b), None, E.ptr(y), None, N, D, H, W, Cin, Cout,
+                   E.stream_ptr())
+            e = float((y - yd).abs().max() / yd.abs().max())
+            worst[form] = max(worst.get(form, 0.0), e)
+            assert e < 2e-5, (form, case, (N, D, H, W, Cin, Cout), e)
+        dwd = torch.empty((Cout, Cin, 3, 3, 3), device=hip_device)
+        wsd = torch.empty((E.query('seg3d_conv3d_k3_mfma_wgrad_workspace_floats', N, D, H, W, Cin, Cout),), device=hip_device)
+        E.call('seg3d_conv3d_k3_mfma_wgrad', E.ptr(x), E.ptr(dy), E.ptr(dwd), E.ptr(wsd), N, D, H, W, Cin, Cout, 0, E.stream_ptr())
+        for form in ('wino', 'wino2d'):
+            dw = torch.full((Cout, Cin, 3, 3, 3), float('nan'), device=hip_device)
+            wsw = torch.empty((E.query('seg3d_conv3d_k3_{}_wgrad_workspace_floats'.format(form), N, D, H, W, Cin, Cout),), device=hip_device)
+            E.call('seg3d_conv3d_k3_{}_wgrad'.format(form), E.ptr(x), E.ptr(dy), E.ptr(dw), E.ptr(wsw), N, D, H, W, Cin, Cout, 0,
+                   E.stream_ptr())
+            e = float((dw - dwd).abs().max() / dwd.abs().max())
+            worst[form + '_wgrad'] = max(worst.get(form + '_wgrad', 0.0), e)
+            assert e < 2e-5, (form + '_wgrad', case, (N, D, H, W, Cin, Cout), e)
+    report('winograd_random_shapes_vs_direct', **worst)

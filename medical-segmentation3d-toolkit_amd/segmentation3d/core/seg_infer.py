@@ -333,11 +333,16 @@ def _job_stream(device, which):
 
 
 def _capture_in_shared_pool(fn, device):
+    """capture fn() into a CUDAGraph whose memory comes from the device's shared volume-graph pool.  Graphs that share a pool
+    must not be alive at the same time unless they replay in capture order (the pool hands a dead temporary's block to the
+    next capture): the shared pool therefore serves ONE live volume graph per device; a second concurrent job (another
+    thread, a nested call) captures into a private pool of its own, as torch.cuda.graph would."""
+    import weakref
     key = device.index if device.index is not None else torch.cuda.current_device()
     entry = _GRAPH_POOLS.get(key)
     cur = torch.cuda.current_stream()
-    stream = _job_stream(device, 'capture')
     if entry is None:
+        stream = _job_stream(device, 'capture')
         pool = torch.cuda.graph_pool_handle()
         keep = torch.cuda.CUDAGraph()
         anchor = torch.zeros(1, device=device)
@@ -347,16 +352,24 @@ def _capture_in_shared_pool(fn, device):
             anchor.add_(1.0)
             keep.capture_end()
         cur.wait_stream(stream)
-        entry = _GRAPH_POOLS[key] = (pool, keep, anchor)
+        entry = _GRAPH_POOLS[key] = {'pool': pool, 'keep': keep, 'anchor': anchor, 'live': 0}
+    shared = entry['live'] == 0
+    stream = _job_stream(device, 'capture') if shared else torch.cuda.Stream(device=device)
     graph = torch.cuda.CUDAGraph()
     stream.wait_stream(cur)
     with torch.cuda.stream(stream):
-        graph.capture_begin(pool=entry[0])
+        graph.capture_begin(pool=entry['pool'] if shared else torch.cuda.graph_pool_handle())
         try:
             fn()
         finally:
             graph.capture_end()
     cur.wait_stream(stream)
+    if shared:
+        entry['live'] += 1
+
+        def _released(e=entry):
+            e['live'] -= 1
+        weakref.finalize(graph, _released)
     return graph
 
 

@@ -11,8 +11,8 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 say() { echo "$(date +%T) $*" >> $O/progress.log; }
-COMMON="--steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-wgrad-overlap"
-PM="--steps 3 --warmup 1 --no-infer --no-cpu-baseline --no-wgrad-overlap"
+COMMON="--steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-wgrad-overlap --step-mode graph"
+PM="--steps 3 --warmup 1 --no-infer --no-cpu-baseline --no-wgrad-overlap --step-mode graph"
 say "fp32 kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp32 -o k -- python3 $R/bench.py $COMMON --kernel-report $O/fp32_shapes.json > $O/fp32_prof.log 2>&1
 say "fp32 FETCH_SIZE"
@@ -32,6 +32,8 @@ say "bf16 FETCH / WRITE"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/bf16_fetch -o p -- python3 $R/bench.py $PM --dtype bf16 > $O/bf16_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/bf16_write -o p -- python3 $R/bench.py $PM --dtype bf16 > $O/bf16_write.log 2>&1
 fi
+# the per-dispatch traces are not needed (statistics and counter tables are) and gpurun returns at most 64 MiB
+find $O -name "*_kernel_trace.csv" -delete
 cd $R
 say "unprofiled bench lines"
 python3 bench.py > $O/fp32_bench_line.log 2>&1

@@ -744,6 +744,85 @@ __global__ __launch_bounds__(64 * G) void conv3d_k3_wgrad_wino2d_reduce_kernel(c
   }
 }
 
+// The same reduce for MANY slabs (>= 64: the 32- and 64-channel levels).  The kernel above has 12 workgroups per block pair
+// (one lane per (kz, a, b quad), 16 loads per lane and slab, G waves over the slabs): 50 MB of slabs at 1.7 TB/s.  Here a
+// lane owns ONE point row (py: four of the sixteen loads) of one (kz, a, b quad), a workgroup of 16 waves takes 16 such
+// positions with its waves striding over the slabs -- 48 workgroups per block pair and four times the loads in flight --
+// and the rows meet in LDS for the output transform.  Same fixed summation order per output (slabs g, g + 16, .. summed
+// per wave, then waves 0..15): bitwise reproducible, but a different order than the kernel above.
+__global__ __launch_bounds__(1024) void conv3d_k3_wgrad_wino2d_reduce16_kernel(const float* __restrict__ part,
+                                                                                 float* __restrict__ dw, int slabs, int A, int B,
+                                                                                 int BB32, int npairs, i64 sa, i64 sb,
+                                                                                 int accumulate) {
+  __shared__ f32x4 red[16 * 64 * 4];                            // [wave][lane][px]: 64 KB
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int ql = lane & 15, py = lane >> 4;
+  const i64 qidx = (i64)blockIdx.x * 16 + ql;                   // position (pair, kz, a, b quad); their count is a multiple of 16
+  const i64 slabq = (i64)npairs * 48 * 256;                     // float4 quads per slab
+  f32x4 s[4];
+#pragma unroll
+  for (int px = 0; px < 4; ++px) s[px] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const i64 r3 = qidx >> 8;                                   // pair * 3 + kz
+    const f32x4* p0 = reinterpret_cast<const f32x4*>(part) + (r3 * 16 + py * 4) * 256 + (qidx & 255);
+    for (int k = g; k < slabs; k += 16) {
+      const f32x4* q = p0 + (i64)k * slabq;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) s[px] += q[px * 256];
+    }
+  }
+#pragma unroll
+  for (int px = 0; px < 4; ++px) red[(g * 64 + lane) * 4 + px] = s[px];
+  __syncthreads();
+  if (g == 0) {
+    // this lane's point row over all 16 waves, back into LDS (slot of wave 0), then every lane reads the four rows of its
+    // position: lanes with py < 3 produce the output row ky = py
+#pragma unroll
+    for (int j = 1; j < 16; ++j)
+#pragma unroll
+      for (int px = 0; px < 4; ++px) s[px] += red[(j * 64 + lane) * 4 + px];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) red[lane * 4 + px] = s[px];
+  }
+  __syncthreads();
+  if (g == 0 && py < 3) {
+    f32x4 m[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int px = 0; px < 4; ++px) m[r][px] = red[((r * 16 + ql)) * 4 + px];
+    f32x4 rw[4];   // output row ky = py of A'^T M
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const f32x4 hs = (m[1][px] + m[2][px]) * 0.5f, hd = (m[1][px] - m[2][px]) * 0.5f;
+      rw[px] = py == 0 ? m[0][px] + hs : (py == 1 ? hd : hs - m[3][px]);
+    }
+    const f32x4 hs = (rw[1] + rw[2]) * 0.5f, hd = (rw[1] - rw[2]) * 0.5f;
+    const f32x4 w0 = rw[0] + hs, w1 = hd, w2 = hs - rw[3];
+    const int b32 = (int)((qidx & 7) * 4), a32 = (int)((qidx >> 3) & 31);
+    const i64 r3 = qidx >> 8;
+    const int kz = (int)(r3 % 3);
+    const int pair = (int)(r3 / 3);
+    const int a = (pair / BB32) * 32 + a32, b = (pair % BB32) * 32 + b32;
+    if (a < A) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (b + j < B) {
+          float* d = dw + a * sa + (b + j) * sb + kz * 9 + py * 3;
+          if (accumulate) {
+            d[0] += w0[j];
+            d[1] += w1[j];
+            d[2] += w2[j];
+          } else {
+            d[0] = w0[j];
+            d[1] = w1[j];
+            d[2] = w2[j];
+          }
+        }
+    }
+  }
+}
+
 static int g2_slabs(int N, int D, int H, int W, int Cin, int Cout) {
   const i64 ntiles = (i64)N * (D / 4) * (H / 4) * (W / 4);
   const int npairs = ((Cin + 31) / 32) * ((Cout + 31) / 32);
@@ -762,13 +841,13 @@ extern "C" int seg3d_conv3d_k3_wino2d_wgrad_supported(int N, int D, int H, int W
   return 1;
 }
 
-// ... and where it is the faster choice (else F(3, 2) along x, conv_wino.hip): enough tiles per workgroup to amortise its
-// 48 partial accumulators, or few slabs to reduce
+// ... and where it is the faster choice (else F(3, 2) along x, conv_wino.hip): enough tiles per workgroup (>= 10) to amortise
+// its 48 partial accumulators
 extern "C" int seg3d_conv3d_k3_wino2d_wgrad_preferred(int N, int D, int H, int W, int Cin, int Cout) {
   if (!seg3d_conv3d_k3_wino2d_wgrad_supported(N, D, H, W, Cin, Cout)) return 0;
   const int slabs = g2_slabs(N, D, H, W, Cin, Cout);
   const long long ntiles = (long long)N * (D / 4) * (H / 4) * (W / 4);
-  return ntiles >= 40ll * slabs || (slabs <= 8 && ntiles >= 16ll * slabs);
+  return ntiles >= 10ll * slabs;
 }
 
 extern "C" long long seg3d_conv3d_k3_wino2d_wgrad_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
@@ -803,7 +882,10 @@ extern "C" int seg3d_conv3d_k3_wino2d_wgrad(const float* x, const float* dy, flo
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_wgrad");
   const i64 totalq = (i64)npairs * 3 * 256;
   const unsigned grid = (unsigned)((totalq + 63) / 64);
-  if (slabs >= 16)
+  if (slabs >= 64)
+    hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_reduce16_kernel, dim3((unsigned)(totalq / 16)), dim3(1024), 0, s, workspace, dw,
+                       slabs, Cin, Cout, COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
+  else if (slabs >= 16)
     hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_reduce_kernel<4>, dim3(grid), dim3(256), 0, s, workspace, dw, slabs, Cin, Cout,
                        COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
   else

@@ -448,7 +448,7 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
 // tile's RAW x halo tile (6^3 voxels) and dy tile arrive by (inline-assembly) LDS-DMA behind the first K steps, branch-free;
 // between two tiles 192 threads transform RAW x into T[p][z][quad][32 ci] (two barriers per tile); E is formed from the raw
 // dy quad in registers (4 FMAs / adds per 12 MFMAs).  Partial slabs [slab][pair][48][32][32] are reduced in fixed order,
-// and turned into the 27 taps, by conv3d_k3_wgrad_wino2d_reduce_kernel (bitwise reproducible).
+// and turned into the 27 taps, by conv3d_k3_wgrad_wino2d_reduce16_kernel (bitwise reproducible).
 // A tile is only 96 MFMAs per wave (2.6 us): too short to cover a DMA issued in the same tile, so tiles are fetched TWO
 // ahead (RAW x double-, dy triple-buffered; the wait before the barrier is vmcnt(pieces of one tile), not 0).
 // LDS: 2 x 27 KB RAW x + T 48 KB + 3 x 8 KB dy = 126 KB.
@@ -678,83 +678,18 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
 
 // dw[a*sa + b*sb + kz*9 + ky*3 + kx] from  M[py][px] = sum_slab part[slab][a/32][b/32][kz*16 + py*4 + px][a%32][b%32]:
 //   dW[kz] = A'^T M A',  A'^T = [1 1/2 1/2 0; 0 1/2 -1/2 0; 0 1/2 1/2 -1].
-// A lane owns four consecutive b of one (pair, kz, a); the G waves of a workgroup take the slabs k = g, g + G, ..; partial
-// sums are combined through LDS in a fixed order.
+// A lane owns ONE point row (py: four 16-byte loads per slab) of one position (pair, kz, a, b quad); a workgroup takes 16
+// positions with its G waves striding over the slabs (G = 16 from 64 slabs up: 48 workgroups per block pair and 64 KB of
+// loads in flight each; G = 4 below); per-wave sums meet in LDS in a fixed order (slabs g, g + G, .. per wave, then waves
+// 0..G-1: bitwise reproducible), the four rows of a position meet in LDS for the output transform, and lanes py < 3 write
+// the output row ky = py.  (The first form -- one lane per position, 16 loads per slab, 12 workgroups per block pair, 36
+// scattered scalar stores per lane -- ran 50 MB of slabs at 1.7 TB/s: 29 us where this one takes 15.)
 template <int G>
-__global__ __launch_bounds__(64 * G) void conv3d_k3_wgrad_wino2d_reduce_kernel(const float* __restrict__ part,
+__global__ __launch_bounds__(64 * G) void conv3d_k3_wgrad_wino2d_reduce16_kernel(const float* __restrict__ part,
                                                                                  float* __restrict__ dw, int slabs, int A, int B,
                                                                                  int BB32, int npairs, i64 sa, i64 sb,
                                                                                  int accumulate) {
-  __shared__ f32x4 red[G * 64 * 16];
-  const i64 totalq = (i64)npairs * 3 * 256;                     // (pair, kz, a, b quad)
-  const i64 qidx = (i64)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int g = threadIdx.x >> 6;
-  f32x4 s[16];
-#pragma unroll
-  for (int p = 0; p < 16; ++p) s[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const i64 slabq = (i64)npairs * 48 * 256;                     // float4 quads per slab
-  if (qidx < totalq) {
-    const i64 r3 = qidx >> 8;                                   // pair * 3 + kz
-    const f32x4* p0 = reinterpret_cast<const f32x4*>(part) + r3 * 16 * 256 + (qidx & 255);
-    for (int k = g; k < slabs; k += G) {
-      const f32x4* q = p0 + (i64)k * slabq;
-#pragma unroll
-      for (int p = 0; p < 16; ++p) s[p] += q[p * 256];
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < 16; ++p) red[(p * G + g) * 64 + (threadIdx.x & 63)] = s[p];
-  __syncthreads();
-  if (g == 0 && qidx < totalq) {
-#pragma unroll
-    for (int j = 1; j < G; ++j)
-#pragma unroll
-      for (int p = 0; p < 16; ++p) s[p] += red[(p * G + j) * 64 + threadIdx.x];
-    // rows (py -> ky), then columns (px -> kx)
-    f32x4 rw[3][4];
-#pragma unroll
-    for (int px = 0; px < 4; ++px) {
-      const f32x4 hs = (s[4 + px] + s[8 + px]) * 0.5f, hd = (s[4 + px] - s[8 + px]) * 0.5f;
-      rw[0][px] = s[px] + hs;
-      rw[1][px] = hd;
-      rw[2][px] = hs - s[12 + px];
-    }
-    f32x4 wv[3][3];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const f32x4 hs = (rw[ky][1] + rw[ky][2]) * 0.5f, hd = (rw[ky][1] - rw[ky][2]) * 0.5f;
-      wv[ky][0] = rw[ky][0] + hs;
-      wv[ky][1] = hd;
-      wv[ky][2] = hs - rw[ky][3];
-    }
-    const int b32 = (int)((qidx & 7) * 4), a32 = (int)((qidx >> 3) & 31);
-    const i64 r3 = qidx >> 8;
-    const int kz = (int)(r3 % 3);
-    const int pair = (int)(r3 / 3);
-    const int a = (pair / BB32) * 32 + a32, b = (pair % BB32) * 32 + b32;
-    if (a < A) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (b + j < B) {
-          float* d = dw + a * sa + (b + j) * sb + kz * 9;
-#pragma unroll
-          for (int t = 0; t < 9; ++t) d[t] = accumulate ? d[t] + wv[t / 3][t % 3][j] : wv[t / 3][t % 3][j];
-        }
-    }
-  }
-}
-
-// The same reduce for MANY slabs (>= 64: the 32- and 64-channel levels).  The kernel above has 12 workgroups per block pair
-// (one lane per (kz, a, b quad), 16 loads per lane and slab, G waves over the slabs): 50 MB of slabs at 1.7 TB/s.  Here a
-// lane owns ONE point row (py: four of the sixteen loads) of one (kz, a, b quad), a workgroup of 16 waves takes 16 such
-// positions with its waves striding over the slabs -- 48 workgroups per block pair and four times the loads in flight --
-// and the rows meet in LDS for the output transform.  Same fixed summation order per output (slabs g, g + 16, .. summed
-// per wave, then waves 0..15): bitwise reproducible, but a different order than the kernel above.
-__global__ __launch_bounds__(1024) void conv3d_k3_wgrad_wino2d_reduce16_kernel(const float* __restrict__ part,
-                                                                                 float* __restrict__ dw, int slabs, int A, int B,
-                                                                                 int BB32, int npairs, i64 sa, i64 sb,
-                                                                                 int accumulate) {
-  __shared__ f32x4 red[16 * 64 * 4];                            // [wave][lane][px]: 64 KB
+  __shared__ f32x4 red[G * 64 * 4];                             // [wave][lane][px]: 64 KB at G = 16
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int ql = lane & 15, py = lane >> 4;
   const i64 qidx = (i64)blockIdx.x * 16 + ql;                   // position (pair, kz, a, b quad); their count is a multiple of 16
@@ -765,7 +700,7 @@ __global__ __launch_bounds__(1024) void conv3d_k3_wgrad_wino2d_reduce16_kernel(c
   {
     const i64 r3 = qidx >> 8;                                   // pair * 3 + kz
     const f32x4* p0 = reinterpret_cast<const f32x4*>(part) + (r3 * 16 + py * 4) * 256 + (qidx & 255);
-    for (int k = g; k < slabs; k += 16) {
+    for (int k = g; k < slabs; k += G) {
       const f32x4* q = p0 + (i64)k * slabq;
 #pragma unroll
       for (int px = 0; px < 4; ++px) s[px] += q[px * 256];
@@ -778,7 +713,7 @@ __global__ __launch_bounds__(1024) void conv3d_k3_wgrad_wino2d_reduce16_kernel(c
     // this lane's point row over all 16 waves, back into LDS (slot of wave 0), then every lane reads the four rows of its
     // position: lanes with py < 3 produce the output row ky = py
 #pragma unroll
-    for (int j = 1; j < 16; ++j)
+    for (int j = 1; j < G; ++j)
 #pragma unroll
       for (int px = 0; px < 4; ++px) s[px] += red[(j * 64 + lane) * 4 + px];
 #pragma unroll
@@ -881,16 +816,13 @@ extern "C" int seg3d_conv3d_k3_wino2d_wgrad(const float* x, const float* dy, flo
                      dy, workspace, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, COB32);
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_wgrad");
   const i64 totalq = (i64)npairs * 3 * 256;
-  const unsigned grid = (unsigned)((totalq + 63) / 64);
+  // one point row per lane; 16 waves over the slabs where there are many of them, 4 otherwise
   if (slabs >= 64)
-    hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_reduce16_kernel, dim3((unsigned)(totalq / 16)), dim3(1024), 0, s, workspace, dw,
+    hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_reduce16_kernel<16>, dim3((unsigned)(totalq / 16)), dim3(1024), 0, s, workspace, dw,
                        slabs, Cin, Cout, COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
-  else if (slabs >= 16)
-    hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_reduce_kernel<4>, dim3(grid), dim3(256), 0, s, workspace, dw, slabs, Cin, Cout,
-                       COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
   else
-    hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_reduce_kernel<2>, dim3(grid), dim3(128), 0, s, workspace, dw, slabs, Cin, Cout,
-                       COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
+    hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_reduce16_kernel<4>, dim3((unsigned)(totalq / 16)), dim3(256), 0, s, workspace, dw,
+                       slabs, Cin, Cout, COB32, npairs, (i64)27, (i64)Cin * 27, accumulate);
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_wgrad(reduce)");
   return SEG3D_OK;
 }

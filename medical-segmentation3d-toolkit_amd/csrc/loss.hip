@@ -125,31 +125,49 @@ __global__ __launch_bounds__(256) void dice_partial_kernel(const float* __restri
 }
 
 // sums[n][c] = (I, P2 + T) in fp32 for the backward; loss = sum_c w_c mean_n (1 - (2I + eps)/(P2 + T + eps))
+// One workgroup; 32 lanes per (n, c) stride over the partial blocks (fp64, then a fixed-shape shuffle tree: reproducible).
+// The first form walked the nblk blocks of a (n, c) with ONE thread -- 8 threads busy, 34 us on the loss's critical path.
 __global__ __launch_bounds__(256) void dice_finalize_kernel(const float* __restrict__ part,
                                                               const float* __restrict__ weights, float* __restrict__ sums,
                                                               float* __restrict__ loss, int N, int C, int nblk) {
-  __shared__ double red[4];
+  __shared__ double red[8];
+  const int grp = threadIdx.x >> 5, l32 = threadIdx.x & 31;
   double acc = 0.0;
-  for (int idx = threadIdx.x; idx < N * C; idx += 256) {
-    const int n = idx / C, c = idx % C;
+  for (int idx0 = 0; idx0 < N * C; idx0 += 8) {   // uniform trip count: the shuffles below need whole waves
+    const int idx = idx0 + grp;
+    const bool ok = idx < N * C;
+    const int n = ok ? idx / C : 0, c = ok ? idx % C : 0;
     double I = 0.0, P2 = 0.0, T = 0.0;
-    const float* p = part + ((i64)n * nblk * C + c) * 3;
-    for (int k = 0; k < nblk; ++k) {
-      I += (double)p[(i64)k * C * 3 + 0];
-      P2 += (double)p[(i64)k * C * 3 + 1];
-      T += (double)p[(i64)k * C * 3 + 2];
+    if (ok) {
+      const float* p = part + ((i64)n * nblk * C + c) * 3;
+      for (int k = l32; k < nblk; k += 32) {
+        I += (double)p[(i64)k * C * 3 + 0];
+        P2 += (double)p[(i64)k * C * 3 + 1];
+        T += (double)p[(i64)k * C * 3 + 2];
+      }
     }
-    const float If = (float)I, sumf = (float)(P2 + T);
-    sums[2 * idx + 0] = If;
-    sums[2 * idx + 1] = sumf;
-    const float eps = 1e-6f;
-    const float l = 1.0f - (2.0f * If + eps) / (sumf + eps);
-    acc += (double)weights[c] * (double)l / (double)N;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {   // within the 32-lane group (width 32: never crosses into the other group)
+      I += __shfl_down(I, off, 32);
+      P2 += __shfl_down(P2, off, 32);
+      T += __shfl_down(T, off, 32);
+    }
+    if (ok && l32 == 0) {
+      const float If = (float)I, sumf = (float)(P2 + T);
+      sums[2 * idx + 0] = If;
+      sums[2 * idx + 1] = sumf;
+      const float eps = 1e-6f;
+      const float l = 1.0f - (2.0f * If + eps) / (sumf + eps);
+      acc += (double)weights[c] * (double)l / (double)N;
+    }
   }
-  acc = wave_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  if (l32 == 0) red[grp] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) loss[0] = (float)(red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int g = 0; g < 8; ++g) t += red[g];
+    loss[0] = (float)t;
+  }
 }
 
 // dprobs[n][c][s] = gout * w_c / N * [p > thresh] * -(2 t (sum + eps) - (2 I + eps) 2 p) / (sum + eps)^2

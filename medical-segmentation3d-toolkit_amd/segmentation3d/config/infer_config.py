@@ -6,7 +6,7 @@ __C = edict()
 cfg = __C
 
 __C.general = {}
-__C.general.single_scale = 'fine'                      # 'coarse' | 'fine' | 'DISABLE' (= coarse-to-fine cascade)
+__C.general.single_scale = 'DISABLE'                   # 'coarse' | 'fine' | 'DISABLE' (= coarse-to-fine cascade)
 
 __C.coarse = {}
 __C.coarse.model_name = 'coarse'

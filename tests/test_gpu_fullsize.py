@@ -1,0 +1,212 @@
+"""Full-size parity gates: the BASELINE configurations at the sizes bench.py quotes, each whole network against
+oracle/torch_ref (the stock torch CPU operators the reference composes) with the C-ABI entry points that ran recorded
+and asserted -- so every number DESIGN.md quotes for the 4 x 96^3 step, vbnet and the 128^3 patch has a checker behind
+the kernel instantiations those sizes select.  Bar (north_star): probabilities and loss within 1e-4 in fp32; gradient
+norms to 2e-2 (whole-network gradients move by up to ~1e-3 when a ReLU input of magnitude 1e-6 lands on the other side
+of zero under another summation order, tests/test_gpu_parity.py); bf16 mode to its own stated tolerance
+(tests/test_gpu_bf16.py: probabilities max 3e-2 / mean 3e-3, loss 3e-3)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import report, max_err, rel_err
+from oracle import detgen, torch_ref
+
+pytestmark = pytest.mark.gpu
+
+WINO_FWD = 'seg3d_conv3d_k3_wino2d_fwd'
+WINO_WGRADS = ('seg3d_conv3d_k3_wino2d_wgrad', 'seg3d_conv3d_k3_wino_wgrad')
+
+
+def _load(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = detgen.state_dict_like(shapes, seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return sd
+
+
+class _Spy(object):
+    """records the name of every int-returning C-ABI entry point called through segmentation3d._engine.call"""
+
+    def __init__(self, monkeypatch):
+        from segmentation3d import _engine as E
+        self.called = []
+        orig = E.call
+
+        def spy(fn, *a):
+            self.called.append(fn)
+            return orig(fn, *a)
+        monkeypatch.setattr(E, 'call', spy)
+
+    def counts(self, *names):
+        return {n: self.called.count(n) for n in names}
+
+
+def _grad_errors(params, ref_sd, keys):
+    names = sorted(params)
+    gn_ref = np.array([float(ref_sd[k].grad.double().norm()) for k in names])
+    gn_got = np.array([float(params[k].grad.double().norm()) for k in names])
+    e = dict(gradnorm=float(np.max(np.abs(gn_got - gn_ref) / (gn_ref + 1e-6 * gn_ref.max()))))
+    for tag, k in keys.items():
+        e['g_' + tag] = rel_err(params[k].grad, ref_sd[k].grad)
+    return e
+
+
+def test_headline_train_step_4x96_vnet_1_2(hip_device, monkeypatch):
+    """BASELINE config 2 exactly as bench.py runs it: vnet(1,2), batch of FOUR 96^3 patches, forward + Dice + backward +
+    Adam (gradient sinks, packed-weight cache, weight gradients on the side stream) against the oracle's train step
+    (core/seg_train.py:119-127).  The 4-patch backward is where the largest Winograd weight-gradient launches (most slabs,
+    the 16-wave reduce) and the 4 x 96^3 data-gradients run."""
+    from segmentation3d import _ops
+    from segmentation3d.network import vnet
+    from segmentation3d.loss.multi_dice_loss import MultiDiceLoss
+    from segmentation3d.optim.fused_adam import FusedAdam
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    spy = _Spy(monkeypatch)
+    net = vnet.SegmentationNet(1, 2)
+    sd = _load(net, 21)
+    net = net.to(hip_device)
+    x4 = torch.from_numpy(detgen.normal(91, 'full/x', (4, 1, 96, 96, 96))).clamp_(-3, 3)
+    t4 = torch.from_numpy(detgen.labels(92, 'full/t', (4, 1, 96, 96, 96), 2))
+    lr = 1e-4
+    prev_cache = _ops.weight_cache(True)
+    try:
+        opt = FusedAdam(net.parameters(), lr=lr, betas=(0.9, 0.999))
+        opt.zero_grad()
+        probs = net(x4.to(hip_device))
+        loss = MultiDiceLoss([0.5, 0.5], 2, use_gpu=True)(probs, t4.to(hip_device))
+        loss.backward()
+        torch.cuda.synchronize()
+        params = dict(net.named_parameters())
+        grads = {k: p.grad.detach().clone() for k, p in params.items()}
+        opt.step()
+        torch.cuda.synchronize()
+        after = {k: p.detach().cpu().clone() for k, p in params.items()}
+        opt.release_grad_sinks()
+    finally:
+        _ops.weight_cache(prev_cache)
+        _ops.PACK_CACHE.clear()
+    ref_sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
+    ref_opt = torch.optim.Adam(list(ref_sd.values()), lr=lr, betas=(0.9, 0.999))
+    ref_opt.zero_grad()
+    rp = torch_ref.segmentation_net(x4, ref_sd, 'vnet')
+    rl = torch_ref.multi_dice_loss(rp, t4, [0.5, 0.5])
+    rl.backward()
+    ref_grads = {k: v.grad.detach().clone() for k, v in ref_sd.items()}
+    ref_opt.step()
+
+    class _G(object):       # adapter: _grad_errors reads `.grad`
+        def __init__(self, g):
+            self.grad = g
+    e = dict(probs=max_err(probs, rp), loss=abs(float(loss) - float(rl)))
+    e.update(_grad_errors({k: _G(g) for k, g in grads.items()}, {k: _G(g) for k, g in ref_grads.items()},
+                          dict(stem='in_block.conv.weight', up32='up_32.rblock.ops.0.conv.weight', down32='down_32.rblock.ops.0.conv.weight',
+                               up64='up_64.rblock.ops.1.conv.weight', down32s='down_32.down_conv.weight', up32t='up_32.up_conv.weight',
+                               head='out_block.conv1.weight', gn='up_32.rblock.ops.0.gn.weight')))
+    # Adam's first update is lr * g / (|g| + 1e-8): it only differs where a gradient is rounding noise
+    moved = np.concatenate([((after[k] - ref_sd[k].detach()).abs() > 0.1 * lr).numpy().ravel() for k in after])
+    e['adam_update_off_fraction'] = float(moved.mean())
+    c = spy.counts(WINO_FWD, *WINO_WGRADS, 'seg3d_conv3d_k3_mfma_fwd', 'seg3d_adam_step')
+    report('headline_train_step_4x96', **e, **{k.replace('seg3d_conv3d_k3_', 'n_'): float(v) for k, v in c.items()})
+    assert e['probs'] < 1e-4 and e['loss'] < 1e-4, e
+    assert all(v < 2e-2 for k, v in e.items() if k.startswith('g')), e
+    assert e['adam_update_off_fraction'] < 1e-2, e
+    # the kernels the bench line is quoted on ran: 96^3 / 48^3 / 24^3 levels, forward (9) + data-gradient (9)
+    assert c[WINO_FWD] == 18, c
+    assert c[WINO_WGRADS[0]] + c[WINO_WGRADS[1]] >= 12 and c[WINO_WGRADS[0]] >= 9, c
+    assert c['seg3d_adam_step'] == 1, c
+
+
+@pytest.mark.parametrize('plugin', ['vbnet'])
+def test_vbnet_one_patch_96(hip_device, plugin, monkeypatch):
+    """the reference's DEFAULT plugin (config/train_config.py:106) at the bench size: vbnet(1,2), one 96^3 patch, forward +
+    Dice + backward against the oracle.  Its bottleneck units select kernel shapes no 32^3 fixture reaches (64 -> 16,
+    16 -> 16, 16 -> 64 at 24^3; 32 -> 32, 128 -> 32 at 12^3 / 24^3)"""
+    from segmentation3d.loss.multi_dice_loss import MultiDiceLoss
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    spy = _Spy(monkeypatch)
+    mod = importlib.import_module('segmentation3d.network.' + plugin)
+    net = mod.SegmentationNet(1, 2)
+    sd = _load(net, 21)
+    net = net.to(hip_device)
+    x = torch.from_numpy(detgen.normal(93, 'fullvb/x', (1, 1, 96, 96, 96))).clamp_(-3, 3)
+    t = torch.from_numpy(detgen.labels(94, 'fullvb/t', (1, 1, 96, 96, 96), 2))
+    ref_sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
+    rp = torch_ref.segmentation_net(x, ref_sd, plugin)
+    rl = torch_ref.multi_dice_loss(rp, t, [0.5, 0.5])
+    rl.backward()
+    probs = net(x.to(hip_device))
+    loss = MultiDiceLoss([0.5, 0.5], 2, use_gpu=True)(probs, t.to(hip_device))
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(net.named_parameters())
+    e = dict(probs=max_err(probs, rp), loss=abs(float(loss) - float(rl)))
+    e.update(_grad_errors(params, ref_sd, dict(stem='in_block.conv.weight', up32='up_32.rblock.ops.0.conv.weight',
+                                               bott1='down_64.rblock.ops.0.conv1.conv.weight', bott2='down_64.rblock.ops.0.conv2.conv.weight',
+                                               bott3='down_128.rblock.ops.2.conv3.conv.weight', up256='up_256.rblock.ops.1.conv2.conv.weight',
+                                               head='out_block.conv1.weight')))
+    c = spy.counts(WINO_FWD, *WINO_WGRADS, 'seg3d_conv3d_k3_mfma_fwd', 'seg3d_conv3d_k3_mfma_wgrad')
+    report('vbnet_1x96', **e, **{k.replace('seg3d_conv3d_k3_', 'n_'): float(v) for k, v in c.items()})
+    assert e['probs'] < 1e-4 and e['loss'] < 1e-4, e
+    assert all(v < 2e-2 for k, v in e.items() if k.startswith('g')), e
+    assert c[WINO_FWD] >= 2 and c[WINO_WGRADS[0]] + c[WINO_WGRADS[1]] >= 1, c
+
+
+def test_vnet_4_4_one_patch_128_fp32_and_bf16(hip_device, monkeypatch):
+    """BASELINE config 5's network at its patch size: vnet(4,4), one 128^3 patch.  fp32 against the oracle (1e-4 bar);
+    bf16 mode against the fp32 engine and the oracle at the bf16 tolerance stated in tests/test_gpu_bf16.py.  A 128^3 patch
+    puts 128^3 / 64^3 / 32^3 / 16^3 / 8^3 levels under the tile plans instead of 96 / 48 / 24 / 12 / 6."""
+    from segmentation3d import _ops
+    from segmentation3d.network import vnet
+    from segmentation3d.loss.multi_dice_loss import MultiDiceLoss
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    spy = _Spy(monkeypatch)
+    net = vnet.SegmentationNet(4, 4)
+    sd = _load(net, 21)
+    net = net.to(hip_device)
+    x = torch.from_numpy(detgen.normal(95, 'full128/x', (1, 4, 128, 128, 128))).clamp_(-3, 3)
+    t = torch.from_numpy(detgen.labels(96, 'full128/t', (1, 1, 128, 128, 128), 4))
+    w = [1.0, 1.0, 1.0, 1.0]
+    ref_sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
+    rp = torch_ref.segmentation_net(x, ref_sd, 'vnet')
+    rl = torch_ref.multi_dice_loss(rp, t, w)
+    rl.backward()
+    res = {}
+    for mode in ('fp32', 'bf16'):
+        del spy.called[:]
+        with _ops.activation_dtype(mode):
+            _ops.PACK_CACHE.clear()
+            net.zero_grad()
+            probs = net(x.to(hip_device))
+            loss = MultiDiceLoss(w, 4, use_gpu=True)(probs, t.to(hip_device))
+            loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (probs.detach().clone(), float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters()},
+                     list(spy.called))
+    _ops.PACK_CACHE.clear()
+    p32, l32, g32, calls32 = res['fp32']
+    params = dict(net.named_parameters())
+    for k, p in params.items():
+        p.grad = g32[k]
+    e = dict(probs=max_err(p32, rp), loss=abs(l32 - float(rl)))
+    e.update(_grad_errors(params, ref_sd, dict(stem='in_block.conv.weight', up32='up_32.rblock.ops.0.conv.weight',
+                                               down256='down_256.rblock.ops.1.conv.weight', head='out_block.conv1.weight')))
+    c32 = {n: calls32.count(n) for n in (WINO_FWD,) + WINO_WGRADS}
+    report('vnet_4_4_1x128_fp32', **e, **{k.replace('seg3d_conv3d_k3_', 'n_'): float(v) for k, v in c32.items()})
+    assert e['probs'] < 1e-4 and e['loss'] < 1e-4, e
+    assert all(v < 2e-2 for k, v in e.items() if k.startswith('g')), e
+    assert c32[WINO_FWD] >= 6 and c32[WINO_WGRADS[0]] + c32[WINO_WGRADS[1]] >= 3, c32
+    p16, l16, g16, calls16 = res['bf16']
+    gcos = np.array([float((g16[k].double() * g32[k].double()).sum() /
+                           (g16[k].double().norm() * g32[k].double().norm() + 1e-30)) for k in g32])
+    b = dict(probs_max=max_err(p16, p32), probs_mean=float((p16 - p32).abs().mean()), loss=abs(l16 - l32),
+             probs_vs_oracle=max_err(p16, rp), loss_vs_oracle=abs(l16 - float(rl)), grad_cos_min=float(gcos.min()),
+             grad_cos_median=float(np.median(gcos)), n_bf16_fwd=float(calls16.count('seg3d_conv3d_k3_bf16_fwd')),
+             n_bf16_wgrad=float(calls16.count('seg3d_conv3d_k3_bf16_wgrad')))
+    report('vnet_4_4_1x128_bf16', **b)
+    assert p16.dtype == torch.float32
+    assert b['probs_max'] < 3e-2 and b['probs_mean'] < 3e-3 and b['loss'] < 3e-3 and b['loss_vs_oracle'] < 3e-3, b
+    assert b['grad_cos_min'] > 0.8, b
+    assert b['n_bf16_fwd'] >= 20 and b['n_bf16_wgrad'] >= 10, b

@@ -81,6 +81,7 @@ BENCH_VARIANT_CASES = [
     ((4, 64, 48, 48, 48), 131),      # up_64.rblock
     ((4, 32, 48, 48, 48), 311),      # down_32.rblock
     ((1, 128, 24, 24, 24), 311),
+    ((4, 32, 96, 96, 96), 321),      # up_32.rblock at batch 4: the largest launch of the step (most weight-gradient slabs)
 ]
 
 

@@ -174,3 +174,37 @@ def test_epoch_accounting_counts_the_global_batch():
     from segmentation3d.core.seg_train import epoch_of_batch
     assert epoch_of_batch(10, 4, 40) == 1 and epoch_of_batch(9, 4, 40) == 0           # the reference's formula at world 1
     assert epoch_of_batch(5, 4, 40, world_size=2) == 1 and epoch_of_batch(10, 4, 40, world_size=8) == 8
+
+
+_REF_CONFIG_DIR = '/root/reference/segmentation3d/config'
+
+
+@pytest.mark.skipif(not __import__('os').path.isdir(_REF_CONFIG_DIR), reason='the reference tree is only present in the build container')
+def test_reference_config_files_load_unchanged():
+    """north_star: `config/train_config.py` drops in unchanged.  The reference's OWN two config files are loaded through
+    this package's load_config (utils/file_io.py:8-28 of the reference) with this package as `segmentation3d` on the path:
+    every section / key the engines read is there, and the values are the reference's.  Nothing of the reference travels:
+    the test reads it in place and is skipped where /root/reference does not exist (the GPU box)."""
+    import os
+    import segmentation3d
+    from segmentation3d.utils.file_io import load_config
+    from segmentation3d.utils.normalizer import AdaptiveNormalizer
+    assert 'medical-segmentation3d-toolkit_amd' in segmentation3d.__file__
+    tc = load_config(os.path.join(_REF_CONFIG_DIR, 'train_config.py'))
+    assert tc.net.name == 'vbnet' and tc.loss.name == 'Focal' and tc.loss.focal_gamma == 2
+    assert tc.train.batchsize == 4 and tc.train.lr == 1e-4 and tuple(tc.train.betas) == (0.9, 0.999)
+    assert tc.dataset.num_classes == 2 and list(tc.dataset.crop_size) == [64, 64, 64] and tc.dataset.sampling_method == 'HYBRID'
+    assert isinstance(tc.dataset.crop_normalizers[0], AdaptiveNormalizer)          # the config imports OUR normalizer module
+    assert tc.general.resume_epoch == -1 and tc.general.num_gpus == 1 and tc.debug.save_inputs is False
+    ic = load_config(os.path.join(_REF_CONFIG_DIR, 'infer_config.py'))
+    assert ic.general.single_scale == 'DISABLE'
+    assert ic.coarse.partition_type == 'DISABLE' and ic.fine.partition_type == 'SIZE'
+    assert list(ic.fine.partition_size) == [89.6] * 3 and list(ic.fine.partition_stride) == [89.6] * 3
+    # the shipped defaults have the same sections and keys (values may differ where documented), and the same default mode
+    mine = load_config(os.path.join(os.path.dirname(segmentation3d.__file__), 'config', 'infer_config.py'))
+    assert mine.general.single_scale == ic.general.single_scale == 'DISABLE'
+    for section in ('general', 'coarse', 'fine'):
+        assert sorted(mine[section].keys()) == sorted(ic[section].keys()), section
+    mine_t = load_config(os.path.join(os.path.dirname(segmentation3d.__file__), 'config', 'train_config.py'))
+    for section in ('general', 'dataset', 'loss', 'net', 'train'):
+        assert set(tc[section].keys()) <= set(mine_t[section].keys()), (section, set(tc[section].keys()) - set(mine_t[section].keys()))

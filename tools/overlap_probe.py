@@ -1,6 +1,6 @@
 """does an HBM-bound kernel share the chip with a persistent MFMA kernel of another stream?  times K launches of one 3x3x3
 kernel form on stream A, K elementwise passes (GroupNorm-apply-like: 1 read + 1 write of a 453 MB tensor) on stream B, and
-both at once.  usage: python tools/overlap_test.py [wgrad_wino2d|wgrad_wino|wino2d|direct]"""
+both at once.  usage: python tools/overlap_probe.py [wgrad_wino2d|wgrad_wino|wino2d|direct]"""
 import os, sys, time, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, 'medical-segmentation3d-toolkit_amd')); sys.path.insert(0, REPO)

@@ -92,6 +92,7 @@ class KernelTimer(object):
         from segmentation3d import _engine
         self.E = _engine
         self.records = []
+        self.wgrad_records = []
         self._orig = None
 
     def __enter__(self):
@@ -100,6 +101,14 @@ class KernelTimer(object):
         timer = self
 
         def call(name, *args):
+            if name in WGRAD_ENTRY_POINTS:
+                N, D, H, W, Cin, Cout = args[4:10]
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                rc = timer._orig(name, *args)
+                b.record()
+                timer.wgrad_records.append(((N, D, H, W, Cin, Cout, name), a, b))
+                return rc
             if name not in ('seg3d_conv3d_k3_mfma_fwd', 'seg3d_conv3d_k3_bf16_fwd', 'seg3d_conv3d_k3_wino_fwd',
                             'seg3d_conv3d_k3_wino2d_fwd'):
                 return timer._orig(name, *args)
@@ -134,11 +143,35 @@ class KernelTimer(object):
             e['bytes'] += elem_bytes * (float(N) * D * H * W * (Cin + Cout) + 27.0 * Cin * Cout)
         return table
 
+    def wgrad_summary(self):
+        """weight-gradient launches of the 3x3x3 C -> C layers (entry point + the reduce kernel it ends with), by entry point:
+        {name: {'launches', 'ms', 'flops' (algorithmic), 'executed' (issued to the matrix cores)}}"""
+        torch.cuda.synchronize()
+        table = {}
+        for key, a, b in self.wgrad_records:
+            N, D, H, W, Cin, Cout, name = key
+            flops = 2.0 * N * D * H * W * 27 * Cin * Cout
+            e = table.setdefault(name, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'executed': 0.0})
+            e['launches'] += 1
+            e['ms'] += a.elapsed_time(b)
+            e['flops'] += flops
+            e['executed'] += flops * WGRAD_ENTRY_POINTS[name][1]
+        return table
+
 
 WINO_VARIANT = 500   # the Winograd F(2,3) kernel (csrc/conv_wino.hip) in the variant column of the launch tables
 WINO_EXECUTED = 2.0 / 3.0   # it executes 4 multiplies per 2 outputs x 3 taps: 2/3 of the algorithmic FLOPs
 WINO2D_VARIANT = 600   # the Winograd F(2x2,3x3) kernel (csrc/conv_wino2d.hip)
 WINO2D_EXECUTED = 4.0 / 9.0   # 16 multiplies per 4 outputs x 9 (ky, kx) taps
+# weight-gradient entry points of the 3x3x3 C -> C layers: (kernel symbol, executed share of the algorithmic FLOPs)
+WGRAD_ENTRY_POINTS = {'seg3d_conv3d_k3_wino2d_wgrad': ('conv3d_k3_wgrad_wino2d_kernel', WINO2D_EXECUTED),   # F(3x3, 2x2)
+                      'seg3d_conv3d_k3_wino_wgrad': ('conv3d_k3_wgrad_wino_kernel', WINO_EXECUTED),          # F(3, 2)
+                      'seg3d_conv3d_k3_mfma_wgrad': ('conv3d_k3_wgrad2_kernel', 1.0),
+                      'seg3d_conv3d_k3_bf16_wgrad': ('conv3d_k3_wgrad3_bf16_kernel', 1.0)}
+
+
+def executed_share(variant):
+    return WINO_EXECUTED if variant == WINO_VARIANT else WINO2D_EXECUTED if variant == WINO2D_VARIANT else 1.0
 
 
 def variant_kernel_name(v):
@@ -159,18 +192,22 @@ def variant_kernel_name(v):
     return 'conv3d_k3_mfma_kernel<{}>'.format(v)
 
 
-def winograd_fields(variant, achieved, peak):
-    """`achieved` is priced on ALGORITHMIC FLOPs (2 x 27 x Cin x Cout per output voxel).  The Winograd kernel issues 2/3 of
-    them to the matrix cores, so its algorithmic fraction may exceed 1; the fraction of the MFMA peak its issued
-    multiply-adds reach is reported beside it."""
-    if variant not in (WINO_VARIANT, WINO2D_VARIANT):
-        return {}
-    ex = WINO_EXECUTED if variant == WINO_VARIANT else WINO2D_EXECUTED
-    what = ('F(2,3) along x: 4 multiplies per 2 outputs x 3 taps, so the matrix cores execute 2/3' if variant == WINO_VARIANT
-            else 'F(2x2,3x3) over (y, x): 16 multiplies per 4 outputs x 9 taps, so the matrix cores execute 4/9')
-    return {'executed_tflops': round(achieved * ex, 2), 'frac_executed': round(achieved * ex / peak, 4),
-            'flops_note': 'Winograd ' + what + ' of the algorithmic FLOPs `achieved`/`frac` are priced on; '
-                          'frac_executed = executed FLOPs / peak'}
+def mfma_roofline_fields(variant, algorithmic_tflops, peak):
+    """`achieved` / `frac` price the multiply-adds the kernel ISSUES to the matrix cores against the dense MFMA peak, so
+    frac <= 1 by construction.  A Winograd kernel issues only 4/9 (F(2x2,3x3)) or 2/3 (F(2,3)) of the ALGORITHMIC FLOPs
+    (2 x 27 x Cin x Cout per output voxel); the algorithmic rate -- what the layer is worth to the step -- is reported in
+    its own fields and may exceed the peak."""
+    ex = executed_share(variant)
+    out = {'achieved': round(algorithmic_tflops * ex, 2), 'peak': peak, 'unit': 'TFLOP/s',
+           'frac': round(algorithmic_tflops * ex / peak, 4),
+           'algorithmic_tflops': round(algorithmic_tflops, 2), 'frac_algorithmic': round(algorithmic_tflops / peak, 4),
+           'executed_share_of_algorithmic_flops': round(ex, 4)}
+    if ex != 1.0:
+        what = ('F(2,3) along x: 4 multiplies per 2 outputs x 3 taps' if variant == WINO_VARIANT
+                else 'F(2x2,3x3) over (y, x): 16 multiplies per 4 outputs x 9 taps')
+        out['flops_note'] = ('Winograd ' + what + ': `achieved` / `frac` = FLOPs issued to the matrix cores / dense fp32 MFMA '
+                             'peak; algorithmic_tflops = 2*27*Cin*Cout per output voxel / time')
+    return out
 
 
 def pmc_traffic_gb(kernel_name):
@@ -257,7 +294,10 @@ def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):
     return out
 
 
-def time_inference(net, volume_xyz, patch, stride, ncls, batch, device, two_streams=True):
+def time_inference(net, volume_xyz, patch, stride, ncls, batch, device, two_streams=True, world=1, dtype='fp32'):
+    """whole-volume sliding-window job.  world > 1: every rank holds the volume, the patch list is sharded into z-contiguous
+    chunks (core/seg_infer.SlabShardPlan), only the halo planes travel point to point, every rank divides / arg-maxes its own
+    slab and the mask slabs are replicated (gather='mask'); seconds = MAX over ranks of the job time."""
     from segmentation3d.core.seg_infer import sliding_window_inference
     from segmentation3d.utils.image_tools import image_partition_by_fixed_size
     X, Y, Z = volume_xyz
@@ -272,21 +312,39 @@ def time_inference(net, volume_xyz, patch, stride, ncls, batch, device, two_stre
     vol = host.to(device)
     torch.cuda.synchronize()
     t_h2d = time.time() - t0
-    # the complete job (accumulator allocation, warm-up batch, graph capture, all replays, divide + arg-max) three times;
-    # the median is reported -- single runs occasionally read ~1 s high on a shared host (allocator / graph instantiation)
+    # the complete job (accumulator allocation, warm-up batch, graph capture, all replays, halo merge, divide + arg-max,
+    # mask replication) three times; the median is reported -- single runs occasionally read high on a shared host
     runs = []
     for _ in range(3):
-        t0 = time.time()
-        probs, mask, _ = sliding_window_inference(net, vol, starts, (patch,) * 3, ncls, {'type': 1, 'clip_sigma': 3},
-                                                  batch_size=batch, use_graph=True, two_streams=two_streams)
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        runs.append(time.time() - t0)
+        t0 = time.time()
+        probs, mask, batcher = sliding_window_inference(net, vol, starts, (patch,) * 3, ncls, {'type': 1, 'clip_sigma': 3},
+                                                        batch_size=batch, use_graph=True, two_streams=two_streams,
+                                                        shard=world > 1, gather='mask')
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        runs.append(dt)
         if len(runs) < 3:
             del probs, mask
     t_dev = sorted(runs)[1]
     t0 = time.time()
     mask_host = mask.cpu()
     t_d2h = time.time() - t0
+    shard_info = None
+    if world > 1:
+        plan = batcher.shard_plan
+        halo = sum((ncls + 1) * (z1 - z0) * Y * X * 4 for _, _, z0, z1 in plan.transfers())
+        shard_info = {'ranks': world, 'patches_per_rank': [len(q) for q in plan.patches],
+                      'owned_z_slabs': [list(plan.owned(r)) for r in range(world)],
+                      'halo_bytes_point_to_point': int(halo), 'mask_bytes_replicated': int(Z * Y * X),
+                      'full_allreduce_bytes_avoided': int((ncls + 1) * Z * Y * X * 4),
+                      'seconds_is': 'max over ranks of each complete job, median of 3 jobs'}
     # roofline of the job: one eager, single-stream forward of a half batch (what one stream of a replay runs) with every
     # launch of the MFMA 3x3x3 convolution bracketed by events -> its dominant instantiation against the fp32 MFMA peak,
     # and the whole job against the FLOP floor (algorithmic forward FLOPs of all patches / peak)
@@ -314,23 +372,88 @@ def time_inference(net, volume_xyz, patch, stride, ncls, batch, device, two_stre
         conv_flops_per_patch = sum(e['flops'] for e in table.values()) / half
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
         job_tflop = conv_flops_per_patch * len(starts) / 1e12
-        roof = {'kernel': variant_kernel_name(dom), 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'launches_per_forward': d['launches'],
-                'avg_launch_ms': round(d['ms'] / d['launches'], 4),
-                **winograd_fields(dom, achieved, FP32_MFMA_PEAK_TFLOPS),
-                'job': {'algorithmic_tflop_mfma_convs': round(job_tflop, 2),
-                        'flop_floor_seconds': round(job_tflop / FP32_MFMA_PEAK_TFLOPS, 4),
-                        'frac_of_fp32_mfma_peak': round(job_tflop / t_dev / FP32_MFMA_PEAK_TFLOPS, 4)},
+        job_exec = sum(e['flops'] * executed_share(k[6]) for k, e in table.items()) / half * len(starts) / 1e12
+        peak = BF16_MFMA_PEAK_TFLOPS if dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
+        roof = {'kernel': variant_kernel_name(dom), 'bound': 'mfma', **mfma_roofline_fields(dom, achieved, peak),
+                'launches_per_forward': d['launches'], 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                'job': {'algorithmic_tflop_mfma_convs': round(job_tflop, 2), 'executed_tflop_mfma_convs': round(job_exec, 2),
+                        'executed_flop_floor_seconds': round(job_exec / peak, 4),
+                        'frac_of_mfma_peak_executed': round(job_exec / t_dev / peak, 4),
+                        'frac_of_mfma_peak_algorithmic': round(job_tflop / t_dev / peak, 4)},
                 'note': 'one eager single-stream forward of {} patches after the timed jobs; the job runs two such half '
                         'batches on two streams inside each hipGraph replay'.format(half)}
     except Exception as exc:   # the roofline is a report, never a reason to lose the measurement
         roof = {'error': repr(exc)}
-    return {'roofline': roof,'workload': 'sliding-window inference, {}x{}x{} volume, {}^3 patches stride {}, {} patches, batch {} per '
-                        'hipGraph replay (two half batches on two streams), 1 forward/patch'.format(
-                            X, Y, Z, patch, stride, len(starts), batch),
+    return {'roofline': roof, 'workload': 'sliding-window inference, {}x{}x{} volume, {}^3 patches stride {}, {} patches, batch {} per '
+                        'hipGraph replay (two half batches on two streams), 1 forward/patch{}'.format(
+                            X, Y, Z, patch, stride, len(starts), batch,
+                            ', patch list sharded over {} GPUs in z-contiguous chunks'.format(world) if world > 1 else ''),
             'seconds': round(t_dev, 4), 'seconds_all_runs': [round(v, 4) for v in runs], 'h2d_seconds': round(t_h2d, 4),
             'd2h_mask_seconds': round(t_d2h, 4), 'patches_per_s': round(len(starts) / t_dev, 2),
-            'mask_nonzero': int((mask_host != 0).sum())}
+            'mask_nonzero': int((mask_host != 0).sum()), 'n_gpus': world, 'sharding': shard_info}
+
+
+def time_config1_gpu(net, net_name, cin, ncls, patch, device):
+    """BASELINE config 1 on the GPU, beside cpu_baseline.config1_whole_volume_128: one synthetic 128^3 volume, 96^3 boxes at
+    stride 48 (8 patches), adaptive normaliser.  Two readings: `segmentation_volume` on a resident image (what the CPU figure
+    covers: patch loop, accumulate, divide, arg-max; no file IO), and the reference's CLI entry `segmentation()` on a .mha
+    file with a reference-layout model folder (model load + file read + inference, mask returned, nothing saved)."""
+    import shutil
+    import tempfile
+    from segmentation3d.core.seg_infer import load_models, segmentation, segmentation_volume
+    from segmentation3d.utils.image3d import Image3d
+    from segmentation3d.utils.mha_io import write_mha
+    root = tempfile.mkdtemp(prefix='seg3d_cfg1_')
+    try:
+        chk = os.path.join(root, 'model', 'fine', 'checkpoints', 'chk_1')
+        os.makedirs(chk)
+        norm = {'type': 1, 'clip_sigma': 3}
+        torch.save({'epoch': 1, 'batch': 1, 'net': net_name, 'max_stride': 16,
+                    'state_dict': {'module.' + k: v.detach().cpu() for k, v in net.state_dict().items()},
+                    'spacing': [1.0, 1.0, 1.0], 'interpolation': 'LINEAR', 'in_channels': cin, 'out_channels': ncls,
+                    'crop_normalizers': [norm]}, os.path.join(chk, 'params.pth'))
+        import segmentation3d
+        cfg_src = open(os.path.join(os.path.dirname(segmentation3d.__file__), 'config', 'infer_config.py')).read()
+        cfg_src = cfg_src.replace("__C.general.single_scale = 'DISABLE'", "__C.general.single_scale = 'fine'")
+        cfg_src = cfg_src.replace('__C.fine.pick_largest_cc = True', '__C.fine.pick_largest_cc = False')
+        cfg_src += '\n__C.fine.partition_size = [{0}.0, {0}.0, {0}.0]\n__C.fine.partition_stride = [{1}.0, {1}.0, {1}.0]\n'.format(
+            patch, patch // 2)
+        with open(os.path.join(root, 'model', 'infer_config.py'), 'w') as f:
+            f.write(cfg_src)
+        vol = torch.randn((128, 128, 128), generator=torch.Generator().manual_seed(11)).numpy()
+        frame = ((1.0, 1.0, 1.0), (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0))
+        img = Image3d(vol, *frame)
+        path = os.path.join(root, 'case.mha')
+        write_mha(img, path)
+        models = load_models(os.path.join(root, 'model'), device.index or 0)
+        vols = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            _, mask = segmentation_volume(models['fine_model'], models['infer_cfg'].fine, img, None, None, True)
+            torch.cuda.synchronize()
+            vols.append(time.time() - t0)
+        import contextlib
+        import io
+        cli = []
+        for _ in range(2):
+            t0 = time.time()
+            with contextlib.redirect_stdout(io.StringIO()):
+                segmentation(path, os.path.join(root, 'model'), os.path.join(root, 'out'), 'seg.mha', device.index or 0,
+                             True, False, False, False)
+            torch.cuda.synchronize()
+            cli.append(time.time() - t0)
+        return {'patches': 8, 'seconds_segmentation_volume': round(sorted(vols[1:])[1], 4),
+                'seconds_segmentation_volume_all_runs': [round(v, 4) for v in vols],
+                'seconds_segmentation_cli_entry': round(min(cli), 4), 'seconds_segmentation_cli_entry_all_runs': [round(v, 4) for v in cli],
+                'mask_nonzero': int((mask.array != 0).sum()),
+                'what': 'synthetic 128^3 volume at 1 mm, {0}^3 boxes at stride {1} (8 patches, one hipGraph-free batch), adaptive '
+                        'normaliser, device accumulate / divide / arg-max, probabilities and mask copied to the host; '
+                        'segmentation_volume = resident image (comparable with cpu_baseline.config1_whole_volume_128, which has no '
+                        'file IO either; the reference\'s second, identical forward per patch is not repeated), cli_entry = '
+                        'segmentation() on the .mha incl. model-folder load and file read'.format(patch, patch // 2)}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def launch_ranks(args):
@@ -499,24 +622,42 @@ def main():
         peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
         gbps = d['bytes'] / (d['ms'] * 1e-3) / 1e9
         hbm_frac = gbps / HBM_PEAK_GBPS
-        roofline = {'kernel': kname, 'bound': 'mfma', 'achieved': round(achieved, 2),
-                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+        roofline = {'kernel': kname, 'bound': 'mfma', **mfma_roofline_fields(dom, achieved, peak),
                     'traffic': traffic, 'traffic_unit': 'GB per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, see profiles/)',
                     'launches_per_step': d['launches'] // 2,
                     'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                     'gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
                     'share_of_step_ms': round(d['ms'] / 2, 3),
-                    **winograd_fields(dom, achieved, peak),
                     'note': 'launch durations from 2 instrumented eager steps with the weight-gradient side stream off '
                             '(kernels back to back on one stream, garbage collector parked); value/ms_per_step are '
                             'measured with the side stream on'}
-        # the whole step against the FLOP floor: algorithmic FLOPs of the MFMA convolutions (forward + data-gradient measured
-        # live above, weight gradients = one more forward's worth; SURVEY.md 8d: 541.6 GFLOP per 96^3 patch of vnet(1,2))
-        step_tflop = 1.5 * sum(e['flops'] for e in table.values()) / 2 / 1e12
-        roofline['step'] = {'algorithmic_tflop_mfma_convs': round(step_tflop, 3),
-                            'flop_floor_ms': round(step_tflop / peak * 1e3, 2),
-                            'frac_of_peak': round(step_tflop / (ms_per_step * 1e-3) / peak, 4)}
-        if hbm_frac > achieved / peak:
+        # the weight gradients of the same layers, measured the same way (entry point = main kernel + its slab reduce)
+        wg = kt.wgrad_summary()
+        if wg:
+            wdom = max(wg, key=lambda n: wg[n]['ms'])
+            w = wg[wdom]
+            walg = w['flops'] / (w['ms'] * 1e-3) / 1e12
+            wex = WGRAD_ENTRY_POINTS[wdom][1]
+            roofline['wgrad'] = {'kernel': WGRAD_ENTRY_POINTS[wdom][0] + ' (+ its slab reduce)', 'bound': 'mfma',
+                                 'achieved': round(walg * wex, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(walg * wex / peak, 4),
+                                 'algorithmic_tflops': round(walg, 2), 'executed_share_of_algorithmic_flops': round(wex, 4),
+                                 'launches_per_step': w['launches'] // 2, 'avg_launch_ms': round(w['ms'] / w['launches'], 4),
+                                 'share_of_step_ms': round(w['ms'] / 2, 3)}
+        # the whole step against the MFMA roof, everything measured: algorithmic and executed FLOPs of the 3x3x3 C -> C
+        # convolutions (forward + data-gradient + weight-gradient launches bracketed above) / ms_per_step / peak
+        fwd_alg = sum(e['flops'] for e in table.values()) / 2
+        fwd_exec = sum(e['flops'] * executed_share(k[6]) for k, e in table.items()) / 2
+        wg_alg = sum(e['flops'] for e in wg.values()) / 2
+        wg_exec = sum(e['executed'] for e in wg.values()) / 2
+        step_tflop, step_exec = (fwd_alg + wg_alg) / 1e12, (fwd_exec + wg_exec) / 1e12
+        roofline['step'] = {'algorithmic_tflop_mfma_convs': round(step_tflop, 3), 'executed_tflop_mfma_convs': round(step_exec, 3),
+                            'executed_flop_floor_ms': round(step_exec / peak * 1e3, 2),
+                            'frac_of_peak': round(step_exec / (ms_per_step * 1e-3) / peak, 4),
+                            'frac_of_peak_algorithmic': round(step_tflop / (ms_per_step * 1e-3) / peak, 4),
+                            'mfma_conv_kernel_ms': round((sum(e['ms'] for e in table.values()) + sum(e['ms'] for e in wg.values())) / 2, 3),
+                            'note': 'frac_of_peak = FLOPs issued to the matrix cores by the bracketed 3x3x3 convolution launches '
+                                    '(forward, data-gradient, weight-gradient; all measured) / ms_per_step / peak, <= 1'}
+        if hbm_frac > roofline['frac']:
             # (bf16 mode) the same launches priced against HBM: algorithmic bytes = input + output once
             roofline.update({'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                              'frac': round(hbm_frac, 4), 'gb_per_launch': round(d['bytes'] / d['launches'] / 1e9, 4),
@@ -532,9 +673,17 @@ def main():
                 json.dump({'mfma_conv_launches': kernels, 'ms_per_step': ms_per_step}, f, indent=1)
 
     infer = None
-    if not args.no_infer and world == 1:
+    if not args.no_infer:
+        # every rank takes part (N > 1: the patch list is sharded, the halo merge and the mask replication are collectives)
         vx = tuple(int(v) for v in args.infer_volume.split(','))
-        infer = time_inference(step.net, vx, args.patch, args.patch // 2, args.classes, args.infer_batch, device)
+        infer = time_inference(step.net, vx, args.patch, args.patch // 2, args.classes, args.infer_batch, device,
+                               world=world, dtype=args.dtype)
+        if world == 1 and args.in_channels == 1:
+            try:
+                infer['config1_whole_volume_128_gpu'] = time_config1_gpu(step.net, args.net, args.in_channels, args.classes,
+                                                                          args.patch, device)
+            except Exception as exc:   # a report beside the headline, never a reason to lose it
+                infer['config1_whole_volume_128_gpu'] = {'error': repr(exc)}
 
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1 and rank == 0:

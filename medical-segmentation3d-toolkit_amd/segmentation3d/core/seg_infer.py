@@ -15,6 +15,7 @@ replayed per batch; only a 4*(3P+7)-byte control block changes between replays.
 """
 import importlib
 import os
+import threading
 import time
 
 import numpy as np
@@ -320,8 +321,12 @@ def sliding_window_inference(net, volume, starts, box, num_classes, normalizer, 
 # The caching allocator keeps free blocks per (pool, stream): the warm-up stream, the capture stream and the second forward
 # stream are therefore created once per device as well -- with fresh streams per volume no block was ever reused (reserved
 # memory grew by 20 GB per job).
+# Retained footprint: the pool keeps every segment a volume graph of this device ever needed (the peak intermediates of the
+# largest box / batch seen, ~20 GB for 16 patches of 96^3) reserved until release_graph_pool(device) is called --
+# torch.cuda.empty_cache() cannot return memory of a live graph pool.
 _GRAPH_POOLS = {}
 _JOB_STREAMS = {}
+_GRAPH_POOL_LOCK = threading.Lock()
 
 
 def _job_stream(device, which):
@@ -339,38 +344,70 @@ def _capture_in_shared_pool(fn, device):
     thread, a nested call) captures into a private pool of its own, as torch.cuda.graph would."""
     import weakref
     key = device.index if device.index is not None else torch.cuda.current_device()
-    entry = _GRAPH_POOLS.get(key)
     cur = torch.cuda.current_stream()
-    if entry is None:
-        stream = _job_stream(device, 'capture')
-        pool = torch.cuda.graph_pool_handle()
-        keep = torch.cuda.CUDAGraph()
-        anchor = torch.zeros(1, device=device)
-        stream.wait_stream(cur)
-        with torch.cuda.stream(stream):
-            keep.capture_begin(pool=pool)
-            anchor.add_(1.0)
-            keep.capture_end()
-        cur.wait_stream(stream)
-        entry = _GRAPH_POOLS[key] = {'pool': pool, 'keep': keep, 'anchor': anchor, 'live': 0}
-    shared = entry['live'] == 0
+    # the check of `live`, the claim of the shared pool and the creation of the pool itself are one critical section: two
+    # threads that both saw live == 0 would capture into the same pool while both graphs are alive
+    with _GRAPH_POOL_LOCK:
+        entry = _GRAPH_POOLS.get(key)
+        if entry is None:
+            stream = _job_stream(device, 'capture')
+            pool = torch.cuda.graph_pool_handle()
+            keep = torch.cuda.CUDAGraph()
+            anchor = torch.zeros(1, device=device)
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                keep.capture_begin(pool=pool)
+                anchor.add_(1.0)
+                keep.capture_end()
+            cur.wait_stream(stream)
+            entry = _GRAPH_POOLS[key] = {'pool': pool, 'keep': keep, 'anchor': anchor, 'live': 0}
+        shared = entry['live'] == 0
+        if shared:
+            entry['live'] += 1
     stream = _job_stream(device, 'capture') if shared else torch.cuda.Stream(device=device)
     graph = torch.cuda.CUDAGraph()
-    stream.wait_stream(cur)
-    with torch.cuda.stream(stream):
-        graph.capture_begin(pool=entry['pool'] if shared else torch.cuda.graph_pool_handle())
-        try:
-            fn()
-        finally:
-            graph.capture_end()
-    cur.wait_stream(stream)
+    try:
+        stream.wait_stream(cur)
+        with torch.cuda.stream(stream):
+            graph.capture_begin(pool=entry['pool'] if shared else torch.cuda.graph_pool_handle())
+            try:
+                fn()
+            finally:
+                graph.capture_end()
+        cur.wait_stream(stream)
+    except BaseException:
+        if shared:
+            with _GRAPH_POOL_LOCK:
+                entry['live'] -= 1
+        raise
     if shared:
-        entry['live'] += 1
-
         def _released(e=entry):
-            e['live'] -= 1
+            with _GRAPH_POOL_LOCK:
+                e['live'] -= 1
         weakref.finalize(graph, _released)
     return graph
+
+
+def release_graph_pool(device=None):
+    """hand the shared volume-graph pool of `device` (default: the current one) back to the caching allocator -- for a process
+    that ran inference and now wants the memory for training, or shares the GPU.  Refuses (returns False) while a volume
+    graph of that device is alive; the next sliding-window job simply builds a new pool."""
+    if device is None:
+        key = torch.cuda.current_device()
+    else:
+        device = torch.device(device)
+        key = device.index if device.index is not None else torch.cuda.current_device()
+    with _GRAPH_POOL_LOCK:
+        entry = _GRAPH_POOLS.get(key)
+        if entry is None:
+            return True
+        if entry['live'] != 0:
+            return False
+        del _GRAPH_POOLS[key]
+    entry.clear()                 # drops the keep-alive graph: the pool's segments become ordinary cached blocks
+    torch.cuda.synchronize(key)
+    torch.cuda.empty_cache()
+    return True
 
 
 def _sliding_window_inference(net, volume, starts, box, num_classes, normalizer, batch_size, use_graph, process_group,

@@ -46,7 +46,10 @@ def read_mha(path, dtype=np.float32):
         array = array.astype(dtype)
     spacing = [float(v) for v in header.get('ElementSpacing', '1 1 1').split()]
     origin = [float(v) for v in header.get('Offset', header.get('Position', '0 0 0')).split()]
-    direction = [float(v) for v in header.get('TransformMatrix', '1 0 0 0 1 0 0 0 1').split()]
+    # ITK's MetaImageIO stores the direction cosines AXIS BY AXIS: the i-th triple of TransformMatrix is the physical
+    # direction of image axis i = COLUMN i of the direction matrix, whose row-major flattening sitk's GetDirection() returns
+    tm = [float(v) for v in header.get('TransformMatrix', header.get('Orientation', '1 0 0 0 1 0 0 0 1')).split()]
+    direction = [tm[3 * c + r] for r in range(3) for c in range(3)]
     return Image3d(array, spacing, origin, direction)
 
 
@@ -58,7 +61,8 @@ def write_mha(image, path):
     x, y, z = image.GetSize()
     lines = ['ObjectType = Image', 'NDims = 3', 'BinaryData = True', 'BinaryDataByteOrderMSB = False',
              'CompressedData = False',
-             'TransformMatrix = ' + ' '.join(repr(float(v)) for v in image.GetDirection()),
+             # axis by axis = the columns of the direction matrix (see read_mha)
+             'TransformMatrix = ' + ' '.join(repr(float(image.GetDirection()[3 * r + c])) for c in range(3) for r in range(3)),
              'Offset = ' + ' '.join(repr(float(v)) for v in image.GetOrigin()),
              'CenterOfRotation = 0 0 0', 'AnatomicalOrientation = RAI',
              'ElementSpacing = ' + ' '.join(repr(float(v)) for v in image.GetSpacing()),

@@ -208,3 +208,37 @@ def test_reference_config_files_load_unchanged():
     mine_t = load_config(os.path.join(os.path.dirname(segmentation3d.__file__), 'config', 'train_config.py'))
     for section in ('general', 'dataset', 'loss', 'net', 'train'):
         assert set(tc[section].keys()) <= set(mine_t[section].keys()), (section, set(tc[section].keys()) - set(mine_t[section].keys()))
+
+
+def test_image_readers_against_independent_fixtures(tmp_path):
+    """f3: the product readers (utils/mha_io.py, utils/image_io.py -- they replace sitk.ReadImage / sitk.WriteImage,
+    core/seg_infer.py:414,467-481) on files they did NOT write: tests/golden/images/* are assembled byte by byte by
+    tests/golden/make_image_fixtures.py from the MetaImage / NIfTI-1 format definitions (raw, zlib and big-endian MetaImage
+    payloads, .mhd + separate data file, oblique TransformMatrix; NIfTI sform with scl_slope, qform with qfac = -1 in a
+    .nii.gz, big-endian header).  Array, spacing, origin and direction must come out as the definitions say; then each
+    image is written by the product writers and read back (the writers against the now independently checked readers)."""
+    import os
+    from conftest import GOLDEN
+    from segmentation3d.utils.image_io import read_image, write_image
+    folder = os.path.join(GOLDEN, 'images')
+    expected = golden_json(os.path.join('images', 'expected'))
+    assert len(expected) == 6
+    for name, exp in sorted(expected.items()):
+        img = read_image(os.path.join(folder, name), dtype=None)
+        want = np.asarray(exp['array'])
+        assert img.array.shape == want.shape and img.GetSize() == want.shape[::-1], name
+        assert np.array_equal(np.asarray(img.array, dtype=np.float64), want.astype(np.float64)), name
+        if '*' not in exp['dtype']:
+            assert img.array.dtype == np.dtype(exp['dtype']), (name, img.array.dtype)
+        assert np.allclose(img.GetSpacing(), exp['spacing'], rtol=1e-6, atol=0), (name, img.GetSpacing())
+        assert np.allclose(img.GetOrigin(), exp['origin'], rtol=1e-6, atol=1e-6), (name, img.GetOrigin())
+        assert np.allclose(img.GetDirection(), exp['direction'], rtol=0, atol=1e-6), (name, img.GetDirection())
+        as_f32 = read_image(os.path.join(folder, name))                      # sitk.ReadImage(path, sitk.sitkFloat32)
+        assert as_f32.array.dtype == np.float32 and np.allclose(as_f32.array, want, rtol=1e-6)
+        for ext in ('.mha', '.nii.gz'):
+            out = str(tmp_path / (name.split('.')[0] + '_rt' + ext))
+            write_image(img, out)
+            back = read_image(out, dtype=None)
+            assert np.array_equal(back.array, img.array) and back.array.dtype == img.array.dtype, (name, ext)
+            assert np.allclose(back.GetSpacing(), exp['spacing'], rtol=1e-6) and np.allclose(back.GetOrigin(), exp['origin'], rtol=1e-6, atol=1e-6)
+            assert np.allclose(back.GetDirection(), exp['direction'], atol=1e-6), (name, ext)

@@ -1095,16 +1095,8 @@ static int launch_fwd(const float* x, const float* wp, const float* bias, float*
                       const float* addend) {
   const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
   const size_t lds = seg3d_fwd_lds_bytes(t);
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma_kernel<MA>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) {
-      seg3d_set_error("conv3d_k3_mfma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SEG3D_ERR_LAUNCH;
-    }
-    configured = 160 * 1024;
-  }
+  static Seg3dOncePerDevice configured;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_mfma_kernel<MA>), configured, "conv3d_k3_mfma")) return rc;
   const int cib = (Cin + 7) / 8;
   const int cpk = (cib + ks - 1) / ks;
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32), (unsigned)(ks > 1 ? (cib + cpk - 1) / cpk : 1));
@@ -1120,19 +1112,10 @@ static int launch_fwd2(const float* x, const float* wp, const float* bias, float
   if constexpr (BF16) {  // Cin counts bf16 channels; the kernel sees Cin / 2 words per voxel and 16-channel chunks
     const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
     const size_t lds = seg3d_fwd2_lds_bytes(t, NB);
-    static bool configured16 = false;
-    if (!configured16) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_bf16_kernel<MA, NB, OUT_BF>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_bf16_splitk_kernel<MA, NB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-      if (e != hipSuccess) {
-        seg3d_set_error("conv3d_k3_mfma2_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        return SEG3D_ERR_LAUNCH;
-      }
-      configured16 = true;
-    }
+    static Seg3dOncePerDevice configured16;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_mfma2_bf16_kernel<MA, NB, OUT_BF>), configured16, "conv3d_k3_mfma2_bf16")) return rc;
+    static Seg3dOncePerDevice configured16_b;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_mfma2_bf16_splitk_kernel<MA, NB>), configured16_b, "conv3d_k3_mfma2_bf16")) return rc;
     const int ncog = (Cout + 31) / 32 / NB;
     const int nitems = N * ntz * nty * ntx * ncog * ks;
     const int cib = Cin / 16, cpk = (cib + ks - 1) / ks;
@@ -1147,19 +1130,10 @@ static int launch_fwd2(const float* x, const float* wp, const float* bias, float
   }
   const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
   const size_t lds = seg3d_fwd2_lds_bytes(t, NB);
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_kernel<MA, NB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2_splitk_kernel<MA, NB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) {
-      seg3d_set_error("conv3d_k3_mfma2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SEG3D_ERR_LAUNCH;
-    }
-    configured = true;
-  }
+  static Seg3dOncePerDevice configured;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_mfma2_kernel<MA, NB>), configured, "conv3d_k3_mfma2")) return rc;
+  static Seg3dOncePerDevice configured_b;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_mfma2_splitk_kernel<MA, NB>), configured_b, "conv3d_k3_mfma2")) return rc;
   const int ncog = (Cout + 31) / 32 / NB;
   const int nitems = N * ntz * nty * ntx * ncog * ks;
   const int cib = Cin / 8, cpk = (cib + ks - 1) / ks;
@@ -1178,16 +1152,8 @@ static int launch_fwd2_w8_bf16(const float* x, const float* wp, const float* bia
                                int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, const float* addend) {
   const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
   const size_t lds = seg3d_fwd2_lds_bytes(t, 1);
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2w8_bf16_kernel<MA, 1, OUT_BF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) {
-      seg3d_set_error("conv3d_k3_mfma2w8_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SEG3D_ERR_LAUNCH;
-    }
-    configured = true;
-  }
+  static Seg3dOncePerDevice configured;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_mfma2w8_bf16_kernel<MA, 1, OUT_BF>), configured, "conv3d_k3_mfma2w8_bf16")) return rc;
   const int ncog = (Cout + 31) / 32;
   const int nitems = N * ntz * nty * ntx * ncog;
   dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
@@ -1201,16 +1167,8 @@ static int launch_fwd2_w8(const float* x, const float* wp, const float* bias, fl
                           int W, int Cin, int Cout, const Seg3dTile& t, hipStream_t s, const float* addend) {
   const int ntz = seg3d_cdiv(D, t.tz), nty = seg3d_cdiv(H, t.ty), ntx = seg3d_cdiv(W, t.tx);
   const size_t lds = seg3d_fwd2_lds_bytes(t, 1);
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_mfma2w8_kernel<MA, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) {
-      seg3d_set_error("conv3d_k3_mfma2w8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SEG3D_ERR_LAUNCH;
-    }
-    configured = true;
-  }
+  static Seg3dOncePerDevice configured;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_mfma2w8_kernel<MA, 1>), configured, "conv3d_k3_mfma2w8")) return rc;
   const int ncog = (Cout + 31) / 32;
   const int nitems = N * ntz * nty * ntx * ncog;
   dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
@@ -2146,16 +2104,8 @@ static int launch_wgrad2(const float* x, const float* dy, float* workspace, int 
                          int slabs, hipStream_t s) {
   const int ntz = seg3d_cdiv(D, TZ), nty = seg3d_cdiv(H, TY), ntx = seg3d_cdiv(W, TX);
   const int ntiles = N * ntz * nty * ntx;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad2_kernel<NB, TZ, TY, TX>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) {
-      seg3d_set_error("conv3d_k3_wgrad2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SEG3D_ERR_LAUNCH;
-    }
-    configured = true;
-  }
+  static Seg3dOncePerDevice configured;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wgrad2_kernel<NB, TZ, TY, TX>), configured, "conv3d_k3_wgrad2")) return rc;
   const int CIB32 = (Cin + 31) / 32, COG = (Cout + 31) / 32 / NB;
   const size_t lds = (size_t)2 * ((TZ + 2) * (TY + 2) * (TX + 2) * 32 + NB * TZ * TY * TX * 32) * 4;
   hipLaunchKernelGGL((conv3d_k3_wgrad2_kernel<NB, TZ, TY, TX>), dim3((unsigned)(slabs * CIB32 * COG)), dim3(256), lds, s, x, dy, workspace,
@@ -2233,16 +2183,8 @@ static int launch_wgrad3(const void* x, const void* dy, float* workspace, int N,
   constexpr int TZ = 4, TY = 4;
   const int ntz = seg3d_cdiv(D, TZ), nty = seg3d_cdiv(H, TY), ntx = seg3d_cdiv(W, TX);
   const int ntiles = N * ntz * nty * ntx;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad3_bf16_kernel<TZ, TY, TX, IRR>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) {
-      seg3d_set_error("conv3d_k3_wgrad3_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SEG3D_ERR_LAUNCH;
-    }
-    configured = true;
-  }
+  static Seg3dOncePerDevice configured;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wgrad3_bf16_kernel<TZ, TY, TX, IRR>), configured, "conv3d_k3_wgrad3_bf16")) return rc;
   const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
   constexpr int NVH = (TZ + 2) * (TY + 2) * (TX + 2), MTV = TZ * TY * TX;
   const size_t lds = (size_t)SEG3D_WG3_NBUF * ((((NVH + 15) / 16) + MTV / 16 + 3) / 4) * 4 * 1024;

@@ -60,7 +60,7 @@ __device__ __forceinline__ void wn_glds16(const float* src, float* lds_dst_wave_
 typedef __attribute__((address_space(3))) float wn_lds_float;
 __device__ __forceinline__ void wn_glds16_asm(const float* src, float* lds_dst_wave_uniform) {
   const unsigned off = (unsigned)(uintptr_t)(wn_lds_float*)lds_dst_wave_uniform;
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(off) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(off) : "memory", "m0");
 }
 __device__ __forceinline__ void wn_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -339,16 +339,8 @@ extern "C" int seg3d_conv3d_k3_wino_fwd(const float* x, const float* wp, const f
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_wino_fwd: null pointer");
   SEG3D_REQUIRE(seg3d_conv3d_k3_wino_supported(N, D, H, W, Cin, Cout),
                 "seg3d_conv3d_k3_wino_fwd: shape not supported (whole 8^3 tiles, Cin %% 8 == 0, Cout %% 32 == 0)");
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) {
-      seg3d_set_error("conv3d_k3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SEG3D_ERR_LAUNCH;
-    }
-    configured = true;
-  }
+  static Seg3dOncePerDevice configured;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino_kernel), configured, "conv3d_k3_wino")) return rc;
   const int ntz = D / WN_TZ, nty = H / WN_TY, ntx = W / WN_TX, ncog = Cout / 32;
   const int nitems = N * ntz * nty * ntx * ncog;
   dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
@@ -672,16 +664,8 @@ static int wn_launch_wgrad(const float* x, const float* dy, float* workspace, in
                            int slabs, hipStream_t s) {
   const int ntz = D / TZ, nty = H / TY, ntx = W / TX;
   const int ntiles = N * ntz * nty * ntx;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_wino_kernel<TZ, TY, TX>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) {
-      seg3d_set_error("conv3d_k3_wgrad_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SEG3D_ERR_LAUNCH;
-    }
-    configured = true;
-  }
+  static Seg3dOncePerDevice configured;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wgrad_wino_kernel<TZ, TY, TX>), configured, "conv3d_k3_wgrad_wino")) return rc;
   const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32;
   constexpr int NRH = (TZ + 2) * (TY + 2);
   const size_t lds = (size_t)(NRH * (TX + 2) * 32 + 4 * NRH * (TX / 2) * 32 + 2 * TZ * TY * TX * 32) * 4;

@@ -57,7 +57,7 @@ __device__ __attribute__((aligned(16))) float w2_zero16[4];   // DMA source for 
 typedef __attribute__((address_space(3))) float w2_lds_float;
 __device__ __forceinline__ void w2_glds16(const float* src, float* lds_dst_wave_uniform) {
   const unsigned off = (unsigned)(uintptr_t)(w2_lds_float*)lds_dst_wave_uniform;
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(off) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(off) : "memory", "m0");
 }
 __device__ __forceinline__ void w2_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // a - b on two packed floats in one instruction (hipcc selects v_pk_add_f32 for additions but two v_sub_f32 for this)
@@ -415,16 +415,8 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_wino2d_fwd: null pointer");
   SEG3D_REQUIRE(seg3d_conv3d_k3_wino2d_supported(N, D, H, W, Cin, Cout),
                 "seg3d_conv3d_k3_wino2d_fwd: shape not supported (whole 8^3 tiles, Cin %% 8 == 0, Cout %% 32 == 0)");
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) {
-      seg3d_set_error("conv3d_k3_wino2d: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SEG3D_ERR_LAUNCH;
-    }
-    configured = true;
-  }
+  static Seg3dOncePerDevice configured;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel), configured, "conv3d_k3_wino2d")) return rc;
   const int ntz = D / W2_TS, nty = H / W2_TS, ntx = W / W2_TS, ncog = Cout / 32;
   const int nitems = N * ntz * nty * ntx * ncog;
   dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
@@ -797,16 +789,8 @@ extern "C" int seg3d_conv3d_k3_wino2d_wgrad(const float* x, const float* dy, flo
   SEG3D_REQUIRE(x && dy && dw && workspace, "seg3d_conv3d_k3_wino2d_wgrad: null pointer");
   SEG3D_REQUIRE(seg3d_conv3d_k3_wino2d_wgrad_supported(N, D, H, W, Cin, Cout),
                 "seg3d_conv3d_k3_wino2d_wgrad: shape not supported (whole 4^3 tiles, Cin %% 4 == 0, Cout %% 4 == 0)");
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_wgrad_wino2d_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) {
-      seg3d_set_error("conv3d_k3_wgrad_wino2d: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SEG3D_ERR_LAUNCH;
-    }
-    configured = true;
-  }
+  static Seg3dOncePerDevice configured;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wgrad_wino2d_kernel), configured, "conv3d_k3_wgrad_wino2d")) return rc;
   const int slabs = g2_slabs(N, D, H, W, Cin, Cout);
   const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32, npairs = CIB32 * COB32;
   const int ntz = D / 4, nty = H / 4, ntx = W / 4;

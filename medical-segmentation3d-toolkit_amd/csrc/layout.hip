@@ -201,12 +201,15 @@ __global__ __launch_bounds__(256) void pack_mfma_bf16_kernel(const float* __rest
 }
 
 extern "C" long long seg3d_packed_mfma_bf16_elems(int A, int B, int T) {
+  if (T == SEG3D_WINO_T || T == SEG3D_WINO2D_T) return -1;   // no bf16 Winograd image: callers must not size a buffer for one
   return (long long)((B + 31) / 32) * ((A + 15) / 16) * T * 512;
 }
 
 extern "C" int seg3d_pack_weights_mfma_bf16(const float* w, void* wp, int A, int B, int T, long long sa, long long sb,
                                             int flip, void* stream) {
   SEG3D_REQUIRE(w && wp && A > 0 && B > 0 && T > 0, "seg3d_pack_weights_mfma_bf16: bad arguments");
+  SEG3D_REQUIRE(T != SEG3D_WINO_T && T != SEG3D_WINO2D_T,
+                "seg3d_pack_weights_mfma_bf16: T = 36 / 48 (Winograd images) exist in fp32 only");
   int AB = (A + 15) / 16, BB = (B + 31) / 32;
   i64 total = (i64)BB * AB * T * 512;
   hipLaunchKernelGGL(pack_mfma_bf16_kernel, dim3(seg3d_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
@@ -380,7 +383,7 @@ extern "C" long long seg3d_pack_job_blocks(int A, int B, int T) {
 extern "C" int seg3d_pack_weights_mfma_multi(const Seg3dPackJob* jobs_device, int njobs, long long total_blocks,
                                              void* stream) {
   SEG3D_REQUIRE(jobs_device && njobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31),
-                "seg3d_pack_weights_mfma_multi: bad arguments");   // every job must have T <= 27 (the kernels' taps)
+                "seg3d_pack_weights_mfma_multi: bad arguments");   // job T: 27 / 8 / 1 taps, or 36 / 48 = Winograd images (fp32 only)
   hipLaunchKernelGGL(pack_mfma_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device,
                      njobs);
   SEG3D_LAUNCH_CHECK("seg3d_pack_weights_mfma_multi");
@@ -388,7 +391,7 @@ extern "C" int seg3d_pack_weights_mfma_multi(const Seg3dPackJob* jobs_device, in
 }
 
 extern "C" long long seg3d_pack_job_blocks_bf16(int A, int B, int T) {
-  (void)T;
+  if (T == SEG3D_WINO_T || T == SEG3D_WINO2D_T) return -1;   // Winograd-transformed images exist in fp32 only (pack_mfma_chunk)
   return (long long)((B + 31) / 32) * ((A + 15) / 16);
 }
 

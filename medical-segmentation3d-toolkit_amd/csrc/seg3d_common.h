@@ -40,6 +40,31 @@ void seg3d_set_error(const char* fmt, ...);
 
 typedef long long i64;
 
+// MI355X in SPX mode: 256 CUs.  The persistent grids ("one workgroup per CU") and the slab counts of the weight-gradient
+// kernels -- and therefore the workspace-size queries, which are pure functions of the shape -- are sized for it.  The
+// kernels are correct for any CU count (items / slabs are walked with a stride of gridDim.x); on a partitioned device
+// (CPX: 32 CUs) they merely run in more rounds.
+#define SEG3D_NUM_CUS 256
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: several devices in one process are a supported flow
+// (load_single_model / TrainStep select their device), so the "already configured" flag is kept per device ordinal.
+struct Seg3dOncePerDevice {
+  bool done[64] = {};
+};
+static inline int seg3d_allow_full_lds(const void* kernel, Seg3dOncePerDevice& once, const char* name) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && once.done[dev]) return SEG3D_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+  if (e != hipSuccess) {
+    seg3d_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d: %s", name, dev, hipGetErrorString(e));
+    return SEG3D_ERR_LAUNCH;
+  }
+  if (tracked) once.done[dev] = true;
+  return SEG3D_OK;
+}
+
 static inline int seg3d_cdiv(i64 a, i64 b) { return (int)((a + b - 1) / b); }
 static inline int seg3d_round_up(int a, int b) { return ((a + b - 1) / b) * b; }
 

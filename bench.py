@@ -216,17 +216,26 @@ def pmc_traffic_gb(kernel_name):
     passes).  gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE under-reports wide coalesced reads
     by 2x, WRITE_SIZE is exact.  Counters cannot be collected from inside bench.py; returns None when absent."""
     prof = os.path.join(REPO, 'profiles')
-    cands = (['r02_bf16_pmc_fetch_write_per_kernel.json', 'r01_i_bf16_pmc_fetch_write_per_kernel.json'] if 'bf16' in kernel_name
-             else ['r02_pmc_fetch_write_per_kernel.json', 'r01_pmc_fetch_write_per_kernel.json'])
+    cands = (['r03_bf16_pmc_fetch_write_per_kernel.json', 'r02_bf16_pmc_fetch_write_per_kernel.json',
+              'r01_i_bf16_pmc_fetch_write_per_kernel.json'] if 'bf16' in kernel_name
+             else ['r03_pmc_fetch_write_per_kernel.json', 'r02_pmc_fetch_write_per_kernel.json', 'r01_pmc_fetch_write_per_kernel.json'])
     path = next((os.path.join(prof, c) for c in cands if os.path.isfile(os.path.join(prof, c))), None)
     if path is None:
         return None
     with open(path) as f:
         table = json.load(f)
-    e = table.get(kernel_name) or table.get(kernel_name.replace('void ', '', 1))   # non-template kernels print without 'void'
-    if not e or 'FETCH_SIZE_KB_per_launch' not in e or 'WRITE_SIZE_KB_per_launch' not in e:
+    base = kernel_name.replace('void ', '', 1)
+    # exact name first (non-template kernels print without 'void'); else every template instantiation of the kernel
+    # (`void name<...>`), averaged by launches -- the F(2x2,3x3) kernel has <BIAS, ADD> instantiations since round 3
+    hits = [e for k, e in table.items() if k in (kernel_name, base)]
+    if not hits:
+        hits = [e for k, e in table.items() if k.replace('void ', '', 1).startswith(base + '<')]
+    hits = [e for e in hits if 'FETCH_SIZE_KB_per_launch' in e and 'WRITE_SIZE_KB_per_launch' in e]
+    if not hits:
         return None
-    return round((2.0 * e['FETCH_SIZE_KB_per_launch'] + e['WRITE_SIZE_KB_per_launch']) * 1024 / 1e9, 3)
+    n = sum(e.get('launches', 1) for e in hits)
+    kb = sum((2.0 * e['FETCH_SIZE_KB_per_launch'] + e['WRITE_SIZE_KB_per_launch']) * e.get('launches', 1) for e in hits) / n
+    return round(kb * 1024 / 1e9, 3)
 
 
 def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):

@@ -329,24 +329,33 @@ __device__ __forceinline__ void k2_scatter_epilogue(f32x16 (&acc)[NACC], int o, 
     // the even tap, g4 = 2, 3 the same channels of the odd tap.  Cout % 8 == 0 and Cout <= 16 (host-checked).
     if (o >= 0) {
       const int nq = Cout >> 3;   // channel quads per lane half: 1 or 2
+      // ADD: all addend quads of the lane's 2^3 cell (8 taps x <= 2 quads) are requested BEFORE the first store.  Loaded tap by
+      // tap, each load followed the previous tap's stores, and on gfx9 the wait for a load also waits for every store issued
+      // before it (one in-order vmcnt): the epilogue ran at the latency of eight store + load round trips (round 2: 192 us
+      // for the 32 -> 16 data-gradient + skip addend of the top level, 0.33 of the HBM peak).  64 registers at most, beside 64
+      // of accumulators: inside the 256 of two workgroups per CU.
+      typename Seg3dQuad<OUT_BF>::raw ar[8][2];
+      if (ADD) {
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) {
+          const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
+          const i64 src = ((i64)o + (kz * Ho + ky) * Wo + kx) * lda + co0;
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            if (g < nq) ar[tap][g] = Seg3dQuad<OUT_BF>::load(addend, src + 8 * g);
+        }
+      }
 #pragma unroll
       for (int tap = 0; tap < 8; ++tap) {
         const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
         const i64 dsto = ((i64)o + (kz * Ho + ky) * Wo + kx) * Cout + co0;
-        typename Seg3dQuad<OUT_BF>::raw ar[2];
-        if (ADD) {
-          const i64 src = ((i64)o + (kz * Ho + ky) * Wo + kx) * lda + co0;
-#pragma unroll
-          for (int g = 0; g < 2; ++g)
-            if (g < nq) ar[g] = Seg3dQuad<OUT_BF>::load(addend, src + 8 * g);
-        }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           if (g < nq) {
             const int g4 = 2 * (tap & 1) + g;
             f32x4 v;
             f32x4 av = {0.f, 0.f, 0.f, 0.f};
-            if (ADD) av = Seg3dQuad<OUT_BF>::cvt(ar[g]);
+            if (ADD) av = Seg3dQuad<OUT_BF>::cvt(ar[tap][g]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               v[c] = acc[PAIR ? (tap >> 1) : 0][4 * g4 + c] + bv[g][c] + av[c];

@@ -83,6 +83,11 @@ __device__ long long* w2_stamp_buf;
 #define W2_STAMP(chunk, k)
 #endif
 
+// BIAS / ADD: is there a bias (forward launches) / a fused addend (data-gradient launches that take the residual-path gradient)?
+// Compile-time, not run-time: a data-gradient launch must not issue the (zero) bias load at all -- on gfx9 the wait for a
+// load issued after a group's stores also waits for those stores (one in-order vmcnt), and with neither load in the way the
+// epilogue of a plain data-gradient item takes 5 700 instead of 7 900 cycles (tools/ubench/wino2d_stamp.hip, mode 1).
+template <bool BIAS, bool ADD>
 __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                    const float* __restrict__ bias, float* __restrict__ y,
                                                                    float* __restrict__ stats, int N, int D, int H, int W, int Cin,
@@ -300,11 +305,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
           bv2 = ldb(st + 2);
         }
         // steps 0-9: DMA issue (weights first, they are needed first); steps 12-21: row stages; 24-33: column stages
+#ifndef W2_EXP_NODMA   // (diagnostic builds of tools/ubench/wino2d_stamp.hip drop one ingredient of the loop to price it)
         if (st < W2_WPW) dma_w(st, wsrc1, wdst1);
         else if (st - W2_WPW < W2_XPW) dma_x(st - W2_WPW, rdst2);
+#endif
+#ifndef W2_EXP_NOTR
         if (st >= 12 && st <= 18 && (st & 1) == 0) tr_read(rsrc1, (st - 12) >> 1);
         if (st >= 15 && st <= 21 && (st & 1) == 1) tr_x((st - 15) >> 1);
         if (st >= 24 && st <= 33 && (st - 24) % 3 == 0) tr_y(tdst1, (st - 24) / 3);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // A = weights, B = quads: D[co][quad], a lane owns quad (lane & 31) and channels 8 g + 4 (lane >> 5) + c
         acc[st & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw0[0], bv0[0], acc[st & 15], 0, 0, 0);
@@ -337,7 +346,19 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
     for (int g4 = 0; g4 < 4; ++g4) {
       const int co = co_lane + 8 * g4;
       if (co < Cout) {   // Cout % 4 == 0 (host-checked)
-        const f32x4 bvv = *reinterpret_cast<const f32x4*>(bias ? bias + co : w2_zero16);
+        f32x4 bvv = {0.f, 0.f, 0.f, 0.f};
+        if (BIAS) bvv = *reinterpret_cast<const f32x4*>(bias + co);
+        // fused addend: the group's four quads are requested BEFORE its accumulators are read and transformed, so their
+        // latency -- and the drain of the previous group's stores that the wait implies -- passes behind ~180 vector
+        // instructions.  Loaded next to each store (first version) the epilogue was 16 store + load round trips: 22 000 cycles
+        // per item against 13 000 now (mode 2 of the stamp harness; 96^3 32 -> 32: 177 -> 191 TFLOP/s algorithmic).  Fetching a
+        // group ahead of the previous group's stores needs 16 more registers and spills (54): measured slower.
+        f32x4 adq[4];
+        if (ADD) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            adq[k] = *reinterpret_cast<const f32x4*>(addend + (i64)(vo00 + (k >> 1) * W + (k & 1)) * Cout + co);
+        }
         f32x4 v[2][2];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -359,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const i64 off = (i64)(vo00 + i * W + j) * Cout + co;
-            if (addend) v[i][j] += *reinterpret_cast<const f32x4*>(addend + off);
+            if (ADD) v[i][j] += adq[2 * i + j];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               s0 += v[i][j][c];
@@ -415,13 +436,23 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_wino2d_fwd: null pointer");
   SEG3D_REQUIRE(seg3d_conv3d_k3_wino2d_supported(N, D, H, W, Cin, Cout),
                 "seg3d_conv3d_k3_wino2d_fwd: shape not supported (whole 8^3 tiles, Cin %% 8 == 0, Cout %% 32 == 0)");
-  static Seg3dOncePerDevice configured;
-  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel), configured, "conv3d_k3_wino2d")) return rc;
+  static Seg3dOncePerDevice configured[4];
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<false, false>), configured[0], "conv3d_k3_wino2d")) return rc;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<true, false>), configured[1], "conv3d_k3_wino2d")) return rc;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<false, true>), configured[2], "conv3d_k3_wino2d")) return rc;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<true, true>), configured[3], "conv3d_k3_wino2d")) return rc;
   const int ntz = D / W2_TS, nty = H / W2_TS, ntx = W / W2_TS, ncog = Cout / 32;
   const int nitems = N * ntz * nty * ntx * ncog;
   dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
-  hipLaunchKernelGGL(conv3d_k3_wino2d_kernel, grid, dim3(256), (size_t)W2_LDS_FLOATS * 4, (hipStream_t)stream, x, wp, bias, y,
-                     stats, N, D, H, W, Cin, Cout, ntz, nty, ntx, ncog, nitems, addend);
+#define W2_LAUNCH(B_, A_)                                                                                                       \
+  hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<B_, A_>), grid, dim3(256), (size_t)W2_LDS_FLOATS * 4, (hipStream_t)stream, x, wp, \
+                     bias, y, stats, N, D, H, W, Cin, Cout, ntz, nty, ntx, ncog, nitems, addend)
+  if (bias) {
+    if (addend) W2_LAUNCH(true, true); else W2_LAUNCH(true, false);
+  } else {
+    if (addend) W2_LAUNCH(false, true); else W2_LAUNCH(false, false);
+  }
+#undef W2_LAUNCH
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_fwd");
   return SEG3D_OK;
 }
@@ -653,8 +684,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
     xi ^= 1;
     yi = yi == 2 ? 0 : yi + 1;
     if (more) {
+#ifndef G2_EXP_NOTR    // (diagnostic builds: what do the exposed transform and its barrier cost?)
       transform(rawx + xi * G2_XS);   // the next tile's RAW x -> T
+#endif
+#ifndef G2_EXP_NOBAR2
       __syncthreads();
+#endif
     }
   }
   w2_dma_wait();   // nothing in flight when the workgroup's LDS is released

@@ -2,36 +2,42 @@
 // conv3d_k3_wino2d_kernel spends its cycles per K chunk.  Not part of the product library.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DW2_STAMPS -I include -I medical-segmentation3d-toolkit_amd/csrc \
 //         tools/ubench/wino2d_stamp.hip medical-segmentation3d-toolkit_amd/csrc/seg3d_api.cpp -o tools/ubench/wino2d_stamp
-#include "../../medical-segmentation3d-toolkit_amd/csrc/conv_wino2d.hip"
+#ifndef W2_SRC   // -DW2_SRC='"/path/to/an/experimental/copy.hip"' builds the harness around a variant of the kernel file
+#define W2_SRC "../../medical-segmentation3d-toolkit_amd/csrc/conv_wino2d.hip"
+#endif
+#include W2_SRC
 #include <stdio.h>
 #include <vector>
 int main(int argc, char** argv) {
   int N = 8, D = 96, H = 96, W = 96, C = 32;
   if (argc >= 6) { N = atoi(argv[1]); D = atoi(argv[2]); H = atoi(argv[3]); W = atoi(argv[4]); C = atoi(argv[5]); }
+  const int mode = argc >= 7 ? atoi(argv[6]) : 0;   // 0: bias (forward); 1: neither bias nor addend (plain data-gradient); 2: addend, no bias (fused data-gradient)
   const size_t nx = (size_t)N * D * H * W * C;
   const size_t nw = (size_t)(C / 32) * (C / 8) * 48 * 256;
   std::vector<float> hx(nx), hw(nw);
   unsigned s = 12345u;
   for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) % 2001 - 1000) * 1e-3f; }
   for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) % 2001 - 1000) * 1e-4f; }
-  float *x, *wp, *y, *bias;
+  float *x, *wp, *y, *bias, *addend = nullptr;
   long long* stamps;
   (void)hipMalloc(&x, nx * 4); (void)hipMalloc(&wp, nw * 4); (void)hipMalloc(&y, nx * 4);
   (void)hipMalloc(&bias, C * 4); (void)hipMemset(bias, 0, C * 4);
+  if (mode == 2) { (void)hipMalloc(&addend, nx * 4); (void)hipMemset(addend, 0, nx * 4); }
+  if (mode != 0) bias = nullptr;
   (void)hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); (void)hipMemcpy(wp, hw.data(), nw * 4, hipMemcpyHostToDevice);
   const size_t nst = 8 * 4 * 64 * 8;
   (void)hipMalloc(&stamps, nst * 8); (void)hipMemset(stamps, 0, nst * 8);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(w2_stamp_buf), &stamps, sizeof(stamps));
   for (int r = 0; r < 3; ++r) {
-    int rc = seg3d_conv3d_k3_wino2d_fwd(x, wp, bias, nullptr, y, nullptr, N, D, H, W, C, C, nullptr);
+    int rc = seg3d_conv3d_k3_wino2d_fwd(x, wp, bias, addend, y, nullptr, N, D, H, W, C, C, nullptr);
     if (rc) { printf("error %d\n", rc); return 1; }
   }
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0);
-  for (int r = 0; r < 10; ++r) seg3d_conv3d_k3_wino2d_fwd(x, wp, bias, nullptr, y, nullptr, N, D, H, W, C, C, nullptr);
+  for (int r = 0; r < 10; ++r) seg3d_conv3d_k3_wino2d_fwd(x, wp, bias, addend, y, nullptr, N, D, H, W, C, C, nullptr);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
-  printf("N=%d %d^3 C=%d: %.3f ms, %.1f TFLOP/s algorithmic (stamped build)\n", N, D, C, ms, 2.0 * N * D * H * W * 27 * C * C / ms / 1e9);
+  printf("N=%d %d^3 C=%d mode %d: %.3f ms, %.1f TFLOP/s algorithmic (stamped build)\n", N, D, C, mode, ms, 2.0 * N * D * H * W * 27 * C * C / ms / 1e9);
   std::vector<long long> h(nst);
   (void)hipMemcpy(h.data(), stamps, nst * 8, hipMemcpyDeviceToHost);
   const char* names[4] = {"MFMA loop (+ DMA issue, transform stages)", "cursor advance + DMA wait", "barrier", "to next loop start (per-item work)"};

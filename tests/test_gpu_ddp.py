@@ -20,14 +20,14 @@ def _free_port():
     return port
 
 
-def _data():
+def _data(ncls=2):
     from oracle import detgen
     x = torch.from_numpy(detgen.normal(81, 'ddp/x', (2, 1, 32, 32, 32)))
-    t = torch.from_numpy(detgen.labels(82, 'ddp/t', (2, 1, 32, 32, 32), 2))
+    t = torch.from_numpy(detgen.labels(82, 'ddp/t', (2, 1, 32, 32, 32), ncls))
     return x, t
 
 
-def _worker(rank, world, port, out, mode):
+def _worker(rank, world, port, out, mode, ncls=2):
     from conftest import PKG  # noqa: F401  (sys.path)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -36,8 +36,8 @@ def _worker(rank, world, port, out, mode):
     from segmentation3d.core.seg_train import TrainStep
     from segmentation3d import _ops
     _ops.set_activation_dtype(mode)
-    step = TrainStep('vnet', 1, 2, 'Dice', [0.5, 0.5], device=torch.device('cuda:0'), seed=rank)  # different init per rank
-    x, t = _data()
+    step = TrainStep('vnet', 1, ncls, 'Dice', [1.0 / ncls] * ncls, device=torch.device('cuda:0'), seed=rank)  # different init per rank
+    x, t = _data(ncls)
     dev = step.device
     loss = step(x[rank:rank + 1].to(dev), t[rank:rank + 1].to(dev))
     torch.cuda.synchronize()
@@ -49,11 +49,12 @@ def _worker(rank, world, port, out, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
-def test_two_rank_train_step_matches_global_batch(hip_device, tmp_path, mode):
-    """(bf16 mode: the gradients that are all-reduced are fp32 either way; the reference run below uses the same mode)"""
+@pytest.mark.parametrize('mode,ncls', [('fp32', 2), ('bf16', 2), ('fp32', 5)])
+def test_two_rank_train_step_matches_global_batch(hip_device, tmp_path, mode, ncls):
+    """(bf16 mode: the gradients that are all-reduced are fp32 either way; the reference run below uses the same mode.
+    ncls = 5: BASELINE config 3's network, vnet(1,5), under data parallelism)"""
     world, port, out = 2, _free_port(), str(tmp_path / 'rank{}.pt')
-    mp.spawn(_worker, args=(world, port, out, mode), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, mode, ncls), nprocs=world, join=True)
     r0 = torch.load(out.format(0), weights_only=True)
     r1 = torch.load(out.format(1), weights_only=True)
     assert torch.equal(r0['params'], r1['params'])          # broadcast at start + identical reduced gradients
@@ -64,8 +65,8 @@ def test_two_rank_train_step_matches_global_batch(hip_device, tmp_path, mode):
     assert r0['overlapped'] == 4 and r1['overlapped'] == 4
     from segmentation3d.core.seg_train import TrainStep
     from segmentation3d import _ops
-    ref = TrainStep('vnet', 1, 2, 'Dice', [0.5, 0.5], device=hip_device, seed=0, distributed=False)
-    x, t = _data()
+    ref = TrainStep('vnet', 1, ncls, 'Dice', [1.0 / ncls] * ncls, device=hip_device, seed=0, distributed=False)
+    x, t = _data(ncls)
     ref.opt.zero_grad()
     with _ops.activation_dtype(mode):
         loss = ref.loss_func(ref.net(x.to(hip_device)), t.to(hip_device))
@@ -138,7 +139,12 @@ def test_two_rank_sharded_sliding_window_matches_single_rank(hip_device, tmp_pat
     assert 0 < r[0]['moved_planes'] <= 32                   # only the halo of one box travels, not 80 planes x (C + 1)
     for k in range(world):
         assert float((r[k]['probs'] - probs.cpu()).abs().max()) < 1e-6
-        assert float((r[k]['mask'] != mask.cpu()).float().mean()) < 1e-4
+        # arg-max masks are integer work: a slab-sharded run may only differ from the single-rank run where the halo sum
+        # order (rounding, <= 1e-6 above) decides between two classes that tie to that rounding
+        diff = r[k]['mask'] != mask.cpu()
+        if bool(diff.any()):
+            top2 = probs.cpu()[:, diff].topk(2, dim=0).values
+            assert float((top2[0] - top2[1]).max()) < 4e-6, int(diff.sum())
     assert torch.equal(r[0]['probs'], r[1]['probs']) and torch.equal(r[0]['mask'], r[1]['mask'])
 
 

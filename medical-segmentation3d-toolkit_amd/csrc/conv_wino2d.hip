@@ -84,9 +84,10 @@ __device__ long long* w2_stamp_buf;
 #endif
 
 // BIAS / ADD: is there a bias (forward launches) / a fused addend (data-gradient launches that take the residual-path gradient)?
-// Compile-time, not run-time: a data-gradient launch must not issue the (zero) bias load at all -- on gfx9 the wait for a
-// load issued after a group's stores also waits for those stores (one in-order vmcnt), and with neither load in the way the
-// epilogue of a plain data-gradient item takes 5 700 instead of 7 900 cycles (tools/ubench/wino2d_stamp.hip, mode 1).
+// Compile-time, not run-time: the epilogue must not contain a load it does not need -- on gfx9 the wait for a load issued
+// after a group's stores also waits for those stores (one in-order vmcnt); without any load the epilogue of an item takes
+// 5 700 instead of 7 900 cycles (tools/ubench/wino2d_stamp.hip, mode 1).  The bias therefore enters at accumulator
+// initialisation (below), not in the epilogue.
 template <bool BIAS, bool ADD>
 __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                    const float* __restrict__ bias, float* __restrict__ y,
@@ -276,11 +277,29 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
     const int next_item = item + istride;
     const bool more_items = next_item < ilimit;
 
+    // The bias enters through the accumulator of point (py, px) = (1, 1): the output transform Y = A^T M A adds M[1][1] to each of
+    // the quad's four outputs once (r0[1] and r1[1] both contain it with weight +1, and each output takes row entry 1 with
+    // weight +1), so starting that accumulator at b instead of 0 yields + b on every output.  The lane's 16 channels (8 g + 4 lh
+    // + c) come through SCALAR loads of the column block's 32 biases (wave-uniform address, selected per lane half): loaded
+    // in the epilogue instead, each group's vector load followed the previous group's stores, and on gfx9 the wait for a load
+    // also waits for every store issued before it -- 7 200 cycles per item against 5 700 for an item without bias
+    // (tools/ubench/wino2d_stamp.hip).  The scalar loads count on lgkmcnt and land behind the 240 register writes below.
     f32x16 acc[16];
+    {
+      float binit[16];
+      if (BIAS) {
+        const int cb = __builtin_amdgcn_readfirstlane(cur_cog * 32);
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+        for (int r = 0; r < 16; ++r) {
+          const float b0 = bias[cb + 8 * (r >> 2) + (r & 3)], b1 = bias[cb + 8 * (r >> 2) + 4 + (r & 3)];
+          binit[r] = lh ? b1 : b0;
+        }
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+      for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = (BIAS && p == 5) ? binit[r] : 0.f;
+    }
     for (int sc = 0; sc < NSC; ++sc) {
       const float* ws = wbuf + ci_ * W2_W;
       const float* tcur = timg + ci_ * W2_T;
@@ -346,8 +365,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
     for (int g4 = 0; g4 < 4; ++g4) {
       const int co = co_lane + 8 * g4;
       if (co < Cout) {   // Cout % 4 == 0 (host-checked)
-        f32x4 bvv = {0.f, 0.f, 0.f, 0.f};
-        if (BIAS) bvv = *reinterpret_cast<const f32x4*>(bias + co);
         // fused addend: the group's four quads are requested BEFORE its accumulators are read and transformed, so their
         // latency -- and the drain of the previous group's stores that the wait implies -- passes behind ~180 vector
         // instructions.  Loaded next to each store (first version) the epilogue was 16 store + load round trips: 22 000 cycles
@@ -370,10 +387,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
             r0[px] = (m0 + m1) + m2;
             r1[px] = (m1 - m2) - m3;
           }
-          v[0][0][c] = ((r0[0] + r0[1]) + r0[2]) + bvv[c];
-          v[0][1][c] = ((r0[1] - r0[2]) - r0[3]) + bvv[c];
-          v[1][0][c] = ((r1[0] + r1[1]) + r1[2]) + bvv[c];
-          v[1][1][c] = ((r1[1] - r1[2]) - r1[3]) + bvv[c];
+          v[0][0][c] = (r0[0] + r0[1]) + r0[2];
+          v[0][1][c] = (r0[1] - r0[2]) - r0[3];
+          v[1][0][c] = (r1[0] + r1[1]) + r1[2];
+          v[1][1][c] = (r1[1] - r1[2]) - r1[3];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)

@@ -146,6 +146,9 @@ template <> struct GnQuad<true> {
 // (voxel, channel quad, sample) of a grid-stride loop over [total_vox][CQ] quads WITHOUT per-element divisions: idx / CQ and
 // v / S are 64-bit divisions (~70 vector instructions each, two per 16 bytes moved); the walker divides once per thread and
 // then advances by the constant stride with adds and compares
+#ifndef GN_U
+#define GN_U 2   // quads per thread and trip in the apply passes (1 / 2 / 4 measured: 16.00 / 15.95 / 15.99 ms per step, i.e. equal within the noise -- the passes sit at what the memory system gives a 3-read + 2-write stream)
+#endif
 struct GnWalker {
   i64 v;       // voxel (row of the [total_vox][C] tensor)
   i64 vs;      // voxel within its sample
@@ -190,11 +193,13 @@ __device__ __forceinline__ void gn_apply_body(const float* __restrict__ y, const
     const i64 total = total_vox * CQ;
     const i64 stride = (i64)gridDim.x * 256;
     GnWalker wk((i64)blockIdx.x * 256 + threadIdx.x, stride, CQ, S);
-    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride, wk.step(CQ, S)) {
-      const i64 v = wk.v;
-      const int q = wk.q, n = wk.n;
+    // GN_U quads per trip, every load issued before the first store: a wave keeps GN_U x (1 or 2) 16-byte loads in flight
+    // instead of one or two -- what counts when these passes share a CU with a weight-gradient kernel of the side stream and
+    // get a fraction of the wave slots, and it keeps a trip's loads clear of the previous trip's stores
+    // (on gfx9 the wait for a load also waits for the stores issued before it)
+    auto one = [&](i64 idx, i64 v, int q, int n, typename GnQuad<Y_BF>::raw yraw, typename GnQuad<RES_BF>::raw rraw) {
       const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
-      const seg3d_f32x4 yq = GnQuad<Y_BF>::cvt(GnQuad<Y_BF>::load(y, idx * 4));   // y: bf16 storage when Y_BF
+      const seg3d_f32x4 yq = GnQuad<Y_BF>::cvt(yraw);   // y: bf16 storage when Y_BF
       const float4 yv = make_float4(yq[0], yq[1], yq[2], yq[3]);
       const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * q);
       const float4 b = *reinterpret_cast<const float4*>(beta + 4 * q);
@@ -204,7 +209,7 @@ __device__ __forceinline__ void gn_apply_body(const float* __restrict__ y, const
       o.z = (yv.z - mean) * rstd * g.z + b.z;
       o.w = (yv.w - mean) * rstd * g.w + b.w;
       if (res) {
-        const seg3d_f32x4 rv = GnQuad<RES_BF>::cvt(GnQuad<RES_BF>::load(res_v, idx * 4));
+        const seg3d_f32x4 rv = GnQuad<RES_BF>::cvt(rraw);
         o.x += rv[0]; o.y += rv[1]; o.z += rv[2]; o.w += rv[3];
       }
       if (relu) {
@@ -212,6 +217,27 @@ __device__ __forceinline__ void gn_apply_body(const float* __restrict__ y, const
       }
       const seg3d_f32x4 ov = {o.x, o.y, o.z, o.w};
       GnQuad<OUT_BF>::store(out_v, v * ldo + 4 * q, ov);
+    };
+    i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+    for (; idx + (GN_U - 1) * stride < total; idx += GN_U * stride) {
+      i64 vv[GN_U];
+      int qq[GN_U], nn[GN_U];
+      typename GnQuad<Y_BF>::raw yraw[GN_U];
+      typename GnQuad<RES_BF>::raw rraw[GN_U];
+#pragma unroll
+      for (int u = 0; u < GN_U; ++u) {
+        vv[u] = wk.v, qq[u] = wk.q, nn[u] = wk.n;
+        wk.step(CQ, S);
+        yraw[u] = GnQuad<Y_BF>::load(y, (idx + u * stride) * 4);
+        if (res) rraw[u] = GnQuad<RES_BF>::load(res_v, (idx + u * stride) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < GN_U; ++u) one(idx + u * stride, vv[u], qq[u], nn[u], yraw[u], rraw[u]);
+    }
+    for (; idx < total; idx += stride, wk.step(CQ, S)) {
+      typename GnQuad<RES_BF>::raw rraw = {};
+      if (res) rraw = GnQuad<RES_BF>::load(res_v, idx * 4);
+      one(idx, wk.v, wk.q, wk.n, GnQuad<Y_BF>::load(y, idx * 4), rraw);
     }
   } else {
     const i64 total = total_vox * C;
@@ -693,20 +719,21 @@ __device__ __forceinline__ void gn_bwd_apply_body(const void* __restrict__ dout_
     const i64 total = total_vox * CQ;
     const i64 stride = (i64)gridDim.x * 256;
     GnWalker wk((i64)blockIdx.x * 256 + threadIdx.x, stride, CQ, S);
-    for (i64 idx = (i64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride, wk.step(CQ, S)) {
-      const i64 v = wk.v;
-      const int q = wk.q, n = wk.n;
+    const bool need_out = relu && out;
+    // GN_U quads per trip, all loads ahead of the first store (see gn_apply_body)
+    auto one = [&](i64 idx, int q, int n, typename GnQuad<ACT_BF>::raw graw, typename GnQuad<Y_BF>::raw yraw,
+                   typename GnQuad<ACT_BF>::raw oraw) {
       const float mean = mean_rstd[2 * n], rstd = mean_rstd[2 * n + 1];
       const float s1 = s12[2 * n], s2 = s12[2 * n + 1];
-      const seg3d_f32x4 gq = GnQuad<ACT_BF>::cvt(GnQuad<ACT_BF>::load(dout_v, v * ldd + 4 * q));
+      const seg3d_f32x4 gq = GnQuad<ACT_BF>::cvt(graw);
       float4 g = make_float4(gq[0], gq[1], gq[2], gq[3]);
-      const seg3d_f32x4 yq = GnQuad<Y_BF>::cvt(GnQuad<Y_BF>::load(y, idx * 4));
+      const seg3d_f32x4 yq = GnQuad<Y_BF>::cvt(yraw);
       const float4 yv = make_float4(yq[0], yq[1], yq[2], yq[3]);
       const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * q);
       if (relu) {
         float4 o;
         if (out) {
-          const seg3d_f32x4 oq = GnQuad<ACT_BF>::cvt(GnQuad<ACT_BF>::load(out_v, idx * 4));
+          const seg3d_f32x4 oq = GnQuad<ACT_BF>::cvt(oraw);
           o = make_float4(oq[0], oq[1], oq[2], oq[3]);
         } else {
           const float4 bt = *reinterpret_cast<const float4*>(beta + 4 * q);
@@ -723,6 +750,27 @@ __device__ __forceinline__ void gn_bwd_apply_body(const void* __restrict__ dout_
       const seg3d_f32x4 dq = {d.x, d.y, d.z, d.w};
       GnQuad<DY_BF>::store(dy_v, idx * 4, dq);
       if (dres) *reinterpret_cast<float4*>(dres + idx * 4) = g;
+    };
+    i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+    for (; idx + (GN_U - 1) * stride < total; idx += GN_U * stride) {
+      int qq[GN_U], nn[GN_U];
+      typename GnQuad<ACT_BF>::raw graw[GN_U], oraw[GN_U];
+      typename GnQuad<Y_BF>::raw yraw[GN_U];
+#pragma unroll
+      for (int u = 0; u < GN_U; ++u) {
+        qq[u] = wk.q, nn[u] = wk.n;
+        graw[u] = GnQuad<ACT_BF>::load(dout_v, wk.v * ldd + 4 * wk.q);
+        wk.step(CQ, S);
+        yraw[u] = GnQuad<Y_BF>::load(y, (idx + u * stride) * 4);
+        if (need_out) oraw[u] = GnQuad<ACT_BF>::load(out_v, (idx + u * stride) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < GN_U; ++u) one(idx + u * stride, qq[u], nn[u], graw[u], yraw[u], oraw[u]);
+    }
+    for (; idx < total; idx += stride, wk.step(CQ, S)) {
+      typename GnQuad<ACT_BF>::raw oraw = {};
+      if (need_out) oraw = GnQuad<ACT_BF>::load(out_v, idx * 4);
+      one(idx, wk.q, wk.n, GnQuad<ACT_BF>::load(dout_v, wk.v * ldd + 4 * wk.q), GnQuad<Y_BF>::load(y, idx * 4), oraw);
     }
   } else {
     const i64 total = total_vox * C;

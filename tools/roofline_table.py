@@ -50,8 +50,11 @@ for r in stats[:40]:
         gb = (2.0 * e['FETCH_SIZE_KB_per_launch'] + e['WRITE_SIZE_KB_per_launch']) * 1024 / 1e9
     gbs = gb / (avg_us * 1e-6) if gb else None
     tf = None
-    if short in variant_flops and variant_flops[short][1] > 0:
-        tf = variant_flops[short][0] / (variant_flops[short][1] * 1e-3) / 1e12
+    # template instantiations of one kernel (conv3d_k3_wino2d_kernel<BIAS, ADD> since round 3) share the live shape report's
+    # entry of the base name: their TFLOP/s figure is the average over all instantiations
+    vkey = short if short in variant_flops else short.split('<')[0]
+    if vkey in variant_flops and variant_flops[vkey][1] > 0:
+        tf = variant_flops[vkey][0] / (variant_flops[vkey][1] * 1e-3) / 1e12
     print('| `{}` | {:.1f} | {:.3f} | {:.1f} | {} | {} | {} | {} | {} |'.format(
         short[:60], calls, ms, avg_us, '-' if gb is None else '{:.3f}'.format(gb), '-' if gbs is None else '{:.0f}'.format(gbs),
         '-' if gbs is None else '{:.0f}'.format(100 * gbs / HBM_PEAK_GBS), '-' if tf is None else '{:.1f}'.format(tf),

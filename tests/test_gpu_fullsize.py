@@ -210,3 +210,44 @@ def test_vnet_4_4_one_patch_128_fp32_and_bf16(hip_device, monkeypatch):
     assert b['probs_max'] < 3e-2 and b['probs_mean'] < 3e-3 and b['loss'] < 3e-3 and b['loss_vs_oracle'] < 3e-3, b
     assert b['grad_cos_min'] > 0.8, b
     assert b['n_bf16_fwd'] >= 20 and b['n_bf16_wgrad'] >= 10, b
+
+
+def test_vnet_1_5_four_patches_96_focal_and_dice(hip_device, monkeypatch):
+    """BASELINE config 3's per-GPU workload: vnet(1,5), FOUR 96^3 patches, forward + loss + backward against the oracle, once
+    with the Dice loss and once with the reference's default Focal loss (config/train_config.py:89).  Five classes put the
+    head on other kernels than the two-class headline (the 5-channel fp32 head forward, its data-gradient zero-padded to 8
+    channels on the Winograd kernel, the 1x1x1 conv with 5 outputs)."""
+    from segmentation3d.network import vnet
+    from segmentation3d.loss.multi_dice_loss import MultiDiceLoss
+    from segmentation3d.loss.focal_loss import FocalLoss
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    spy = _Spy(monkeypatch)
+    net = vnet.SegmentationNet(1, 5)
+    sd = _load(net, 21)
+    net = net.to(hip_device)
+    x = torch.from_numpy(detgen.normal(97, 'full15/x', (4, 1, 96, 96, 96))).clamp_(-3, 3)
+    t = torch.from_numpy(detgen.labels(98, 'full15/t', (4, 1, 96, 96, 96), 5))
+    w = [0.2] * 5
+    for loss_name in ('dice', 'focal'):
+        ref_sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
+        rp = torch_ref.segmentation_net(x, ref_sd, 'vnet')
+        rl = torch_ref.multi_dice_loss(rp, t, w) if loss_name == 'dice' else torch_ref.focal_loss(rp, t, 5, alpha=None, gamma=2)
+        rl.backward()
+        del spy.called[:]
+        net.zero_grad()
+        probs = net(x.to(hip_device))
+        if loss_name == 'dice':
+            loss = MultiDiceLoss(w, 5, use_gpu=True)(probs, t.to(hip_device))
+        else:
+            loss = FocalLoss(class_num=5, alpha=None, gamma=2, use_gpu=True)(probs, t.to(hip_device))
+        loss.backward()
+        torch.cuda.synchronize()
+        params = dict(net.named_parameters())
+        e = dict(probs=max_err(probs, rp), loss=abs(float(loss.detach()) - float(rl.detach())))
+        e.update(_grad_errors(params, ref_sd, dict(stem='in_block.conv.weight', up32='up_32.rblock.ops.0.conv.weight',
+                                                   head='out_block.conv1.weight', head2='out_block.conv2.weight')))
+        c = spy.counts(WINO_FWD, *WINO_WGRADS)
+        report('vnet_1_5_4x96_' + loss_name, **e, **{k.replace('seg3d_conv3d_k3_', 'n_'): float(v) for k, v in c.items()})
+        assert e['probs'] < 1e-4 and e['loss'] < 1e-4, e
+        assert all(v < 2e-2 for k, v in e.items() if k.startswith('g')), e
+        assert c[WINO_FWD] >= 18, c

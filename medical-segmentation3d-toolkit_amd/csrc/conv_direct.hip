@@ -287,6 +287,53 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const float* __restri
   }
 }
 
+// 1x1x1 convolution between two THIN tensors (the head's second conv, vnet_outblock.py:16: classes -> classes, <= 8 channels
+// on both sides): one voxel per thread and trip, the CA x CB products in registers, one partial slab per workgroup in the
+// layout of wgrad_direct_kernel (part[chunk][0][a][bp]).  The generic kernel above puts (a, b quad) pairs across threads: with
+// 5 x 5 channels that is 10 pairs x 16 voxel lanes per workgroup and scalar loads behind each other -- 0.37 ms per step for
+// 140 MB of input (vnet(1,5), BASELINE config 3) where this pass takes the time of reading them once.
+__global__ __launch_bounds__(256) void wgrad_k1_thin_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                              float* __restrict__ part, i64 nvox, int CA, int CB, int CBP,
+                                                              int chunk_vox) {
+  __shared__ float red[4][64];
+  const i64 v0 = (i64)blockIdx.x * chunk_vox;
+  i64 v1 = v0 + chunk_vox;
+  if (v1 > nvox) v1 = nvox;
+  float acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = 0.f;
+  for (i64 v = v0 + threadIdx.x; v < v1; v += 256) {
+    float pv[8], qv[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) pv[a] = a < CA ? P[v * CA + a] : 0.f;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) qv[b] = b < CB ? Q[v * CB + b] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[a][b] = fmaf(pv[a], qv[b], acc[a][b]);
+  }
+  // wave sums (shuffles), then the four waves in fixed order through LDS: reproducible
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const float sum = wave_sum(acc[a][b]);
+      if (lane == 0) red[wave][a * 8 + b] = sum;
+    }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int a = threadIdx.x >> 3, b = threadIdx.x & 7;
+    if (a < CA && b < CBP) {
+      const float sum = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+      part[((i64)blockIdx.x * CA + a) * CBP + b] = b < CB ? sum : 0.f;
+    }
+  }
+}
+
 // number of partial slabs: ~2048 voxels per chunk, at most 512 chunks and at most 64 MiB of slabs
 static int wgrad_direct_chunks(i64 nvox, int T, int CA, int CBP) {
   i64 chunks = (nvox + 2047) / 2048;
@@ -332,6 +379,8 @@ extern "C" int seg3d_wgrad_direct(const float* P, const float* Q, float* part, i
   } else if (ksize == 2 && stride == 2) {
     hipLaunchKernelGGL((wgrad_direct_kernel<2, 2, 0>), grid, block, 0, s, P, Q, part, N, Dp, Hp, Wp_, Dq, Hq, Wq, CA, CB,
                        CBP, PAIRS, chunk_vox);
+  } else if (ksize == 1 && stride == 1 && CA <= 8 && CB <= 8) {
+    hipLaunchKernelGGL(wgrad_k1_thin_kernel, dim3(chunks), block, 0, s, P, Q, part, nvox, CA, CB, CBP, chunk_vox);
   } else if (ksize == 1 && stride == 1) {
     hipLaunchKernelGGL((wgrad_direct_kernel<1, 1, 0>), grid, block, 0, s, P, Q, part, N, Dp, Hp, Wp_, Dq, Hq, Wq, CA, CB,
                        CBP, PAIRS, chunk_vox);

@@ -10,7 +10,8 @@ gradient buffer (58.3 MB for the 14.56 M-parameter V-Net) per step:
     bucket's all-reduce is enqueued from a post-accumulate hook as soon as its last gradient has been written, so the
     transfer overlaps the rest of backward (RCCL runs on its own stream, ordered after the producing kernels);
   * xGMI is a point-to-point full mesh (7 links/GPU): a few large buckets (default 4 x ~16 MB) keep every link busy
-    without paying per-collective latency 116 times; the 1/world scaling is folded into the Adam kernel.
+    without paying per-collective latency 116 times; the bucket that completes last is split so that only ~1 MB of it
+    is reduced after backward has ended; the 1/world scaling is folded into the Adam kernel.
 GroupNorm(1, C) statistics are per sample, Dice is per sample then batch mean and Focal is a mean over voxels, so with
 equal per-rank batches the averaged gradient equals the global-batch gradient: no other collective is needed.
 """
@@ -44,15 +45,49 @@ class FlatGradients(object):
         return [(p, 0, off, p.numel()) for p, off in zip(self.params, self.offsets)]
 
 
+def bucket_cuts(entries, total, num_buckets=4, tail_elems=1 << 18):
+    """[(lo, hi, [params])] in the order the buckets complete in backward, for one flat buffer whose `entries` are
+    (param, offset, numel) in buffer order.  Byte-balanced cuts at parameter boundaries walking from the END of the buffer
+    (those gradients arrive first), then the last-completing bucket is split:
+
+    the bucket at the START of the buffer completes with the very last weight gradient of backward (the stem's), so its
+    all-reduce is the one transfer nothing can hide.  The parameters whose gradients arrive last (about the first
+    `tail_elems` elements of the buffer: stem and the first encoder stages, 0.6 MB for the V-Net) form a small bucket of their
+    own, and the rest of the old bucket (the deeper encoder stages: 8-14 MB) is reduced while those last stages are still in
+    backward.  tail_elems = 0, or a bucket that is not at least twice that size: no split."""
+    target = max(1, total // max(1, num_buckets))
+    cuts = []
+    hi, acc, members = total, 0, []
+    for p, off, n in reversed(entries):
+        members.append(p)
+        acc += n
+        if acc >= target and len(cuts) < num_buckets - 1:
+            cuts.append((off, hi, members))
+            hi, acc, members = off, 0, []
+    if members:
+        cuts.append((0, hi, members))
+    if tail_elems and cuts and cuts[-1][0] == 0 and cuts[-1][1] >= 2 * tail_elems:
+        lo, hi_last, mem = cuts[-1]                 # mem is in reverse buffer order: mem[-1] is the first parameter
+        offs = {id(p): off for p, off, n in entries}
+        split = next((offs[id(p)] for p in mem if offs[id(p)] <= tail_elems), None)   # largest offset <= tail_elems
+        if split is not None and 0 < split < hi_last:
+            head = [p for p in mem if offs[id(p)] >= split]
+            tail = [p for p in mem if offs[id(p)] < split]
+            cuts[-1:] = [(split, hi_last, head), (0, split, tail)]
+    return cuts
+
+
 class GradientReducer(object):
     """bucketed, backward-overlapped sum all-reduce of flat gradient buffers.
 
     :param flat_buffers: list of flat gradient tensors (one per parameter group)
     :param layout: [(param, buffer index, offset, numel)] in buffer order
     :param num_buckets: buckets per buffer (cut by bytes, aligned to parameter boundaries)
+    :param tail_elems: the bucket that completes last is split so that its final part holds at most about this many
+                       elements (0 = no split); see the comment in __init__
     """
 
-    def __init__(self, flat_buffers, layout, process_group=None, num_buckets=4):
+    def __init__(self, flat_buffers, layout, process_group=None, num_buckets=4, tail_elems=1 << 18):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.group = process_group
@@ -68,18 +103,9 @@ class GradientReducer(object):
             entries = [(p, off, n) for p, b, off, n in layout if b == bi]
             if not entries:
                 continue
-            total = buf.numel()
-            target = max(1, total // max(1, num_buckets))
-            # walk parameters from the END of the buffer (their gradients arrive first in backward)
-            hi, acc, members = total, 0, []
-            for p, off, n in reversed(entries):
-                members.append(p)
-                acc += n
-                if acc >= target and len(self._buckets_for(bi)) < num_buckets - 1:
-                    self._add_bucket(bi, off, hi, members)
-                    hi, acc, members = off, 0, []
-            if members:
-                self._add_bucket(bi, 0, hi, members)
+            cuts = bucket_cuts(entries, buf.numel(), num_buckets, tail_elems)
+            for lo, hi_b, mem in cuts:
+                self._add_bucket(bi, lo, hi_b, mem)
         # autograd runs a leaf's AccumulateGrad node (and this hook) once all of its uses have been processed, also
         # when the producing function returned None because its kernel wrote the gradient straight into the flat
         # buffer (gradient sinks, _grad_sink.py) -- so the hook is the "gradient ready" signal in both modes.  Should a

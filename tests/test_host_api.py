@@ -242,3 +242,28 @@ def test_image_readers_against_independent_fixtures(tmp_path):
             assert np.array_equal(back.array, img.array) and back.array.dtype == img.array.dtype, (name, ext)
             assert np.allclose(back.GetSpacing(), exp['spacing'], rtol=1e-6) and np.allclose(back.GetOrigin(), exp['origin'], rtol=1e-6, atol=1e-6)
             assert np.allclose(back.GetDirection(), exp['direction'], atol=1e-6), (name, ext)
+
+
+def test_gradient_bucket_cuts_of_the_vnet():
+    """core/ddp.bucket_cuts on the real V-Net layout: buckets tile the flat gradient buffer, complete in backward order (end of
+    the buffer first), and the last-completing one -- the only all-reduce nothing can overlap -- is the small tail (stem and
+    first encoder stages, < 1.1 MB) split off the deep encoder stages"""
+    from segmentation3d.core.ddp import bucket_cuts
+    from segmentation3d.network import vnet
+    net = vnet.SegmentationNet(1, 2)
+    entries, off = [], 0
+    for name, p in net.named_parameters():
+        entries.append((p, off, p.numel()))
+        off += p.numel()
+    cuts = bucket_cuts(entries, off, num_buckets=4)
+    assert len(cuts) == 5
+    assert cuts[0][1] == off and cuts[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(cuts[:-1], cuts[1:]))                 # contiguous, descending
+    assert sum(len(c[2]) for c in cuts) == len(entries)
+    names = {id(p): n for n, p in net.named_parameters()}
+    tail = [names[id(p)] for p in cuts[-1][2]]
+    assert 'in_block.conv.weight' in tail and all(n.split('.')[0] in ('in_block', 'down_32', 'down_64') for n in tail)
+    assert 0 < cuts[-1][1] <= (1 << 18) and cuts[-2][1] - cuts[-2][0] > (1 << 20)  # <= 1 MB exposed, > 4 MB moved under backward
+    assert len(bucket_cuts(entries, off, num_buckets=4, tail_elems=0)) == 4
+    small = entries[:6]
+    assert len(bucket_cuts(small, sum(e[2] for e in small), num_buckets=2)) == 2   # small buffers are not split

@@ -778,11 +778,55 @@ _SIDE_STREAMS = {}
 _JOIN_QUEUED_FOR = [-1]   # id of the backward pass (graph task) whose end-of-backward join is already queued
 
 
+def _runs_beside(busy, other, spin_cycles=1500000):
+    """does a kernel launched on stream `other` run while an earlier kernel on stream `busy` is still executing?  HIP maps
+    streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two streams that land on one queue are
+    serialised however independent their work is.  Probe: a busy-wait kernel on `busy`, then a small kernel on `other` -- on
+    its own queue it completes long before the spin ends.  (The order matters with the null stream: a pool-stream kernel
+    launched AFTER a null-stream kernel always waits for it on this stack, the reverse order overlaps -- and that is the order
+    of the train step: a long weight gradient on the side stream first, the main stream's short kernels behind it.)"""
+    probe = torch.zeros(1024, device=busy.device)
+    votes = 0
+    for _ in range(3):             # majority of three: a single reading can be spoilt by a late launch of the probe kernel
+        torch.cuda.synchronize()
+        s0, e_busy, e_other = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        s0.record(busy)
+        other.wait_event(s0)
+        with torch.cuda.stream(busy):
+            torch.cuda._sleep(spin_cycles)
+        e_busy.record(busy)
+        with torch.cuda.stream(other):
+            probe.add_(1.0)        # a real dispatch, not just a marker packet
+        e_other.record(other)
+        torch.cuda.synchronize()
+        votes += int(s0.elapsed_time(e_other) < 0.5 * s0.elapsed_time(e_busy))
+    return votes >= 2
+
+
 def _side_stream(device):
+    """the weight-gradient side stream of a device, created at first use: the first of a few fresh streams that demonstrably
+    lets the current (main) stream's kernels run BESIDE its own.  Without the probe the choice is an accident of creation order
+    -- with nothing but an RCCL communicator initialised in the process the next pool stream shares the main stream's hardware
+    queue (tools/stream_probe.py), the
+    overlap of weight gradients with the data-gradient chain is gone and the fp32 step reads 17.05 instead of 15.97 ms
+    (tools/ddp_overhead.py; GPU_MAX_HW_QUEUES = 3 / 5 / 8 also avoid that collision but 5+ queues slow hipGraph replays with
+    side branches down by a third, so the default stays and the stream is chosen by measurement)."""
     st = _SIDE_STREAMS.get(device.index)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        with torch.cuda.device(device):
+            main = torch.cuda.current_stream()
+            cands = [torch.cuda.Stream(device=device) for _ in range(6)]
+            st = cands[0]
+            if not torch.cuda.is_current_stream_capturing():
+                for cand in cands:
+                    if _runs_beside(cand, main):
+                        st = cand
+                        break
         _SIDE_STREAMS[device.index] = st
+        if os.environ.get('SEG3D_DEBUG_STREAMS'):
+            import sys
+            sys.stderr.write('seg3d: side stream {:#x} chosen among {} (main {:#x}, capturing {})\n'.format(
+                st.cuda_stream, [hex(c.cuda_stream) for c in cands], main.cuda_stream, torch.cuda.is_current_stream_capturing()))
     return st
 
 
@@ -796,6 +840,17 @@ def wgrad_stream_join():
 
 def _join_after_backward():
     wgrad_stream_join()
+
+
+def wgrad_side_stream(device=None):
+    """the weight-gradient side stream of `device` (default: the current one), or None when weight gradients run on the main
+    stream.  The gradient reducer (core/ddp.py) enqueues its collectives behind THIS stream instead of joining it into the
+    main stream: the data-gradient chain is then never held up by a bucket launch."""
+    if not WGRAD_SIDE_STREAM:
+        return None
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    return _side_stream(device)
 
 
 def _wgrad_to_sink(xn, dyn, w_shape, kind, sink_view):

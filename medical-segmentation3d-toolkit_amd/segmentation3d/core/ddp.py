@@ -91,10 +91,12 @@ class GradientReducer(object):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.group = process_group
-        self._join = None
+        self._join, self._side = None, None
         if flat_buffers and flat_buffers[0].is_cuda:
             from segmentation3d import _ops
             self._join = _ops.wgrad_stream_join
+            if dist.get_backend(process_group) == 'nccl':     # (gloo stages through the host: it needs the join)
+                self._side = _ops.wgrad_side_stream
         self.world_size = dist.get_world_size(process_group)
         self.buffers = flat_buffers
         self._buckets = []          # dict(buffer, lo, hi, pending, nparams, work)
@@ -138,9 +140,20 @@ class GradientReducer(object):
         self._active = True
 
     def _launch(self, b):
+        view = self.buffers[b['buffer']][b['lo']:b['hi']]
+        side = self._side() if self._side is not None else None
+        if side is not None:
+            # A bucket holds weight gradients (written on the weight-gradient side stream, segmentation3d._ops) and GroupNorm /
+            # bias gradients (written on the main stream).  The collective is enqueued with the SIDE stream current, after
+            # that stream has been told to wait for the main stream's present position: RCCL then orders itself behind both,
+            # and the main stream -- the data-gradient chain, backward's critical path -- is not made to wait for the pending
+            # weight gradients at every bucket launch (one-rank RCCL run, tools/ddp_overhead.py: 16.38 -> see DESIGN.md 5).
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                b['work'] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return
         if self._join is not None:
             self._join()    # weight gradients written on the side stream (segmentation3d._ops) must have landed
-        view = self.buffers[b['buffer']][b['lo']:b['hi']]
         b['work'] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad_ready(self, param):

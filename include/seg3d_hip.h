@@ -195,6 +195,11 @@ int seg3d_conv3d_k3_thin_out_mfma_fwd(const void* x_bf16, const void* wp_bf16, c
 long long seg3d_conv3d_k2s2_mfma_stats_count(int Do, int Ho, int Wo, int Cout);
 int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp_mfma, const float* bias, float* y, float* stats_partial,
                                int N, int Do, int Ho, int Wo, int Cin, int Cout, void* stream);
+/* x is a channel slice of a wider NDHWC buffer: ld_x floats between consecutive voxel rows (>= Cin, multiple of 4).  Inference:
+ * the encoder feature that feeds both the next DownBlock (vnet_downblock.py:11) and a decoder concatenation
+ * (vnet_upblock.py:21) is normalised straight into its half of the concatenated buffer and read from there. */
+int seg3d_conv3d_k2s2_mfma_fwd_ld(const float* x, int ld_x, const float* wp, const float* bias, float* y, float* stats, int N,
+                                  int Do, int Ho, int Wo, int Cin, int Cout, void* stream);
 long long seg3d_convT3d_k2s2_mfma_stats_count(int Di, int Hi, int Wi, int Cout);
 int seg3d_convT3d_k2s2_mfma_fwd(const float* x, const float* wp_mfma, const float* bias, float* y, float* stats_partial,
                                 int N, int Di, int Hi, int Wi, int Cin, int Cout, void* stream);

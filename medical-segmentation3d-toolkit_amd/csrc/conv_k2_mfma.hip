@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
                                                                     const float* __restrict__ bias, float* __restrict__ y,
                                                                     float* __restrict__ stats, int N, int Do, int Ho,
                                                                     int Wo, int Cin, int Cout, int TZ, int TY, int TX,
-                                                                    int ntz, int nty, int ntx) {
+                                                                    int ntz, int nty, int ntx, int ldx) {
+  // ldx: elements between consecutive voxel rows of x (= Cin, or the width of the concatenated buffer x is a channel slice of)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int HY = 2 * TY, HX = 2 * TX;
   const int NV = 8 * TZ * TY * TX;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
       const int hz = seg3d_fdiv(t, rHY);
       const int hy = t - hz * HY;
       const int gz = 2 * z0 + hz, gy = 2 * y0 + hy, gx = 2 * x0 + hx;
-      if (gz < Di && gy < Hi && gx < Wi) goff[e] = (((n * Di + gz) * Hi + gy) * Wi + gx) * Cin + hh * CPH;
+      if (gz < Di && gy < Hi && gx < Wi) goff[e] = (((n * Di + gz) * Hi + gy) * Wi + gx) * ldx + hh * CPH;
     }
   }
   for (int idx = tid; idx < MT; idx += 256) {
@@ -260,12 +261,14 @@ extern "C" long long seg3d_conv3d_k2s2_mfma_stats_count(int Do, int Ho, int Wo, 
 
 // x [N][2Do][2Ho][2Wo][Cin] -> y [N][Do][Ho][Wo][Cout];  wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 8)
 static int k2_gather_launch(const void* x, int x_bf16, const float* wp, const float* bias, float* y, float* stats, int N,
-                            int Do, int Ho, int Wo, int Cin, int Cout, void* stream, int out_bf16 = 0) {
+                            int Do, int Ho, int Wo, int Cin, int Cout, void* stream, int out_bf16 = 0, int ldx = 0) {
+  if (ldx == 0) ldx = Cin;
+  SEG3D_REQUIRE(ldx >= Cin && (ldx % 4) == 0, "seg3d_conv3d_k2s2_mfma_fwd: ld_x must be a multiple of 4 >= Cin");
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k2s2_mfma_fwd: null pointer");
   SEG3D_REQUIRE(N > 0 && Do > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0, "seg3d_conv3d_k2s2_mfma_fwd: bad dims");
   SEG3D_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0,
                 "seg3d_conv3d_k2s2_mfma_fwd: Cin and Cout must be multiples of 4 (got %d, %d)", Cin, Cout);
-  SEG3D_REQUIRE((i64)N * Do * Ho * Wo * 8 * Cin < (1ll << 31) && (i64)N * Do * Ho * Wo * Cout < (1ll << 31),
+  SEG3D_REQUIRE((i64)N * Do * Ho * Wo * 8 * ldx < (1ll << 31) && (i64)N * Do * Ho * Wo * Cout < (1ll << 31),
                 "seg3d_conv3d_k2s2_mfma_fwd: tensor exceeds 2^31 elements");
   K2Tile t = k2_pick_tile(Do, Ho, Wo);
   const int ntz = seg3d_cdiv(Do, t.tz), nty = seg3d_cdiv(Ho, t.ty), ntx = seg3d_cdiv(Wo, t.tx);
@@ -277,7 +280,7 @@ static int k2_gather_launch(const void* x, int x_bf16, const float* wp, const fl
   SEG3D_REQUIRE(x_bf16 != 2 || (Cin % 16) == 0, "seg3d_conv3d_k2s2_bf16_fwd: the bf16 weight image needs Cin %% 16 == 0");
 #define K2_GATHER(MODE_, OB_)                                                                                        \
   hipLaunchKernelGGL((conv3d_k2s2_mfma_kernel<MODE_, OB_>), grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, stats, \
-                     N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx)
+                     N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ldx)
   if (x_bf16 == 2 && out_bf16) K2_GATHER(2, true);
   else if (x_bf16 == 2) K2_GATHER(2, false);
   else if (x_bf16 && out_bf16) K2_GATHER(1, true);
@@ -291,6 +294,13 @@ static int k2_gather_launch(const void* x, int x_bf16, const float* wp, const fl
 extern "C" int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int N,
                                           int Do, int Ho, int Wo, int Cin, int Cout, void* stream) {
   return k2_gather_launch(x, 0, wp, bias, y, stats, N, Do, Ho, Wo, Cin, Cout, stream);
+}
+
+// the same with x a channel slice of a wider NDHWC buffer: ld_x floats between consecutive voxel rows (inference: an
+// encoder feature that was normalised straight into its half of a decoder's concatenated skip buffer)
+extern "C" int seg3d_conv3d_k2s2_mfma_fwd_ld(const float* x, int ld_x, const float* wp, const float* bias, float* y,
+                                             float* stats, int N, int Do, int Ho, int Wo, int Cin, int Cout, void* stream) {
+  return k2_gather_launch(x, 0, wp, bias, y, stats, N, Do, Ho, Wo, Cin, Cout, stream, 0, ld_x);
 }
 
 // bf16 mode: x is bf16 ([N][2Do][2Ho][2Wo][Cin]); wp = fp32 image (w_bf16 = 0) or seg3d_pack_weights_mfma_bf16 image

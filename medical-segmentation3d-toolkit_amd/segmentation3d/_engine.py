@@ -75,6 +75,7 @@ _SIGNATURES = {
     'seg3d_conv3d_k3_mfma_wgrad': (_c_int, [_c_p] * 4 + [_c_int] * 7 + [_c_p]),
     'seg3d_conv3d_k2s2_mfma_stats_count': (_c_ll, [_c_int] * 4),
     'seg3d_conv3d_k2s2_mfma_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
+    'seg3d_conv3d_k2s2_mfma_fwd_ld': (_c_int, [_c_p, _c_int] + [_c_p] * 4 + [_c_int] * 6 + [_c_p]),
     'seg3d_convT3d_k2s2_mfma_stats_count': (_c_ll, [_c_int] * 4),
     'seg3d_convT3d_k2s2_mfma_fwd': (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
     'seg3d_k2_mfma_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),

@@ -45,6 +45,11 @@ def set_activation_dtype(name):
     return prev
 
 
+def activation_dtype_name():
+    """'fp32' or 'bf16': the current activation storage mode"""
+    return 'bf16' if _ACT_BF16[0] else 'fp32'
+
+
 class activation_dtype(object):
     """context manager form of set_activation_dtype"""
 
@@ -84,11 +89,25 @@ def to_ndhwc(x):
     xp = x.permute(0, 2, 3, 4, 1)
     if xp.is_contiguous():
         return xp
+    if _is_channel_slice(xp):
+        # a channel slice of a wider NDHWC buffer (inference: an encoder feature living in its half of a decoder's concatenated
+        # skip buffer, VNetBase.forward): the two consumers that can meet one -- the stride-2 conv and up_cat -- read it in place
+        return xp
     N, C, D, H, W = x.shape
     xc = x.contiguous()
     out = torch.empty((N, D, H, W, C), dtype=torch.float32, device=x.device)
     E.call('seg3d_ncdhw_to_ndhwc', E.ptr(xc), E.ptr(out), N, C, D * H * W, E.stream_ptr())
     return out
+
+
+def _is_channel_slice(t):
+    """[N,D,H,W,C] view whose voxel rows are C contiguous floats at a constant stride > C inside one NDHWC buffer"""
+    if t.dim() != 5 or t.is_contiguous():
+        return False
+    N, D, H, W_, C = t.shape
+    ld = t.stride(3)
+    return (t.stride(4) == 1 and ld > C and ld % 4 == 0 and t.stride(2) == W_ * ld and t.stride(1) == H * t.stride(2) and
+            t.stride(0) == D * t.stride(1) and t.storage_offset() % 4 == 0)
 
 
 def from_ndhwc(t):
@@ -371,7 +390,7 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
     return y, None
 
 
-def _k2_gather(xn, w, bias, y, A, B, sa, sb, want_stats):
+def _k2_gather(xn, w, bias, y, A, B, sa, sb, want_stats, ldx=0):
     """y[v][b] = bias[b] + sum_{t,a} x[2v + t][a] W(a,b,t) on the matrix cores; y preallocated [N,Do,Ho,Wo,B]"""
     N, Do, Ho, Wo, _ = y.shape
     w16 = _is_bf16(xn) and A % 16 == 0    # bf16 weight image -> the kernel's bf16-MFMA mode
@@ -382,6 +401,10 @@ def _k2_gather(xn, w, bias, y, A, B, sa, sb, want_stats):
     if _is_bf16(xn):
         E.call('seg3d_conv3d_k2s2_bf16_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho, Wo, A, B,
                int(_is_bf16(y)), int(w16), E.stream_ptr())
+        return y, stats
+    if ldx:
+        E.call('seg3d_conv3d_k2s2_mfma_fwd_ld', E.ptr(xn), int(ldx), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho,
+               Wo, A, B, E.stream_ptr())
         return y, stats
     E.call('seg3d_conv3d_k2s2_mfma_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(y), E.ptr(stats), N, Do, Ho, Wo, A, B,
            E.stream_ptr())
@@ -433,6 +456,13 @@ def conv_forward(xn, w, bias, kind, want_stats=False, out_bf16=False):
     out_bf16 (bf16 mode): REQUEST a bf16 y; honoured by the kernels that take bf16 input (check y.dtype)"""
     ks, stride, T, transposed = _KINDS[kind]
     N, D, H, W_, Cin = xn.shape
+    ldx = 0
+    if not xn.is_contiguous():
+        if kind == 'k2s2' and xn.dtype == torch.float32 and _is_channel_slice(xn) and _use_mfma(Cin, w.shape[0]) and \
+                w.shape[0] % 4 == 0:
+            ldx = xn.stride(3)            # read in place by seg3d_conv3d_k2s2_mfma_fwd_ld
+        else:
+            xn = xn.contiguous()
     if kind == 'k3':
         Cout = w.shape[0]
         _check_w(w, (Cout, Cin, 3, 3, 3), kind)
@@ -445,7 +475,7 @@ def conv_forward(xn, w, bias, kind, want_stats=False, out_bf16=False):
         if _use_mfma(Cin, Cout) and Cout % 4 == 0:
             ydt = torch.bfloat16 if (out_bf16 and _is_bf16(xn)) else torch.float32
             y = _empty((N, D // 2, H // 2, W_ // 2, Cout), xn, ydt)
-            return _k2_gather(xn, w, bias, y, Cin, Cout, 8, Cin * 8, want_stats)
+            return _k2_gather(xn, w, bias, y, Cin, Cout, 8, Cin * 8, want_stats, ldx=ldx)
         y = _empty((N, D // 2, H // 2, W_ // 2, Cout), xn)
         xn = _to_f32(xn)
         wp = _pack_tapmajor(w, Cin, Cout, 8, 8, Cin * 8)
@@ -897,8 +927,10 @@ class ConvGnActFunction(torch.autograd.Function):
     When x is the residual itself (single-conv block) the two gradients are fused without a link."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in=None, link_out=None):
+    def forward(ctx, x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in=None, link_out=None, out_slot=None):
         E.require_device(x, weight, bias, gamma, beta, residual)
+        if out_slot is not None and torch.is_grad_enabled() and any(ctx.needs_input_grad):
+            raise RuntimeError('out_slot (output written into a slice of another buffer) is an inference-only path')
         xn = to_ndhwc(x)
         w = weight.detach()
         cout = w.shape[1] if kind == 'convT' else w.shape[0]
@@ -912,7 +944,7 @@ class ConvGnActFunction(torch.autograd.Function):
                 raise ValueError('residual shape {} does not match conv output {}'.format(tuple(residual.shape),
                                                                                           tuple(from_ndhwc(yn).shape)))
         C = yn.shape[4]
-        outn = gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), resn, relu, out_bf16=_out_bf16(C))
+        outn = gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), resn, relu, out=out_slot, out_bf16=_out_bf16(C))
         # the gradient w.r.t. the conv output goes to the dgrad / wgrad kernels as bf16 when they take bf16 (same
         # condition as in forward: bf16 input activations and MFMA-shaped channel counts on both sides)
         ctx.dy_bf16 = _is_bf16(xn) and _is_bf16(outn) and xn.shape[4] % 16 == 0
@@ -958,12 +990,13 @@ class ConvGnActFunction(torch.autograd.Function):
             else:
                 dw = conv_wgrad(xn, dy, ctx.w_shape, ctx.kind)
         return (dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta,
-                from_ndhwc(dres) if dres is not None else None, None, None, None, None, None)
+                from_ndhwc(dres) if dres is not None else None, None, None, None, None, None, None)
 
 
 def conv_gn_act(x, weight, bias, gamma, beta, residual=None, kind='k3', relu=True, eps=GN_EPS, link_in=None,
-                link_out=None):
-    return ConvGnActFunction.apply(x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in, link_out)
+                link_out=None, out_slot=None):
+    """out_slot (inference only): [N,D,H,W,C] channel slice of a wider NDHWC buffer the unit's output is written into"""
+    return ConvGnActFunction.apply(x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in, link_out, out_slot)
 
 
 class UpCatFunction(torch.autograd.Function):
@@ -974,7 +1007,7 @@ class UpCatFunction(torch.autograd.Function):
     to autograd as a strided view of it (no copy either)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, skip, relu, eps, link_out=None):
+    def forward(ctx, x, weight, bias, gamma, beta, skip, relu, eps, link_out=None, cat_buf=None):
         E.require_device(x, weight, bias, gamma, beta, skip)
         ctx.link_out = link_out
         xn = to_ndhwc(x)
@@ -992,11 +1025,22 @@ class UpCatFunction(torch.autograd.Function):
         bf = _is_bf16(sn)          # bf16 mode: the skip arrives as bf16, the concatenated buffer is bf16 as a whole
         if bf and (Ca % 16 or Cb % 16):
             raise ValueError('fused up + cat in bf16 mode needs channel counts that are multiples of 16')
-        cat = _empty((N, D, H, W_, Ca + Cb), yn, torch.bfloat16 if bf else torch.float32)
-        gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), None, relu, out=cat[..., :Ca])
-        k = 2 if bf else 1         # the copy kernel moves 32-bit words: a bf16 row of C channels is C / 2 of them
-        E.call('seg3d_copy_channels', E.ptr(sn), E.ptr(cat), N * D * H * W_, Cb // k, Cb // k, 0, (Ca + Cb) // k, Ca // k,
-               E.stream_ptr())
+        if cat_buf is not None:
+            # inference: the skip tensor already lives in the second half of the concatenated buffer (the encoder stage that
+            # produced it wrote it there, VNetBase.forward), so nothing is copied
+            if tuple(cat_buf.shape) != (N, D, H, W_, Ca + Cb) or not cat_buf.is_contiguous() or cat_buf.dtype != sn.dtype or \
+                    sn.data_ptr() != cat_buf[..., Ca:].data_ptr() or sn.stride(3) != Ca + Cb:
+                raise ValueError('up_cat: cat_buf must be the contiguous [N,D,H,W,Ca+Cb] buffer whose slice [..., Ca:] is `skip`')
+            cat = cat_buf
+            gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), None, relu, out=cat[..., :Ca])
+        else:
+            if not sn.is_contiguous():
+                sn = sn.contiguous()
+            cat = _empty((N, D, H, W_, Ca + Cb), yn, torch.bfloat16 if bf else torch.float32)
+            gn_apply(yn, mean_rstd, gamma.detach(), beta.detach(), None, relu, out=cat[..., :Ca])
+            k = 2 if bf else 1         # the copy kernel moves 32-bit words: a bf16 row of C channels is C / 2 of them
+            E.call('seg3d_copy_channels', E.ptr(sn), E.ptr(cat), N * D * H * W_, Cb // k, Cb // k, 0, (Ca + Cb) // k, Ca // k,
+                   E.stream_ptr())
         ctx.dy_bf16 = bf and _is_bf16(xn) and xn.shape[4] % 16 == 0
         ctx.relu, ctx.has_bias, ctx.w_shape, ctx.ca = bool(relu), bias is not None, tuple(weight.shape), Ca
         ctx.sinks = (G.lookup(weight), G.lookup(bias), G.lookup(gamma), G.lookup(beta))
@@ -1026,11 +1070,11 @@ class UpCatFunction(torch.autograd.Function):
                 ctx.link_out.grad = dn[..., ctx.ca:]
             else:
                 dskip = from_ndhwc(dn[..., ctx.ca:])                                  # strided view, no copy
-        return dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta, dskip, None, None, None
+        return dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta, dskip, None, None, None, None
 
 
-def up_cat(x, weight, bias, gamma, beta, skip, relu=True, eps=GN_EPS, link_out=None):
-    return UpCatFunction.apply(x, weight, bias, gamma, beta, skip, relu, eps, link_out)
+def up_cat(x, weight, bias, gamma, beta, skip, relu=True, eps=GN_EPS, link_out=None, cat_buf=None):
+    return UpCatFunction.apply(x, weight, bias, gamma, beta, skip, relu, eps, link_out, cat_buf)
 
 
 class ConvFunction(torch.autograd.Function):

@@ -30,11 +30,12 @@ class ConvGnRelu3(nn.Module):
         self.do_act = do_act
         attach_unit(self, _UNIT, _kind(ksize, stride, padding), in_channels, out_channels, act=do_act, bias=bias)
 
-    def forward(self, input, residual=None, force_act=False, link_in=None, link_out=None):
+    def forward(self, input, residual=None, force_act=False, link_in=None, link_out=None, out_slot=None):
         """plain call = the reference forward.  residual / force_act: compute ReLU(residual + GN(conv(input))) in this
-        unit (residual_block3.py:24); link_in / link_out: _ops.ResidualLink side channel for the backward pass."""
+        unit (residual_block3.py:24); link_in / link_out: _ops.ResidualLink side channel for the backward pass;
+        out_slot (inference): slice of another buffer the output is written into (_ops.conv_gn_act)."""
         return run_unit(self, _UNIT, input, relu=self.do_act or force_act, residual=residual, link_in=link_in,
-                        link_out=link_out)
+                        link_out=link_out, out_slot=out_slot)
 
 
 class BottConvGnRelu3(nn.Module):
@@ -46,6 +47,6 @@ class BottConvGnRelu3(nn.Module):
         for k, (cin, cout, act) in enumerate(stages, start=1):
             setattr(self, 'conv{}'.format(k), ConvGnRelu3(cin, cout, ksize, stride, padding, do_act=act, bias=bias))
 
-    def forward(self, input, residual=None, force_act=False, link_in=None, link_out=None):
+    def forward(self, input, residual=None, force_act=False, link_in=None, link_out=None, out_slot=None):
         squeezed = self.conv2(self.conv1(input, link_in=link_in))
-        return self.conv3(squeezed, residual=residual, force_act=force_act, link_out=link_out)
+        return self.conv3(squeezed, residual=residual, force_act=force_act, link_out=link_out, out_slot=out_slot)

@@ -11,17 +11,17 @@ from segmentation3d.network.module.conv_gn_relu3 import ConvGnRelu3, BottConvGnR
 from segmentation3d.network.module.layers import ReLU
 
 
-def _residual_forward(ops, input):
+def _residual_forward(ops, input, out_slot=None):
     """act(input + ops(input)) with the add + ReLU fused into the last unit (residual_block3.py:21-26, 44-46) and, for
     backward, the identity-path gradient routed from the last unit to the first unit's data-gradient kernel."""
     n = len(ops)
     if n == 1:
-        return ops[0](input, residual=input, force_act=True)
+        return ops[0](input, residual=input, force_act=True, out_slot=out_slot)
     link = _ops.ResidualLink() if input.requires_grad else None
     output = ops[0](input, link_in=link)
     for i in range(1, n - 1):
         output = ops[i](output)
-    return ops[n - 1](output, residual=input, force_act=True, link_out=link)
+    return ops[n - 1](output, residual=input, force_act=True, link_out=link, out_slot=out_slot)
 
 
 class _ResidualBase(nn.Module):
@@ -31,8 +31,8 @@ class _ResidualBase(nn.Module):
         self.ops = nn.Sequential(*[make_unit(i != num_convs - 1) for i in range(num_convs)])
         self.act = ReLU(inplace=True)
 
-    def forward(self, input):
-        return _residual_forward(self.ops, input)
+    def forward(self, input, out_slot=None):
+        return _residual_forward(self.ops, input, out_slot)
 
 
 class ResidualBlock3(_ResidualBase):

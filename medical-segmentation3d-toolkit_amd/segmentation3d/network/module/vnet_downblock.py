@@ -21,7 +21,8 @@ class DownBlock(nn.Module):
         attach_unit(self, _DOWN, 'k2s2', in_channels, width)
         self.rblock = make_residual_block(width, num_convs, compression, ratio)
 
-    def forward(self, input, skip_link=None):
+    def forward(self, input, skip_link=None, out_slot=None):
         """skip_link: _ops.ResidualLink shared with the UpBlock that concatenates `input` as its skip tensor; in backward
-        that block parks the skip gradient there and the stride-2 conv's data-gradient kernel adds it"""
-        return self.rblock(run_unit(self, _DOWN, input, relu=True, link_in=skip_link))
+        that block parks the skip gradient there and the stride-2 conv's data-gradient kernel adds it.
+        out_slot (inference): the block's output goes straight into its half of the decoder's concatenated skip buffer"""
+        return self.rblock(run_unit(self, _DOWN, input, relu=True, link_in=skip_link), out_slot=out_slot)

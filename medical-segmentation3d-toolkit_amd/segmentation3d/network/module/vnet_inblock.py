@@ -16,5 +16,5 @@ class InputBlock(nn.Module):
         super(InputBlock, self).__init__()
         attach_unit(self, _STEM, 'k3', in_channels, out_channels)
 
-    def forward(self, input):
-        return run_unit(self, _STEM, input, relu=True)
+    def forward(self, input, out_slot=None):
+        return run_unit(self, _STEM, input, relu=True, out_slot=out_slot)

@@ -22,11 +22,12 @@ class UpBlock(nn.Module):
         attach_unit(self, _UP, 'convT', in_channels, out_channels // 2)
         self.rblock = make_residual_block(out_channels, num_convs, compression, ratio)
 
-    def forward(self, input, skip, skip_link=None):
+    def forward(self, input, skip, skip_link=None, cat_buf=None):
+        """cat_buf (inference): the concatenated buffer whose second half already holds `skip` (VNetBase.forward)"""
         conv, gn = self.up_conv, self.up_gn
         if conv.out_channels % 4 == 0 and skip.shape[1] % 4 == 0:
             merged = _ops.up_cat(input, conv.weight, conv.bias, gn.weight, gn.bias, skip, relu=True, eps=gn.eps,
-                                 link_out=skip_link)
+                                 link_out=skip_link, cat_buf=cat_buf)
         else:   # odd channel counts: separate concatenation kernel
             merged = _ops.cat_channels(run_unit(self, _UP, input, relu=True), skip)
         return self.rblock(merged)

@@ -13,6 +13,9 @@ dev = torch.device('cuda:0')
 if 'dist' in sys.argv:
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 import bench
+if 'noslots' in sys.argv:
+    from segmentation3d.network import _vnet_base
+    _vnet_base.PREFILL_SKIP_SLOTS = False
 from segmentation3d.core.seg_train import TrainStep
 step = TrainStep('vnet', 1, 2, 'Dice', [0.5, 0.5], device=dev, seed=0, distributed='dist' in sys.argv)
 if 'train' in sys.argv:

@@ -692,9 +692,16 @@ def main():
     if not args.no_infer:
         # every rank takes part (N > 1: the patch list is sharded, the halo merge and the mask replication are collectives)
         vx = tuple(int(v) for v in args.infer_volume.split(','))
-        infer = time_inference(step.net, vx, args.patch, args.patch // 2, args.classes, args.infer_batch, device,
-                               world=world, dtype=args.dtype)
-        if world == 1 and args.in_channels == 1:
+        try:
+            infer = time_inference(step.net, vx, args.patch, args.patch // 2, args.classes, args.infer_batch, device,
+                                   world=world, dtype=args.dtype)
+        except Exception as exc:
+            if world == 1:
+                raise
+            # N > 1: the train-step measurement above is complete; an error that every rank raises alike in the sharded
+            # inference leg (its point-to-point halo exchange has only ever been rehearsed over gloo) must not cost the line
+            infer = {'error': repr(exc), 'n_gpus': world}
+        if world == 1 and args.in_channels == 1 and 'error' not in infer:
             try:
                 infer['config1_whole_volume_128_gpu'] = time_config1_gpu(step.net, args.net, args.in_channels, args.classes,
                                                                           args.patch, device)

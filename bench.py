@@ -688,19 +688,37 @@ def main():
             with open(args.kernel_report, 'w') as f:
                 json.dump({'mfma_conv_launches': kernels, 'ms_per_step': ms_per_step}, f, indent=1)
 
-    infer = None
+    infer, infer_timed_out = None, False
     if not args.no_infer:
         # every rank takes part (N > 1: the patch list is sharded, the halo merge and the mask replication are collectives)
         vx = tuple(int(v) for v in args.infer_volume.split(','))
-        try:
+        if world == 1:
             infer = time_inference(step.net, vx, args.patch, args.patch // 2, args.classes, args.infer_batch, device,
                                    world=world, dtype=args.dtype)
-        except Exception as exc:
-            if world == 1:
-                raise
-            # N > 1: the train-step measurement above is complete; an error that every rank raises alike in the sharded
-            # inference leg (its point-to-point halo exchange has only ever been rehearsed over gloo) must not cost the line
-            infer = {'error': repr(exc), 'n_gpus': world}
+        else:
+            # N > 1: the train-step measurement above is complete, and the sharded inference leg -- whose point-to-point halo
+            # exchange has only ever been rehearsed over gloo -- must not cost the line: it runs in a worker thread; an
+            # exception is reported in its place, and if the leg has not returned after SEG3D_BENCH_INFER_TIMEOUT seconds
+            # (default 240; every rank would be stuck in the same collective) rank 0 prints the line without it and every
+            # rank leaves the process without waiting for the stuck thread.
+            import threading
+            box = {}
+
+            def leg():
+                try:
+                    torch.cuda.set_device(device)
+                    box['infer'] = time_inference(step.net, vx, args.patch, args.patch // 2, args.classes, args.infer_batch,
+                                                  device, world=world, dtype=args.dtype)
+                except Exception as exc:
+                    box['infer'] = {'error': repr(exc), 'n_gpus': world}
+            th = threading.Thread(target=leg, daemon=True)
+            th.start()
+            th.join(float(os.environ.get('SEG3D_BENCH_INFER_TIMEOUT', '240')))
+            if th.is_alive():
+                infer_timed_out = True
+                infer = {'error': 'sharded inference leg did not return within the time limit', 'n_gpus': world}
+            else:
+                infer = box['infer']
         if world == 1 and args.in_channels == 1 and 'error' not in infer:
             try:
                 infer['config1_whole_volume_128_gpu'] = time_config1_gpu(step.net, args.net, args.in_channels, args.classes,
@@ -738,7 +756,9 @@ def main():
             'final_loss': round(final_loss, 6),
             'roofline': roofline, 'cpu_baseline': cpu_baseline, 'infer': infer,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if infer_timed_out:
+        os._exit(0)      # a collective is stuck: no clean shutdown is possible (the line, if this is rank 0, is out)
     if world > 1:
         dist.destroy_process_group()
 

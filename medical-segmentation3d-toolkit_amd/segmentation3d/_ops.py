@@ -9,7 +9,6 @@ Fused unit (the reference's `ConvGnRelu3`, network/module/conv_gn_relu3.py:4-20,
 InputBlock/DownBlock/UpBlock/OutputBlock):   out = act( GN_1(conv(x) + b) [+ residual] )
 """
 import ctypes
-import os
 
 import torch
 
@@ -837,8 +836,8 @@ def _side_stream(device):
     """the weight-gradient side stream of a device, created at first use: the first of a few fresh streams that demonstrably
     lets the current (main) stream's kernels run BESIDE its own.  Without the probe the choice is an accident of creation order
     -- with nothing but an RCCL communicator initialised in the process the next pool stream shares the main stream's hardware
-    queue (tools/stream_probe.py), the
-    overlap of weight gradients with the data-gradient chain is gone and the fp32 step reads 17.05 instead of 15.97 ms
+    queue (tools/stream_probe.py), the overlap of weight gradients with the data-gradient chain is gone and the fp32 step reads
+    17.05 instead of 15.97 ms
     (tools/ddp_overhead.py; GPU_MAX_HW_QUEUES = 3 / 5 / 8 also avoid that collision but 5+ queues slow hipGraph replays with
     side branches down by a third, so the default stays and the stream is chosen by measurement)."""
     st = _SIDE_STREAMS.get(device.index)
@@ -853,10 +852,6 @@ def _side_stream(device):
                         st = cand
                         break
         _SIDE_STREAMS[device.index] = st
-        if os.environ.get('SEG3D_DEBUG_STREAMS'):
-            import sys
-            sys.stderr.write('seg3d: side stream {:#x} chosen among {} (main {:#x}, capturing {})\n'.format(
-                st.cuda_stream, [hex(c.cuda_stream) for c in cands], main.cuda_stream, torch.cuda.is_current_stream_capturing()))
     return st
 
 

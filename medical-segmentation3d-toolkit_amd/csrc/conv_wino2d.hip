@@ -13,21 +13,29 @@
 //
 // Structure: the persistent skeleton of conv_wino.hip (one workgroup per CU walks (tile, column block) items; K chunks
 // arrive by LDS-DMA; packed weight images are straight copies), with
-//   * tile 8 x 8 x 8 voxels = 128 output quads; FOUR waves (one per SIMD, 512 registers): wave w owns the z planes 2w,
-//     2w + 1 = 32 quads x 32 output channels, i.e. 16 point accumulators of 16 registers;
+//   * tile 8 x 8 x 8 voxels = 128 output quads x 32 output channels per item; EIGHT waves, two per SIMD: wave (zw, h)
+//     owns the z planes 2 zw, 2 zw + 1 (32 quads) and the output channels 16 h .. 16 h + 15 of the column block:
+//     16 point accumulators x 2 planes x 4 registers = 128 of its 256 registers, on v_mfma_f32_16x16x4_f32;
 //   * K chunks of FOUR input channels (the weight image of a chunk is 48 x 512 B = 24 KB; chunks of 8 would not fit);
 //   * everything a chunk needs arrives or is made INSIDE the previous chunk's MFMA loop, one barrier per chunk: while chunk c
 //     is multiplied, the weights of chunk c + 1 and the RAW halo tile [10 x 10 x 10 voxels][4] of chunk c + 2 land by
-//     LDS-DMA (steps 0-9), and the RAW tile of chunk c + 1 is transformed into the second T buffer
-//     T[p = 16][z = 10][quad = 16][4] in eight stages spread over steps 12-33 (40 (z, quad) items per wave, packed fp32
-//     adds: 64 vector instructions per wave and chunk beside 96 MFMAs).  The first version transformed between two barriers
-//     with the matrix cores idle: 1 800 of 12 000 cycles per chunk (tools/ubench/wino2d_stamp.hip);
-//   * 48 steps of 2 MFMAs per chunk: (kz, point), operands one ds_read_b64 each, read two steps ahead (a wave's 32 quads
-//     of one (p, z pair) are 512 contiguous bytes of T; the weight image is [t][co][4]);
+//     LDS-DMA (steps 0-4), and the RAW tile of chunk c + 1 is transformed into the second T buffer
+//     T[p = 16][z = 10][quad = 16][4] in eight stages spread over steps 12-33 (320 (z, quad, channel pair) tasks, 40 per wave,
+//     packed fp32 adds: 32 vector instructions per wave and chunk beside 96 MFMAs);
+//   * 48 steps of 2 MFMAs per chunk: (kz, point); one A read (16 channels x 4 K) and two B reads (16 quads x 4 K each) per
+//     step, read two steps ahead (the weight image is [t][co][4], T is [p][z][quad][4]: a wave's reads are contiguous);
 //   * the weight image is the T = 48 pack of seg3d_pack_weights_mfma: t = kz * 16 + py * 4 + px, laid out per 8-channel chunk
 //     [t][half][32 co][4] -- a 4-channel K chunk is one half;
+//   * bias and fused addend enter through the accumulators at item start, the epilogue contains no load (see the kernel);
 //   * LDS: 2 x 16 KB RAW + 2 x 40 KB T + 2 x 24 KB weights = 160 KB, all of it.
+// Rounds 2 and early 3 ran this with FOUR waves (one per SIMD, 32 quads x 32 channels on v_mfma_f32_32x32x2_f32, 256
+// accumulator registers): the eight-wave form issues the same instructions per SIMD in the K loop (that loop is bound by what
+// it issues: 96 MFMAs + ~100 vector / LDS-write / DMA instructions on the one fp32 pipe) but halves the
+// epilogue's exposed time (eight waves' stores in flight), frees half the registers -- which is what lets the addend go
+// through the accumulators without a spill -- and measured 4-7 % faster per launch on every shape.
 #include "seg3d_common.h"
+#include <type_traits>
+#include <utility>
 #include "seg3d_hip.h"
 #include <stdint.h>
 
@@ -42,10 +50,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define W2_RAW 4096                               // floats: [NV][4] padded to whole 1-KiB DMA pieces (16)
 #define W2_T (16 * W2_H * W2_NQ * 4)              // floats of the transformed image: 10240
 #define W2_W (48 * 128)                           // floats of one K chunk's weight image: [48][32][4]
-#define W2_NW 4
 #define W2_LDS_FLOATS (2 * W2_RAW + 2 * W2_T + 2 * W2_W)  // 40960 floats = 163840 bytes: all of the CU's LDS
-#define W2_XPW 4                                  // raw pieces per wave (16 / 4)
-#define W2_WPW 6                                  // weight pieces per wave (24 / 4)
 
 __device__ __attribute__((aligned(16))) float w2_zero16[4];   // DMA source for zero padding
 
@@ -56,8 +61,17 @@ __device__ __attribute__((aligned(16))) float w2_zero16[4];   // DMA source for 
 // the barrier that publishes the data.  Nothing else in this kernel uses M0.
 typedef __attribute__((address_space(3))) float w2_lds_float;
 __device__ __forceinline__ void w2_glds16(const float* src, float* lds_dst_wave_uniform) {
-  const unsigned off = (unsigned)(uintptr_t)(w2_lds_float*)lds_dst_wave_uniform;
+  // (readfirstlane: the "s" operand must be an SGPR also when the compiler cannot prove the address uniform; folded away when it can)
+  const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(w2_lds_float*)lds_dst_wave_uniform);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(off) : "memory", "m0");
+}
+// the same with a wave-uniform base (SGPR pair) and a per-lane byte offset: no vector instruction forms the address
+__device__ __forceinline__ void w2_glds16_sbase(const float* base_wave_uniform, unsigned lane_byte_offset, float* lds_dst_wave_uniform) {
+  const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(w2_lds_float*)lds_dst_wave_uniform);
+  const uint64_t b = (uint64_t)(uintptr_t)base_wave_uniform;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const uint64_t sb = ((uint64_t)hi << 32) | lo;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_byte_offset), "s"(sb), "s"(off) : "memory", "m0");
 }
 __device__ __forceinline__ void w2_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // a - b on two packed floats in one instruction (hipcc selects v_pk_add_f32 for additions but two v_sub_f32 for this)
@@ -71,29 +85,51 @@ __device__ __forceinline__ f32x2 w2_pk_sub(f32x2 a, f32x2 b) {
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+__device__ __forceinline__ f32x2 w2_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 
 #ifdef W2_STAMPS   // diagnostic build only (tools/ubench/wino2d_stamp.hip): s_memtime stamps of the first chunks of a few workgroups
 __device__ long long* w2_stamp_buf;
 #define W2_STAMP(chunk, k)                                                                                        \
   do {                                                                                                            \
     if (blockIdx.x < 8 && (chunk) < 64 && (threadIdx.x & 63) == 0)                                                \
-      w2_stamp_buf[((blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (chunk)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+      w2_stamp_buf[((blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 + (chunk)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define W2_STAMP(chunk, k)
 #endif
 
-// BIAS / ADD: is there a bias (forward launches) / a fused addend (data-gradient launches that take the residual-path gradient)?
-// Compile-time, not run-time: the epilogue must not contain a load it does not need -- on gfx9 the wait for a load issued
-// after a group's stores also waits for those stores (one in-order vmcnt); without any load the epilogue of an item takes
-// 5 700 instead of 7 900 cycles (tools/ubench/wino2d_stamp.hip, mode 1).  The bias therefore enters at accumulator
-// initialisation (below), not in the epilogue.
+#define W2_NW 8                                   // waves per workgroup
+#define W2_XPW 2                                  // raw pieces per wave (16 / 8)
+#define W2_WPW 3                                  // weight pieces per wave (24 / 8)
+#ifndef W2_TR0
+#define W2_TR0 12                                 // first step of the RAW -> T transform stages
+#endif
+#ifndef W2_PF
+#define W2_PF 2                                   // operand prefetch distance in steps
+#endif
+
+// step -> (kz, point) of a K chunk: the twelve ordinary points for kz = 0, 1, 2 first, then the four corner points 0, 3, 12, 15
+// (whose accumulators may still be waiting for a fused addend, see the kernel)
+__host__ __device__ constexpr int w2_kz(int s) { return s < 36 ? s / 12 : (s - 36) >> 2; }
+__host__ __device__ constexpr int w2_pt(int s) {
+  return s < 36 ? (s % 12) + 1 + ((s % 12) >= 2) + ((s % 12) >= 10) : (((s - 36) & 3) >> 1) * 12 + ((s - 36) & 1) * 3;
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the steps index the accumulators with constant expressions
+template <class F, int... I>
+__device__ __forceinline__ void w2_steps(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
 template <bool BIAS, bool ADD>
-__global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                                   const float* __restrict__ bias, float* __restrict__ y,
-                                                                   float* __restrict__ stats, int N, int D, int H, int W, int Cin,
-                                                                   int Cout, int ntz, int nty, int ntx, int ncog, int nitems,
-                                                                   const float* __restrict__ addend) {
+__global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                                      float* __restrict__ stats, int N, int D, int H, int W,
+                                                                      int Cin, int Cout, int ntz, int nty, int ntx, int ncog,
+                                                                      int nitems, const float* __restrict__ addend) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* raw = lds;                               // [2][NV][4] (+ padding)
   float* timg = lds + 2 * W2_RAW;                 // [2][16][10][16][4]
@@ -101,16 +137,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, lh = lane >> 5;
-  const int NSC = Cin >> 2;               // K chunks of 4 channels
-  const int AB = Cin >> 3;                // packed 8-channel chunks per column block
+  const int zw = wave & 3, hh = wave >> 2;        // z-plane pair, output-channel half
+  const int l16 = lane & 15, kq = lane >> 4;      // MFMA column (quad / channel) and K index (= D row group)
+  const int NSC = Cin >> 2;
+  const int AB = Cin >> 3;
   const int G = gridDim.x;
   auto fdiv = [](int v, float r) { return (int)(((float)v + 0.5f) * r); };
   const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz, rNCOG = 1.0f / (float)ncog;
 
-  // ---- per-lane constants ----
-  // raw DMA pieces of this wave: piece p = wave + 4 j covers halo voxels e = 64 p + lane;
-  // hpos[j] = halo coordinates (hz << 20 | hy << 10 | hx), -1 = padding entry
   int hpos[W2_XPW];
 #pragma unroll
   for (int j = 0; j < W2_XPW; ++j) {
@@ -124,16 +158,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
       hpos[j] = (hz << 20) | (hy << 10) | hx;
     }
   }
-  // this lane's output quad: planes 2 wave + zz, quad (qy, qx)
-  const int zz = li >> 4, qq = li & 15, qy = qq >> 2, qx = qq & 3;
-  const int abase = li * 4 + 2 * lh;                                      // weights: [t][co = li][4], channels 2 lh, 2 lh + 1
-  const int bbase = ((2 * wave + zz) * W2_NQ + qq) * 4 + 2 * lh;          // T: + (p * 10 + kz) * 64
-  // transform item of this lane: 160 (z, quad) items, 40 per wave (lanes >= 40 repeat item 39 of their wave: same values to
-  // the same addresses -- no branch)
-  const int t_i = wave * 40 + (lane < 40 ? lane : 39);
+  const int abase = (16 * hh + l16) * 4 + kq;                 // weights [t][co][4]: + t * 128
+  const int bbase = ((2 * zw) * W2_NQ + l16) * 4 + kq;        // T [p][z][quad][4]: + (p * 10 + kz) * 64, second plane + 64
+  // transform task of this lane: 320 (item, channel pair) tasks, 40 per wave (lanes >= 40 repeat task 39 of their wave)
+  const int t_task = wave * 40 + (lane < 40 ? lane : 39);
+  const int t_i = t_task >> 1, t_h = t_task & 1;
   const int t_z = t_i >> 4, t_q = t_i & 15;
-  const int t_src = ((t_z * W2_H + 2 * (t_q >> 2)) * W2_H + 2 * (t_q & 3)) * 4;
-  const int t_dst = (t_z * W2_NQ + t_q) * 4;
+  const int t_src = ((t_z * W2_H + 2 * (t_q >> 2)) * W2_H + 2 * (t_q & 3)) * 4 + 2 * t_h;
+  const int t_dst = (t_z * W2_NQ + t_q) * 4 + 2 * t_h;
 
   auto decode = [&](int item, int& n, int& z0, int& y0, int& x0, int& cog, int& tile) {
     const int tile_all = fdiv(item, rNCOG);
@@ -151,7 +183,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
     tile = (tiz * nty + tiy) * ntx + tix;
     z0 = tiz * W2_TS, y0 = tiy * W2_TS, x0 = tix * W2_TS;
   };
-  // item walk: XCD-contiguous eighths of the item list (as conv_mfma.hip)
   int item = blockIdx.x, istride = G, ilimit = nitems;
   if ((G & 7) == 0) {
     const int per_xcd = (nitems + 7) >> 3, xcd = blockIdx.x & 7;
@@ -161,15 +192,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
   }
   if (item >= ilimit) return;
 
-  // ---- fetch cursors ----
-  // While K chunk c is multiplied, the weights of chunk c + 1 and the RAW tile of chunk c + 2 arrive by DMA and the RAW tile
-  // of chunk c + 1 (landed during chunk c - 1) is transformed into the second T buffer -- all inside the MFMA loop, one
-  // barrier per chunk.  Each stream has its own cursor over the (item, chunk) sequence of this workgroup; past the last
-  // chunk of the last item a cursor wraps to that item's chunk 0 (harmless refetch: the loop stays uniform, no branch).
-  int fx_item = item, fx_sc = 0;   // RAW cursor
+  int fx_item = item, fx_sc = 0;
   const float* xsrc[W2_XPW];
   int xadv = 0;
-  auto fx_setup = [&](int it) {   // DMA sources of chunk 0 of item `it`
+  auto fx_setup = [&](int it) {
     int n, z0, y0, x0, cog, tile;
     decode(it, n, z0, y0, x0, cog, tile);
     xadv = 0;
@@ -192,59 +218,52 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
       fx_setup(fx_item);
     }
   };
-  auto dma_x = [&](int j, float* rdst) {  // issues the piece into RAW, then steps its source to the next K chunk
+  auto dma_x = [&](int j, float* rdst) {
     w2_glds16(xsrc[j], rdst + (wave + W2_NW * j) * 256);
     xsrc[j] += ((xadv >> j) & 1) * 4;
   };
-  int fw_item = item, fw_sc = 0;   // weight cursor
-  // weight image of K chunk sc of column block cog: half (sc & 1) of the packed 8-channel chunk sc >> 1
-  auto fw_src = [&]() {
-    const int cog = fw_item - fdiv(fw_item, rNCOG) * ncog;
-    return wp + ((i64)cog * AB + (fw_sc >> 1)) * (48 * 256) + (fw_sc & 1) * 128;
-  };
+  int fw_item = item, fw_sc = 0;
+  auto cog_of = [&](int it) { return __builtin_amdgcn_readfirstlane(it - fdiv(it, rNCOG) * ncog); };
+  int fw_cog = cog_of(fw_item);
+  auto fw_src = [&]() { return wp + ((i64)fw_cog * AB + (fw_sc >> 1)) * (48 * 256) + (fw_sc & 1) * 128; };
   auto fw_advance = [&]() {
     ++fw_sc;
     if (fw_sc == NSC) {
       fw_sc = 0;
       if (fw_item + istride < ilimit) fw_item += istride;
+      fw_cog = cog_of(fw_item);
     }
   };
+  const unsigned w_lane_off = ((lane >> 5) * 256 + (lane & 31) * 4) * 4;   // bytes: t parity, (channel, 4 K) of the piece
   auto dma_w = [&](int j, const float* wsrc, float* wdst) {
-    const int piece = wave + W2_NW * j;   // two images per piece
-    w2_glds16(wsrc + (2 * piece + (lane >> 5)) * 256 + (lane & 31) * 4, wdst + piece * 256);
+    const int piece = wave + W2_NW * j;
+    w2_glds16_sbase(wsrc + 2 * piece * 256, w_lane_off, wdst + piece * 256);
   };
-  // RAW -> T: V = B^T d B per (z, quad), 16 points, in stages that the MFMA loop interleaves: four row stages (read one row
-  // of the 4 x 4 patch, x pass) and four column stages (y pass of one px, four stores); packed fp32 math
-  f32x4 rd[2][4];
-  f32x2 dxl[4][4], dxh[4][4];   // [row][px], channel pairs (0, 1) and (2, 3)
+  // RAW -> T for one channel pair of one (z, quad) item: V = B^T d B, 16 points, packed over the pair
+  f32x2 rd[2][4];
+  f32x2 dxp[4][4];   // [row][px]
   auto tr_read = [&](const float* rw, int r) {
     const float* sp = rw + t_src + r * (W2_H * 4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rd[r & 1][k] = *reinterpret_cast<const f32x4*>(sp + 4 * k);
+    for (int k = 0; k < 4; ++k) rd[r & 1][k] = *reinterpret_cast<const f32x2*>(sp + 4 * k);
   };
   auto tr_x = [&](int r) {
-    const f32x4* d = rd[r & 1];
-    const f32x2 d0l = {d[0][0], d[0][1]}, d0h = {d[0][2], d[0][3]}, d1l = {d[1][0], d[1][1]}, d1h = {d[1][2], d[1][3]};
-    const f32x2 d2l = {d[2][0], d[2][1]}, d2h = {d[2][2], d[2][3]}, d3l = {d[3][0], d[3][1]}, d3h = {d[3][2], d[3][3]};
-    dxl[r][0] = w2_pk_sub(d0l, d2l), dxh[r][0] = w2_pk_sub(d0h, d2h);
-    dxl[r][1] = w2_pk_add(d1l, d2l), dxh[r][1] = w2_pk_add(d1h, d2h);
-    dxl[r][2] = w2_pk_sub(d2l, d1l), dxh[r][2] = w2_pk_sub(d2h, d1h);
-    dxl[r][3] = w2_pk_sub(d1l, d3l), dxh[r][3] = w2_pk_sub(d1h, d3h);
+    const f32x2* d = rd[r & 1];
+    dxp[r][0] = w2_pk_sub(d[0], d[2]);
+    dxp[r][1] = w2_pk_add(d[1], d[2]);
+    dxp[r][2] = w2_pk_sub(d[2], d[1]);
+    dxp[r][3] = w2_pk_sub(d[3], d[1]);   // column px = 3 with the opposite sign (see the accumulators)
   };
   auto tr_y = [&](float* tdst, int px) {
     float* dst = tdst + t_dst + px * (W2_H * W2_NQ * 4);
-    const f32x2 v0l = w2_pk_sub(dxl[0][px], dxl[2][px]), v0h = w2_pk_sub(dxh[0][px], dxh[2][px]);
-    const f32x2 v1l = w2_pk_add(dxl[1][px], dxl[2][px]), v1h = w2_pk_add(dxh[1][px], dxh[2][px]);
-    const f32x2 v2l = w2_pk_sub(dxl[2][px], dxl[1][px]), v2h = w2_pk_sub(dxh[2][px], dxh[1][px]);
-    const f32x2 v3l = w2_pk_sub(dxl[1][px], dxl[3][px]), v3h = w2_pk_sub(dxh[1][px], dxh[3][px]);
-    *reinterpret_cast<f32x4*>(dst + 0 * 4 * (W2_H * W2_NQ * 4)) = f32x4{v0l[0], v0l[1], v0h[0], v0h[1]};
-    *reinterpret_cast<f32x4*>(dst + 1 * 4 * (W2_H * W2_NQ * 4)) = f32x4{v1l[0], v1l[1], v1h[0], v1h[1]};
-    *reinterpret_cast<f32x4*>(dst + 2 * 4 * (W2_H * W2_NQ * 4)) = f32x4{v2l[0], v2l[1], v2h[0], v2h[1]};
-    *reinterpret_cast<f32x4*>(dst + 3 * 4 * (W2_H * W2_NQ * 4)) = f32x4{v3l[0], v3l[1], v3h[0], v3h[1]};
+    *reinterpret_cast<f32x2*>(dst + 0 * 4 * (W2_H * W2_NQ * 4)) = w2_pk_sub(dxp[0][px], dxp[2][px]);
+    *reinterpret_cast<f32x2*>(dst + 1 * 4 * (W2_H * W2_NQ * 4)) = w2_pk_add(dxp[1][px], dxp[2][px]);
+    *reinterpret_cast<f32x2*>(dst + 2 * 4 * (W2_H * W2_NQ * 4)) = w2_pk_sub(dxp[2][px], dxp[1][px]);
+    *reinterpret_cast<f32x2*>(dst + 3 * 4 * (W2_H * W2_NQ * 4)) = w2_pk_sub(dxp[3][px], dxp[1][px]);   // row py = 3 likewise
   };
 
   fx_setup(item);
-  {  // the exposed prologue of this workgroup: RAW of its chunks 0 and 1, weights of chunk 0; chunk 0 transformed stand-alone
+  {
 #pragma unroll
     for (int j = 0; j < W2_XPW; ++j) dma_x(j, raw);
     fx_advance();
@@ -257,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
     fx_advance();
   }
   w2_dma_wait();
-  __syncthreads();   // publishes RAW / weights
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     tr_read(raw, r);
@@ -267,88 +286,92 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
   for (int px = 0; px < 4; ++px) tr_y(timg, px);
   __syncthreads();
 
-  int ci_ = 0;   // parity of the current chunk: T, W buffers ci_; RAW of the next chunk in raw[ci_ ^ 1]
+  // ---- accumulators [point][plane of the pair]: D[co = 16 hh + 4 kq + r][quad l16] ----
+  // Nothing but MFMAs ever adds to them: the bias AND a fused addend enter at item start.  Y = A^T M A with
+  // A^T = [1 1 1 0; 0 1 -1 -1] takes M[1][1] into all four outputs of the quad with weight + 1 (bias), and M[0][0], M[0][3],
+  // M[3][0], M[3][3] into exactly one output each: (0,0) +, (0,1) -, (1,0) -, (1,1) +.  This kernel computes the points of
+  // column px = 3 and of row py = 3 with the opposite sign (the RAW -> T transform emits d3 - d1 instead of d1 - d3 there, at
+  // no cost, and the output transform adds where it would subtract), which makes all four weights + 1: the addend's 2 x 2
+  // values of a quad are LOADED INTO the accumulators of points 0, 3, 12, 15.  Those loads are issued in the previous item's
+  // epilogue (in front of its stores: a load behind stores waits for them) and first needed at step 36 of the item's first
+  // chunk (the step order below visits these four points last), so the addend costs neither registers nor an exposed
+  // round trip: the epilogue with addend was 9 300 cycles against 3 500 without.
+  f32x4 acc[16][2];
+  auto quad_voxel = [&](int n, int z0, int y0, int x0) __attribute__((always_inline)) {   // first voxel of this lane's quad in plane 2 zw
+    return ((n * D + z0 + 2 * zw) * H + y0 + 2 * (l16 >> 2)) * W + x0 + 2 * (l16 & 3);
+  };
+  auto acc_init_plane = [&](int zz, int vq, int co) __attribute__((always_inline)) {   // addend (or zero) into the four corner points of plane zz
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = (k >> 1) * 12 + (k & 1) * 3;
+      if (ADD) acc[p][zz] = *reinterpret_cast<const f32x4*>(addend + (i64)(vq + zz * H * W + (k >> 1) * W + (k & 1)) * Cout + co);
+      else acc[p][zz] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto acc_init_rest = [&](int co) __attribute__((always_inline)) {
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (BIAS) b4 = *reinterpret_cast<const f32x4*>(bias + co);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      if (p == 0 || p == 3 || p == 12 || p == 15) continue;
+      acc[p][0] = (BIAS && p == 5) ? b4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[p][1] = (BIAS && p == 5) ? b4 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int cur_n, cur_z0, cur_y0, cur_x0, cur_cog, cur_tile;
+  decode(item, cur_n, cur_z0, cur_y0, cur_x0, cur_cog, cur_tile);
+  {
+    const int vq = quad_voxel(cur_n, cur_z0, cur_y0, cur_x0), co = cur_cog * 32 + 16 * hh + 4 * kq;
+    acc_init_plane(0, vq, co);
+    acc_init_plane(1, vq, co);
+    acc_init_rest(co);
+  }
+
+  int ci_ = 0;
 #ifdef W2_STAMPS
   int gchunk = 0;
 #endif
   for (;;) {
-    int cur_n, cur_z0, cur_y0, cur_x0, cur_cog, cur_tile;
-    decode(item, cur_n, cur_z0, cur_y0, cur_x0, cur_cog, cur_tile);
     const int next_item = item + istride;
     const bool more_items = next_item < ilimit;
-
-    // The bias enters through the accumulator of point (py, px) = (1, 1): the output transform Y = A^T M A adds M[1][1] to each of
-    // the quad's four outputs once (r0[1] and r1[1] both contain it with weight +1, and each output takes row entry 1 with
-    // weight +1), so starting that accumulator at b instead of 0 yields + b on every output.  The lane's 16 channels (8 g + 4 lh
-    // + c) come through SCALAR loads of the column block's 32 biases (wave-uniform address, selected per lane half): loaded
-    // in the epilogue instead, each group's vector load followed the previous group's stores, and on gfx9 the wait for a load
-    // also waits for every store issued before it -- 7 200 cycles per item against 5 700 for an item without bias
-    // (tools/ubench/wino2d_stamp.hip).  The scalar loads count on lgkmcnt and land behind the 240 register writes below.
-    f32x16 acc[16];
-    {
-      float binit[16];
-      if (BIAS) {
-        const int cb = __builtin_amdgcn_readfirstlane(cur_cog * 32);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float b0 = bias[cb + 8 * (r >> 2) + (r & 3)], b1 = bias[cb + 8 * (r >> 2) + 4 + (r & 3)];
-          binit[r] = lh ? b1 : b0;
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = (BIAS && p == 5) ? binit[r] : 0.f;
-    }
     for (int sc = 0; sc < NSC; ++sc) {
       const float* ws = wbuf + ci_ * W2_W;
       const float* tcur = timg + ci_ * W2_T;
-      float* wdst1 = wbuf + (ci_ ^ 1) * W2_W;           // weights of the next chunk
-      float* tdst1 = timg + (ci_ ^ 1) * W2_T;           // T of the next chunk
-      const float* rsrc1 = raw + (ci_ ^ 1) * W2_RAW;    // RAW of the next chunk (landed)
-      float* rdst2 = raw + ci_ * W2_RAW;                // RAW of the chunk after next (RAW of this chunk is dead)
+      float* wdst1 = wbuf + (ci_ ^ 1) * W2_W;
+      float* tdst1 = timg + (ci_ ^ 1) * W2_T;
+      const float* rsrc1 = raw + (ci_ ^ 1) * W2_RAW;
+      float* rdst2 = raw + ci_ * W2_RAW;
       const float* wsrc1 = fw_src();
-      // operands of step st + 2 are read while step st is multiplied (one wave per SIMD: nothing else hides the LDS latency);
-      // the scheduling barriers keep hipcc from moving the reads, the DMA issue and the transform stages
-      auto lda = [&](int s1) { return *reinterpret_cast<const f32x2*>(ws + s1 * 128 + abase); };
-      auto ldb = [&](int s1) {
-        return *reinterpret_cast<const f32x2*>(tcur + ((s1 & 15) * W2_H + (s1 >> 4)) * (W2_NQ * 4) + bbase);
-      };
+      auto lda = [&](int s1) { return ws[(w2_kz(s1) * 16 + w2_pt(s1)) * 128 + abase]; };
+      auto ldb = [&](int s1, int zz) { return tcur[(w2_pt(s1) * W2_H + w2_kz(s1)) * (W2_NQ * 4) + bbase + zz * (W2_NQ * 4)]; };
       W2_STAMP(gchunk, 0);
-      f32x2 aw0 = lda(0), bv0 = ldb(0), aw1 = lda(1), bv1 = ldb(1);
+      // operands of step st + W2_PF are read while step st is multiplied
+      float av[48], bv0[48], bv1[48];
 #pragma unroll
-      for (int st = 0; st < 48; ++st) {
-        f32x2 aw2 = aw1, bv2 = bv1;
-        if (st + 2 < 48) {
-          aw2 = lda(st + 2);
-          bv2 = ldb(st + 2);
-        }
-        // steps 0-9: DMA issue (weights first, they are needed first); steps 12-21: row stages; 24-33: column stages
-#ifndef W2_EXP_NODMA   // (diagnostic builds of tools/ubench/wino2d_stamp.hip drop one ingredient of the loop to price it)
-        if (st < W2_WPW) dma_w(st, wsrc1, wdst1);
-        else if (st - W2_WPW < W2_XPW) dma_x(st - W2_WPW, rdst2);
-#endif
-#ifndef W2_EXP_NOTR
-        if (st >= 12 && st <= 18 && (st & 1) == 0) tr_read(rsrc1, (st - 12) >> 1);
-        if (st >= 15 && st <= 21 && (st & 1) == 1) tr_x((st - 15) >> 1);
-        if (st >= 24 && st <= 33 && (st - 24) % 3 == 0) tr_y(tdst1, (st - 24) / 3);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        // A = weights, B = quads: D[co][quad], a lane owns quad (lane & 31) and channels 8 g + 4 (lane >> 5) + c
-        acc[st & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw0[0], bv0[0], acc[st & 15], 0, 0, 0);
-        acc[st & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw0[1], bv0[1], acc[st & 15], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        aw0 = aw1;
-        bv0 = bv1;
-        aw1 = aw2;
-        bv1 = bv2;
-      }
+      for (int st = 0; st < W2_PF; ++st) av[st] = lda(st), bv0[st] = ldb(st, 0), bv1[st] = ldb(st, 1);
+      w2_steps(
+          [&](auto st_c) __attribute__((always_inline)) {
+            constexpr int st = decltype(st_c)::value;
+            constexpr int pt = w2_pt(st);
+            if (st + W2_PF < 48) av[(st + W2_PF) % 48] = lda(st + W2_PF), bv0[(st + W2_PF) % 48] = ldb(st + W2_PF, 0), bv1[(st + W2_PF) % 48] = ldb(st + W2_PF, 1);
+            // steps 0-4: DMA issue (weights first, they are needed first); W2_TR0 ..: four row stages, four column stages
+            if (st < W2_WPW) dma_w(st, wsrc1, wdst1);
+            else if (st - W2_WPW < W2_XPW) dma_x(st - W2_WPW, rdst2);
+            if (st >= W2_TR0 && st <= W2_TR0 + 6 && ((st - W2_TR0) & 1) == 0) tr_read(rsrc1, (st - W2_TR0) >> 1);
+            if (st >= W2_TR0 + 3 && st <= W2_TR0 + 9 && ((st - W2_TR0) & 1) == 1) tr_x((st - W2_TR0 - 3) >> 1);
+            if (st >= W2_TR0 + 12 && st <= W2_TR0 + 21 && (st - W2_TR0 - 12) % 3 == 0) tr_y(tdst1, (st - W2_TR0 - 12) / 3);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv0[st], acc[pt][0], 0, 0, 0);
+            acc[pt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv1[st], acc[pt][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          },
+          std::make_integer_sequence<int, 48>{});
       W2_STAMP(gchunk, 1);
       fw_advance();
       fx_advance();
-      w2_dma_wait();     // own DMAs landed
+      w2_dma_wait();
       W2_STAMP(gchunk, 2);
-      __syncthreads();   // next T complete, everyone is done with this T / weight buffer
+      __syncthreads();
       W2_STAMP(gchunk, 3);
       ci_ ^= 1;
 #ifdef W2_STAMPS
@@ -356,63 +379,55 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
 #endif
     }
 
-    // ---- output transform Y = A^T M A + epilogue: bias (+ addend), dwordx4 stores, per-wave GroupNorm partial sums ----
-    float s0 = 0.f, s1 = 0.f;
-    const int co_lane = cur_cog * 32 + 4 * lh;
-    // the quad's first voxel (whole tiles only, host-checked: always inside the volume)
-    const int vo00 = ((cur_n * D + cur_z0 + 2 * wave + zz) * H + cur_y0 + 2 * qy) * W + cur_x0 + 2 * qx;
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int co = co_lane + 8 * g4;
-      if (co < Cout) {   // Cout % 4 == 0 (host-checked)
-        // fused addend: the group's four quads are requested BEFORE its accumulators are read and transformed, so their
-        // latency -- and the drain of the previous group's stores that the wait implies -- passes behind ~180 vector
-        // instructions.  Loaded next to each store (first version) the epilogue was 16 store + load round trips: 22 000 cycles
-        // per item against 13 000 now (mode 2 of the stamp harness; 96^3 32 -> 32: 177 -> 191 TFLOP/s algorithmic).  Fetching a
-        // group ahead of the previous group's stores needs 16 more registers and spills (54): measured slower.
-        f32x4 adq[4];
-        if (ADD) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            adq[k] = *reinterpret_cast<const f32x4*>(addend + (i64)(vo00 + (k >> 1) * W + (k & 1)) * Cout + co);
-        }
-        f32x4 v[2][2];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int r = 4 * g4 + c;
-          float r0[4], r1[4];
-#pragma unroll
-          for (int px = 0; px < 4; ++px) {
-            const float m0 = acc[px][r], m1 = acc[4 + px][r], m2 = acc[8 + px][r], m3 = acc[12 + px][r];
-            r0[px] = (m0 + m1) + m2;
-            r1[px] = (m1 - m2) - m3;
-          }
-          v[0][0][c] = (r0[0] + r0[1]) + r0[2];
-          v[0][1][c] = (r0[1] - r0[2]) - r0[3];
-          v[1][0][c] = (r1[0] + r1[1]) + r1[2];
-          v[1][1][c] = (r1[1] - r1[2]) - r1[3];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const i64 off = (i64)(vo00 + i * W + j) * Cout + co;
-            if (ADD) v[i][j] += adq[2 * i + j];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              s0 += v[i][j][c];
-              s1 += v[i][j][c] * v[i][j][c];
-            }
-            *reinterpret_cast<f32x4*>(y + off) = v[i][j];
-          }
-      }
+    // ---- output transform Y = A^T M A (signs as explained above) + epilogue, plane by plane: 4 consecutive channels (co_lane ..)
+    // of quad l16, packed fp32 math over the channel pairs (0, 1), (2, 3) of an accumulator (aligned register pairs).  After a
+    // plane's accumulators have been read, the NEXT item's addend is requested into its corner points, then the plane is stored ----
+    const int co_lane = cur_cog * 32 + 16 * hh + 4 * kq;
+    const int vo_q = quad_voxel(cur_n, cur_z0, cur_y0, cur_x0);
+    const int stat_slot = (cur_n * (ntz * nty * ntx) + cur_tile) * ncog + cur_cog;
+    int nco_lane = co_lane, nvo_q = vo_q;
+    if (more_items) {
+      decode(next_item, cur_n, cur_z0, cur_y0, cur_x0, cur_cog, cur_tile);
+      nco_lane = cur_cog * 32 + 16 * hh + 4 * kq;
+      nvo_q = quad_voxel(cur_n, cur_z0, cur_y0, cur_x0);
     }
+    f32x2 s0p = {0.f, 0.f}, s1p = {0.f, 0.f};
+#pragma unroll
+    for (int zz = 0; zz < 2; ++zz) {
+      const int vo00 = vo_q + zz * H * W;
+      f32x2 v[2][2][2];   // [i][j][channel pair]
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        f32x2 r0[4], r1[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          const f32x2 m0 = {acc[px][zz][2 * h2], acc[px][zz][2 * h2 + 1]}, m1 = {acc[4 + px][zz][2 * h2], acc[4 + px][zz][2 * h2 + 1]};
+          const f32x2 m2 = {acc[8 + px][zz][2 * h2], acc[8 + px][zz][2 * h2 + 1]}, m3 = {acc[12 + px][zz][2 * h2], acc[12 + px][zz][2 * h2 + 1]};
+          r0[px] = w2_pk_add(w2_pk_add(m0, m1), m2);
+          r1[px] = w2_pk_add(w2_pk_sub(m1, m2), m3);
+        }
+        v[0][0][h2] = w2_pk_add(w2_pk_add(r0[0], r0[1]), r0[2]);
+        v[0][1][h2] = w2_pk_add(w2_pk_sub(r0[1], r0[2]), r0[3]);
+        v[1][0][h2] = w2_pk_add(w2_pk_add(r1[0], r1[1]), r1[2]);
+        v[1][1][h2] = w2_pk_add(w2_pk_sub(r1[1], r1[2]), r1[3]);
+      }
+      if (more_items) acc_init_plane(zz, nvo_q, nco_lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x2 lo = v[i][j][0], hi = v[i][j][1];
+          s0p = w2_pk_add(s0p, w2_pk_add(lo, hi));
+          s1p = w2_pk_fma(lo, lo, s1p);
+          s1p = w2_pk_fma(hi, hi, s1p);
+          *reinterpret_cast<f32x4*>(y + (i64)(vo00 + i * W + j) * Cout + co_lane) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+    }
+    if (more_items) acc_init_rest(nco_lane);
     if (stats) {
-      s0 = wave_sum(s0);
-      s1 = wave_sum(s1);
+      const float s0 = wave_sum(s0p[0] + s0p[1]), s1 = wave_sum(s1p[0] + s1p[1]);
       if (lane == 0) {
-        const int tiles_per_sample = ntz * nty * ntx;
-        float* dst = stats + ((((i64)cur_n * tiles_per_sample + cur_tile) * ncog + cur_cog) * W2_NW + wave) * 2;
+        float* dst = stats + ((i64)stat_slot * W2_NW + wave) * 2;
         dst[0] = s0;
         dst[1] = s1;
       }
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wino2d_kernel(const float* _
     if (!more_items) break;
     item = next_item;
   }
-  w2_dma_wait();   // nothing in flight when the workgroup's LDS is released
+  w2_dma_wait();
 }
 
 // shapes this kernel takes: whole 8 x 8 x 8 tiles, channel blocks of 8 / 32
@@ -462,8 +477,8 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
   const int nitems = N * ntz * nty * ntx * ncog;
   dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
 #define W2_LAUNCH(B_, A_)                                                                                                       \
-  hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<B_, A_>), grid, dim3(256), (size_t)W2_LDS_FLOATS * 4, (hipStream_t)stream, x, wp, \
-                     bias, y, stats, N, D, H, W, Cin, Cout, ntz, nty, ntx, ncog, nitems, addend)
+  hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<B_, A_>), grid, dim3(64 * W2_NW), (size_t)W2_LDS_FLOATS * 4, (hipStream_t)stream, x, \
+                     wp, bias, y, stats, N, D, H, W, Cin, Cout, ntz, nty, ntx, ncog, nitems, addend)
   if (bias) {
     if (addend) W2_LAUNCH(true, true); else W2_LAUNCH(true, false);
   } else {

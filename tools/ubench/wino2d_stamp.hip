@@ -25,9 +25,11 @@ int main(int argc, char** argv) {
   if (mode == 2) { (void)hipMalloc(&addend, nx * 4); (void)hipMemset(addend, 0, nx * 4); }
   if (mode != 0) bias = nullptr;
   (void)hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); (void)hipMemcpy(wp, hw.data(), nw * 4, hipMemcpyHostToDevice);
-  const size_t nst = 8 * 4 * 64 * 8;
+  const size_t nst = 8 * 8 * 64 * 8;   // 8 workgroups x up to 8 waves x 64 chunks x 8 stamps
   (void)hipMalloc(&stamps, nst * 8); (void)hipMemset(stamps, 0, nst * 8);
+#ifdef W2_STAMPS
   (void)hipMemcpyToSymbol(HIP_SYMBOL(w2_stamp_buf), &stamps, sizeof(stamps));
+#endif
   for (int r = 0; r < 3; ++r) {
     int rc = seg3d_conv3d_k3_wino2d_fwd(x, wp, bias, addend, y, nullptr, N, D, H, W, C, C, nullptr);
     if (rc) { printf("error %d\n", rc); return 1; }
@@ -37,20 +39,25 @@ int main(int argc, char** argv) {
   for (int r = 0; r < 10; ++r) seg3d_conv3d_k3_wino2d_fwd(x, wp, bias, addend, y, nullptr, N, D, H, W, C, C, nullptr);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+#ifndef W2_STAMPS   // plain timing build: -DW2_STAMPS left out
+  printf("N=%d %d^3 C=%d mode %d: %.3f ms, %.1f TFLOP/s algorithmic\n", N, D, C, mode, ms, 2.0 * N * D * H * W * 27 * C * C / ms / 1e9);
+  return 0;
+#endif
   printf("N=%d %d^3 C=%d mode %d: %.3f ms, %.1f TFLOP/s algorithmic (stamped build)\n", N, D, C, mode, ms, 2.0 * N * D * H * W * 27 * C * C / ms / 1e9);
   std::vector<long long> h(nst);
   (void)hipMemcpy(h.data(), stamps, nst * 8, hipMemcpyDeviceToHost);
   const char* names[4] = {"MFMA loop (+ DMA issue, transform stages)", "cursor advance + DMA wait", "barrier", "to next loop start (per-item work)"};
-  for (int wv = 0; wv < 4; ++wv) {
+  for (int wv = 0; wv < 8; ++wv) {
     double acc[4] = {0, 0, 0, 0}; int n = 0; double period = 0;
     for (int b = 0; b < 8; ++b)
       for (int c = 1; c + 1 < 60; ++c) {
-        const long long* t = &h[((b * 4 + wv) * 64 + c) * 8];
-        const long long* tn = &h[((b * 4 + wv) * 64 + c + 1) * 8];
+        const long long* t = &h[((b * 8 + wv) * 64 + c) * 8];
+        const long long* tn = &h[((b * 8 + wv) * 64 + c + 1) * 8];
         if (!t[0] || !t[3] || !tn[0]) continue;
         acc[0] += t[1] - t[0]; acc[1] += t[2] - t[1]; acc[2] += t[3] - t[2]; acc[3] += tn[0] - t[3];
         period += tn[0] - t[0]; ++n;
       }
+    if (!n) continue;
     printf("wave %d (%d chunks): period %.0f cycles", wv, n, n ? period / n : 0.0);
     for (int k = 0; k < 4; ++k) printf(" | %s %.0f", names[k], n ? acc[k] / n : 0.0);
     printf("\n");
@@ -58,10 +65,10 @@ int main(int argc, char** argv) {
   {  // per item: epilogue (after the last chunk's barrier -> stores issued) and accumulator init + decode of the next item
     double epi = 0, ini = 0; int n = 0;
     for (int b = 0; b < 8; ++b)
-      for (int wv = 0; wv < 4; ++wv)
+      for (int wv = 0; wv < 8; ++wv)
         for (int c = 1; c + 1 < 60; ++c) {
-          const long long* t = &h[((b * 4 + wv) * 64 + c) * 8];
-          const long long* tn = &h[((b * 4 + wv) * 64 + c + 1) * 8];
+          const long long* t = &h[((b * 8 + wv) * 64 + c) * 8];
+          const long long* tn = &h[((b * 8 + wv) * 64 + c + 1) * 8];
           if (!t[6] || !t[3] || !tn[0]) continue;
           epi += t[6] - t[3]; ini += tn[0] - t[6]; ++n;
         }

@@ -62,6 +62,22 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 4; ++k) printf(" | %s %.0f", names[k], n ? acc[k] / n : 0.0);
     printf("\n");
   }
+  {  // by position of the chunk inside its item (wave 4 = a slower wave of its SIMD): where do the waits sit?
+    const int nsc = C / 4;
+    printf("wave 4 by chunk position in the item:\n");
+    for (int pos = 0; pos < nsc; ++pos) {
+      double acc[4] = {0, 0, 0, 0}; int n = 0;
+      for (int b = 0; b < 8; ++b)
+        for (int c = 1; c + 1 < 60; ++c) {
+          if (c % nsc != pos) continue;
+          const long long* t = &h[((b * 8 + 4) * 64 + c) * 8];
+          const long long* tn = &h[((b * 8 + 4) * 64 + c + 1) * 8];
+          if (!t[0] || !t[3] || !tn[0]) continue;
+          acc[0] += t[1] - t[0]; acc[1] += t[2] - t[1]; acc[2] += t[3] - t[2]; acc[3] += tn[0] - t[3]; ++n;
+        }
+      if (n) printf("  chunk %d: loop %.0f | advance + DMA wait %.0f | barrier %.0f | to next loop start %.0f\n", pos, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n);
+    }
+  }
   {  // per item: epilogue (after the last chunk's barrier -> stores issued) and accumulator init + decode of the next item
     double epi = 0, ini = 0; int n = 0;
     for (int b = 0; b < 8; ++b)

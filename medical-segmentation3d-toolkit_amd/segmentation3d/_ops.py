@@ -804,6 +804,8 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
 # backward (the bucketed all-reduce, core/ddp.py) call wgrad_stream_join() themselves.
 WGRAD_SIDE_STREAM = True      # False (bench.py --no-wgrad-overlap, profiling): weight gradients on the main stream
 _SIDE_STREAMS = {}
+SIDE_KEEPALIVE = True     # inputs of side-stream weight gradients are held until the join (False: Tensor.record_stream)
+_SIDE_KEEP = {}           # device index -> [(x, dy)] of the weight gradients issued since the last join
 _JOIN_QUEUED_FOR = [-1]   # id of the backward pass (graph task) whose end-of-backward join is already queued
 
 
@@ -861,6 +863,7 @@ def wgrad_stream_join():
     st = _SIDE_STREAMS.get(cur.device.index)
     if st is not None:
         cur.wait_stream(st)
+        _SIDE_KEEP.pop(cur.device.index, None)    # everything the side stream read is safe to recycle behind this wait
 
 
 def _join_after_backward():
@@ -889,8 +892,16 @@ def _wgrad_to_sink(xn, dyn, w_shape, kind, sink_view):
     side.wait_stream(torch.cuda.current_stream())       # x and dy are complete on the main stream
     with torch.cuda.stream(side):
         conv_wgrad(xn, dyn, w_shape, kind, out=sink_view)
-    xn.record_stream(side)                               # the allocator must not recycle them before the side stream is done
-    dyn.record_stream(side)
+    # the allocator must not recycle x / dy before the side stream is done with them: they are kept alive until the main
+    # stream has joined the side stream (wgrad_stream_join drops the references).  Tensor.record_stream would do the same
+    # through per-block events in the caching allocator: ~30 x 2 calls and event queries per backward on the launching thread
+    # (tools/ab_step.py SIDE_KEEPALIVE=True / False, three pairs, eager: 15.69 / 15.79 / 15.74 against 15.88 / 15.87 / 15.87 ms;
+    # a reusable event + bare set_stream calls instead of wait_stream + the stream context manager: no change)
+    if SIDE_KEEPALIVE:
+        _SIDE_KEEP.setdefault(dyn.device.index, []).append((xn, dyn))
+    else:
+        xn.record_stream(side)
+        dyn.record_stream(side)
     task = torch._C._current_graph_task_id()
     if task != _JOIN_QUEUED_FOR[0]:                      # once per backward pass (also after one that raised)
         _JOIN_QUEUED_FOR[0] = task

@@ -439,26 +439,344 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
   w2_dma_wait();
 }
 
-// shapes this kernel takes: whole 8 x 8 x 8 tiles, channel blocks of 8 / 32
+// ================================================================================================================
+// The same algorithm on 4 x 4 x 4 CELLS (conv3d_k3_wino2d_c4_kernel): levels whose edges are multiples of 4 but not of 8 -- the
+// 12^3 levels of the V-Net (down_128 / up_256 residual blocks, network/vnet.py:29-31), which the 8^3-tile kernel cannot tile
+// (a 12 x 12 plane is 36 quads).  A cell is 4 z planes x 2 x 2 quads = 16 (z, quad) columns of ONE 16x16x4 MFMA column group,
+// with its own 6^3 halo; the T layout [p][cell][z 6][quad 4][4] makes the column (z, quad) of step kz the contiguous address
+// (z + kz) * 4 + quad.  An item is FOUR consecutive cells (any four: cells are independent, they may belong to two samples)
+// x one 32-channel column block: wave (c, h) owns cell c and the output channels 16 h .. 16 h + 15 -- 16 point accumulators of
+// 4 registers, one A read, one B read and one MFMA per step.  Everything else is the tile kernel: K chunks of four channels,
+// weights and RAW halo cells by LDS-DMA (16 RAW pieces: four per cell), the transform inside the MFMA loop (192 (cell, z, quad,
+// channel pair) tasks, 24 per wave), one barrier per chunk, bias / addend through the accumulators.  Per chunk a SIMD issues
+// half the MFMAs of the tile kernel for the same DMA, barrier and three fifths of the transform work, so the executed rate is
+// lower (0.5 of the peak) -- on 4/9 of the direct kernel's MFMAs.
+// ================================================================================================================
+#define C4_H 6                                    // halo edge of a cell
+#define C4_NV (C4_H * C4_H * C4_H)                // 216 halo voxels (256 slots = four 1-KiB pieces per cell)
+#define C4_PSTR (4 * 24 * 4)                      // floats between two points of T: [cell 4][z 6][quad 4][4]
+#define C4_T (16 * C4_PSTR)                       // 6144 floats
+#define C4_LDS_FLOATS (2 * W2_RAW + 2 * C4_T + 2 * W2_W)   // 32 + 48 + 48 KB
+
+template <bool BIAS, bool ADD>
+__global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                                      float* __restrict__ stats, int N, int D, int H, int W, int Cin,
+                                                                      int Cout, int ncz, int ncy, int ncx, int ncells, int ncog,
+                                                                      int nitems, const float* __restrict__ addend) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* raw = lds;                               // [2][4 cells][256 slots][4]
+  float* timg = lds + 2 * W2_RAW;                 // [2][16][4][6][4][4]
+  float* wbuf = lds + 2 * W2_RAW + 2 * C4_T;      // [2][48][32][4]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 3, hh = wave >> 2;        // cell of the item, output-channel half
+  const int l16 = lane & 15, kq = lane >> 4;      // MFMA column (z = l16 >> 2, quad = l16 & 3) and K index
+  const int NSC = Cin >> 2;
+  const int AB = Cin >> 3;
+  const int G = gridDim.x;
+  const int cps = ncz * ncy * ncx;                // cells per sample
+  auto fdiv = [](int v, float r) { return (int)(((float)v + 0.5f) * r); };
+  const float rNCX = 1.0f / (float)ncx, rNCY = 1.0f / (float)ncy, rNCZ = 1.0f / (float)ncz, rNCOG = 1.0f / (float)ncog;
+
+  // raw DMA pieces of this wave: piece p = wave + 8 j is slots 64 (p & 3) .. + 63 of cell p >> 2 of the item
+  int hpos[W2_XPW];
+#pragma unroll
+  for (int j = 0; j < W2_XPW; ++j) {
+    const int e = ((wave + W2_NW * j) & 3) * 64 + lane;
+    hpos[j] = -1;
+    if (e < C4_NV) {
+      const int t = e / C4_H;
+      const int hx = e - t * C4_H;
+      const int hz = t / C4_H;
+      const int hy = t - hz * C4_H;
+      hpos[j] = (hz << 20) | (hy << 10) | hx;
+    }
+  }
+  const int abase = (16 * hh + l16) * 4 + kq;                 // weights [t][co][4]: + t * 128
+  const int bbase = (wc * 24 + l16) * 4 + kq;                 // T [p][cell][z][quad][4]: + p * C4_PSTR + kz * 16
+  // transform task of this lane: 192 (cell, z, quad, channel pair) tasks, 24 per wave (lanes >= 24 repeat task 23 of their wave)
+  const int t_task = wave * 24 + (lane < 24 ? lane : 23);
+  const int t_cell = t_task / 48, t_rem = t_task - 48 * t_cell;
+  const int t_i = t_rem >> 1, t_h = t_rem & 1;
+  const int t_z = t_i >> 2, t_q = t_i & 3;
+  const int t_src = t_cell * 1024 + ((t_z * C4_H + 2 * (t_q >> 1)) * C4_H + 2 * (t_q & 1)) * 4 + 2 * t_h;
+  const int t_dst = (t_cell * 24 + t_z * 4 + t_q) * 4 + 2 * t_h;
+
+  // cell -> sample, origin, index inside the sample (cells past the end of a last, partial item are clamped: their waves load
+  // and multiply like the others and store nothing)
+  auto cell_origin = [&](int cell, int& n, int& z0, int& y0, int& x0, int& cis) {
+    int b = cell < ncells ? cell : ncells - 1;
+    int q = fdiv(b, rNCX);
+    const int cx = b - q * ncx;
+    b = q;
+    q = fdiv(b, rNCY);
+    const int cy = b - q * ncy;
+    b = q;
+    q = fdiv(b, rNCZ);
+    const int cz = b - q * ncz;
+    n = q;
+    cis = (cz * ncy + cy) * ncx + cx;
+    z0 = cz * 4, y0 = cy * 4, x0 = cx * 4;
+  };
+  auto group_of = [&](int it, int& cog) {
+    const int grp = fdiv(it, rNCOG);
+    cog = it - grp * ncog;
+    return grp;
+  };
+  int item = blockIdx.x, istride = G, ilimit = nitems;
+  if ((G & 7) == 0) {
+    const int per_xcd = (nitems + 7) >> 3, xcd = blockIdx.x & 7;
+    item = xcd * per_xcd + (blockIdx.x >> 3);
+    istride = G >> 3;
+    ilimit = (xcd + 1) * per_xcd < nitems ? (xcd + 1) * per_xcd : nitems;
+  }
+  if (item >= ilimit) return;
+
+  int fx_item = item, fx_sc = 0;
+  const float* xsrc[W2_XPW];
+  int xadv = 0;
+  auto fx_setup = [&](int it) {
+    int cog;
+    const int grp = group_of(it, cog);
+    xadv = 0;
+#pragma unroll
+    for (int j = 0; j < W2_XPW; ++j) {
+      int n, z0, y0, x0, cis;
+      cell_origin(4 * grp + ((wave + W2_NW * j) >> 2), n, z0, y0, x0, cis);
+      xsrc[j] = w2_zero16;
+      const int hp = hpos[j];
+      const int gz = z0 + ((hp >> 20) & 1023) - 1, gy = y0 + ((hp >> 10) & 1023) - 1, gx = x0 + (hp & 1023) - 1;
+      if (hp >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        xsrc[j] = x + (i64)(((n * D + gz) * H + gy) * W + gx) * Cin;
+        xadv |= 1 << j;
+      }
+    }
+  };
+  auto fx_advance = [&]() {
+    ++fx_sc;
+    if (fx_sc == NSC) {
+      fx_sc = 0;
+      if (fx_item + istride < ilimit) fx_item += istride;
+      fx_setup(fx_item);
+    }
+  };
+  auto dma_x = [&](int j, float* rdst) {
+    w2_glds16(xsrc[j], rdst + (wave + W2_NW * j) * 256);
+    xsrc[j] += ((xadv >> j) & 1) * 4;
+  };
+  int fw_item = item, fw_sc = 0;
+  auto cog_of = [&](int it) { return __builtin_amdgcn_readfirstlane(it - fdiv(it, rNCOG) * ncog); };
+  int fw_cog = cog_of(fw_item);
+  auto fw_src = [&]() { return wp + ((i64)fw_cog * AB + (fw_sc >> 1)) * (48 * 256) + (fw_sc & 1) * 128; };
+  auto fw_advance = [&]() {
+    ++fw_sc;
+    if (fw_sc == NSC) {
+      fw_sc = 0;
+      if (fw_item + istride < ilimit) fw_item += istride;
+      fw_cog = cog_of(fw_item);
+    }
+  };
+  const unsigned w_lane_off = ((lane >> 5) * 256 + (lane & 31) * 4) * 4;
+  auto dma_w = [&](int j, const float* wsrc, float* wdst) {
+    const int piece = wave + W2_NW * j;
+    w2_glds16_sbase(wsrc + 2 * piece * 256, w_lane_off, wdst + piece * 256);
+  };
+  // RAW -> T (signs of column px = 3 / row py = 3 as in the tile kernel)
+  f32x2 rd[2][4];
+  f32x2 dxp[4][4];
+  auto tr_read = [&](const float* rw, int r) {
+    const float* sp = rw + t_src + r * (C4_H * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rd[r & 1][k] = *reinterpret_cast<const f32x2*>(sp + 4 * k);
+  };
+  auto tr_x = [&](int r) {
+    const f32x2* d = rd[r & 1];
+    dxp[r][0] = w2_pk_sub(d[0], d[2]);
+    dxp[r][1] = w2_pk_add(d[1], d[2]);
+    dxp[r][2] = w2_pk_sub(d[2], d[1]);
+    dxp[r][3] = w2_pk_sub(d[3], d[1]);
+  };
+  auto tr_y = [&](float* tdst, int px) {
+    float* dst = tdst + t_dst + px * C4_PSTR;
+    *reinterpret_cast<f32x2*>(dst + 0 * 4 * C4_PSTR) = w2_pk_sub(dxp[0][px], dxp[2][px]);
+    *reinterpret_cast<f32x2*>(dst + 1 * 4 * C4_PSTR) = w2_pk_add(dxp[1][px], dxp[2][px]);
+    *reinterpret_cast<f32x2*>(dst + 2 * 4 * C4_PSTR) = w2_pk_sub(dxp[2][px], dxp[1][px]);
+    *reinterpret_cast<f32x2*>(dst + 3 * 4 * C4_PSTR) = w2_pk_sub(dxp[3][px], dxp[1][px]);
+  };
+
+  fx_setup(item);
+  {
+#pragma unroll
+    for (int j = 0; j < W2_XPW; ++j) dma_x(j, raw);
+    fx_advance();
+    const float* w0 = fw_src();
+#pragma unroll
+    for (int j = 0; j < W2_WPW; ++j) dma_w(j, w0, wbuf);
+    fw_advance();
+#pragma unroll
+    for (int j = 0; j < W2_XPW; ++j) dma_x(j, raw + W2_RAW);
+    fx_advance();
+  }
+  w2_dma_wait();
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    tr_read(raw, r);
+    tr_x(r);
+  }
+#pragma unroll
+  for (int px = 0; px < 4; ++px) tr_y(timg, px);
+  __syncthreads();
+
+  // accumulators [point]: D[co = 16 hh + 4 kq + r][column l16]; bias and addend enter as in the tile kernel
+  f32x4 acc[16];
+  // this wave's cell of an item: first voxel of the lane's quad, statistics slot, is it a real cell
+  auto my_cell = [&](int it, int& vq, int& co, int& slot, bool& valid) __attribute__((always_inline)) {
+    int cog;
+    const int grp = group_of(it, cog);
+    int n, z0, y0, x0, cis;
+    cell_origin(4 * grp + wc, n, z0, y0, x0, cis);
+    valid = 4 * grp + wc < ncells;
+    vq = ((n * D + z0 + (l16 >> 2)) * H + y0 + 2 * ((l16 >> 1) & 1)) * W + x0 + 2 * (l16 & 1);
+    co = cog * 32 + 16 * hh + 4 * kq;
+    slot = ((n * cps + cis) * ncog + cog) * 2 + hh;
+  };
+  auto acc_init = [&](int vq, int co) __attribute__((always_inline)) {
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (BIAS) b4 = *reinterpret_cast<const f32x4*>(bias + co);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      if (ADD && (p == 0 || p == 3 || p == 12 || p == 15)) {
+        const int k = (p >= 12 ? 2 : 0) + (p & 1);   // p = 0, 3, 12, 15 -> output (i, j) = (k >> 1, k & 1)
+        acc[p] = *reinterpret_cast<const f32x4*>(addend + (i64)(vq + (k >> 1) * W + (k & 1)) * Cout + co);
+      } else {
+        acc[p] = (BIAS && p == 5) ? b4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  int cur_vq, cur_co, cur_slot;
+  bool cur_valid;
+  my_cell(item, cur_vq, cur_co, cur_slot, cur_valid);
+  acc_init(cur_vq, cur_co);
+
+  int ci_ = 0;
+  for (;;) {
+    const int next_item = item + istride;
+    const bool more_items = next_item < ilimit;
+    for (int sc = 0; sc < NSC; ++sc) {
+      const float* ws = wbuf + ci_ * W2_W;
+      const float* tcur = timg + ci_ * C4_T;
+      float* wdst1 = wbuf + (ci_ ^ 1) * W2_W;
+      float* tdst1 = timg + (ci_ ^ 1) * C4_T;
+      const float* rsrc1 = raw + (ci_ ^ 1) * W2_RAW;
+      float* rdst2 = raw + ci_ * W2_RAW;
+      const float* wsrc1 = fw_src();
+      auto lda = [&](int s1) { return ws[(w2_kz(s1) * 16 + w2_pt(s1)) * 128 + abase]; };
+      auto ldb = [&](int s1) { return tcur[w2_pt(s1) * C4_PSTR + w2_kz(s1) * 16 + bbase]; };
+      float av[48], bv[48];
+#pragma unroll
+      for (int st = 0; st < W2_PF; ++st) av[st] = lda(st), bv[st] = ldb(st);
+      w2_steps(
+          [&](auto st_c) __attribute__((always_inline)) {
+            constexpr int st = decltype(st_c)::value;
+            constexpr int pt = w2_pt(st);
+            if (st + W2_PF < 48) av[(st + W2_PF) % 48] = lda(st + W2_PF), bv[(st + W2_PF) % 48] = ldb(st + W2_PF);
+            if (st < W2_WPW) dma_w(st, wsrc1, wdst1);
+            else if (st - W2_WPW < W2_XPW) dma_x(st - W2_WPW, rdst2);
+            if (st >= W2_TR0 && st <= W2_TR0 + 6 && ((st - W2_TR0) & 1) == 0) tr_read(rsrc1, (st - W2_TR0) >> 1);
+            if (st >= W2_TR0 + 3 && st <= W2_TR0 + 9 && ((st - W2_TR0) & 1) == 1) tr_x((st - W2_TR0 - 3) >> 1);
+            if (st >= W2_TR0 + 12 && st <= W2_TR0 + 21 && (st - W2_TR0 - 12) % 3 == 0) tr_y(tdst1, (st - W2_TR0 - 12) / 3);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st], acc[pt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          },
+          std::make_integer_sequence<int, 48>{});
+      fw_advance();
+      fx_advance();
+      w2_dma_wait();
+      __syncthreads();
+      ci_ ^= 1;
+    }
+
+    // ---- output transform (signs as in the tile kernel) + epilogue: the quad's 2 x 2 voxels x 4 channels ----
+    int nvq = cur_vq, nco = cur_co, nslot = cur_slot;
+    bool nvalid = cur_valid;
+    if (more_items) my_cell(next_item, nvq, nco, nslot, nvalid);
+    f32x2 v[2][2][2];   // [i][j][channel pair]
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      f32x2 r0[4], r1[4];
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        const f32x2 m0 = {acc[px][2 * h2], acc[px][2 * h2 + 1]}, m1 = {acc[4 + px][2 * h2], acc[4 + px][2 * h2 + 1]};
+        const f32x2 m2 = {acc[8 + px][2 * h2], acc[8 + px][2 * h2 + 1]}, m3 = {acc[12 + px][2 * h2], acc[12 + px][2 * h2 + 1]};
+        r0[px] = w2_pk_add(w2_pk_add(m0, m1), m2);
+        r1[px] = w2_pk_add(w2_pk_sub(m1, m2), m3);
+      }
+      v[0][0][h2] = w2_pk_add(w2_pk_add(r0[0], r0[1]), r0[2]);
+      v[0][1][h2] = w2_pk_add(w2_pk_sub(r0[1], r0[2]), r0[3]);
+      v[1][0][h2] = w2_pk_add(w2_pk_add(r1[0], r1[1]), r1[2]);
+      v[1][1][h2] = w2_pk_add(w2_pk_sub(r1[1], r1[2]), r1[3]);
+    }
+    if (more_items) acc_init(nvq, nco);   // (the next item's addend: requested in front of this item's stores)
+    f32x2 s0p = {0.f, 0.f}, s1p = {0.f, 0.f};
+    if (cur_valid) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x2 lo = v[i][j][0], hi = v[i][j][1];
+          s0p = w2_pk_add(s0p, w2_pk_add(lo, hi));
+          s1p = w2_pk_fma(lo, lo, s1p);
+          s1p = w2_pk_fma(hi, hi, s1p);
+          *reinterpret_cast<f32x4*>(y + (i64)(cur_vq + i * W + j) * Cout + cur_co) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+      if (stats) {
+        const float s0 = wave_sum(s0p[0] + s0p[1]), s1 = wave_sum(s1p[0] + s1p[1]);
+        if (lane == 0) {
+          float* dst = stats + (i64)cur_slot * 2;
+          dst[0] = s0;
+          dst[1] = s1;
+        }
+      }
+    }
+    if (!more_items) break;
+    item = next_item;
+    cur_vq = nvq, cur_co = nco, cur_slot = nslot, cur_valid = nvalid;
+  }
+  w2_dma_wait();
+}
+
+// shapes these kernels take: whole 8 x 8 x 8 tiles (the tile kernel) or, failing that, whole 4 x 4 x 4 cells (the cell kernel);
+// channel blocks of 8 / 32
+static bool w2_tiles(int D, int H, int W) { return !(D % W2_TS) && !(H % W2_TS) && !(W % W2_TS); }
+static bool w2_cells(int D, int H, int W) { return !(D % 4) && !(H % 4) && !(W % 4); }
+static long long w2_items(int N, int D, int H, int W, int Cout) {   // (tile | group of four cells, column block) items
+  if (w2_tiles(D, H, W)) return (long long)N * (D / W2_TS) * (H / W2_TS) * (W / W2_TS) * (Cout / 32);
+  return (((long long)N * (D / 4) * (H / 4) * (W / 4) + 3) / 4) * (Cout / 32);
+}
+
 extern "C" int seg3d_conv3d_k3_wino2d_supported(int N, int D, int H, int W, int Cin, int Cout) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-  if ((D % W2_TS) || (H % W2_TS) || (W % W2_TS) || (Cin & 7) || (Cout & 31)) return 0;
-  const long long items = (long long)N * (D / W2_TS) * (H / W2_TS) * (W / W2_TS) * (Cout / 32);
-  if (items >= (1 << 20)) return 0;
+  if (!w2_cells(D, H, W) || (Cin & 7) || (Cout & 31)) return 0;
+  if (w2_items(N, D, H, W, Cout) >= (1 << 20)) return 0;
   if ((long long)N * D * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;
   return 1;
 }
 
-// ... and where it is the faster choice: enough (tile, column block) items to fill the 256 CUs
+// ... and where it is the faster choice: enough items to fill the 256 CUs
 extern "C" int seg3d_conv3d_k3_wino2d_preferred(int N, int D, int H, int W, int Cin, int Cout) {
   if (!seg3d_conv3d_k3_wino2d_supported(N, D, H, W, Cin, Cout)) return 0;
-  return (long long)N * (D / W2_TS) * (H / W2_TS) * (W / W2_TS) * (Cout / 32) >= 192;
+  return w2_items(N, D, H, W, Cout) >= 192;
 }
 
-// GroupNorm partial (sum, sumsq) slots per sample
+// GroupNorm partial (sum, sumsq) slots per sample: one per (tile, column block, wave) / per (cell, column block, channel half)
 extern "C" long long seg3d_conv3d_k3_wino2d_stats_count(int N, int D, int H, int W, int Cin, int Cout) {
   (void)N; (void)Cin;
-  return (long long)(D / W2_TS) * (H / W2_TS) * (W / W2_TS) * (Cout / 32) * W2_NW;
+  if (w2_tiles(D, H, W)) return (long long)(D / W2_TS) * (H / W2_TS) * (W / W2_TS) * (Cout / 32) * W2_NW;
+  return (long long)(D / 4) * (H / 4) * (W / 4) * (Cout / 32) * 2;
 }
 
 // x [N][D][H][W][Cin], wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 48) (the F(2x2, 3x3) image), y [N][D][H][W][Cout];
@@ -467,24 +785,43 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
                                           float* stats, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_wino2d_fwd: null pointer");
   SEG3D_REQUIRE(seg3d_conv3d_k3_wino2d_supported(N, D, H, W, Cin, Cout),
-                "seg3d_conv3d_k3_wino2d_fwd: shape not supported (whole 8^3 tiles, Cin %% 8 == 0, Cout %% 32 == 0)");
-  static Seg3dOncePerDevice configured[4];
-  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<false, false>), configured[0], "conv3d_k3_wino2d")) return rc;
-  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<true, false>), configured[1], "conv3d_k3_wino2d")) return rc;
-  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<false, true>), configured[2], "conv3d_k3_wino2d")) return rc;
-  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<true, true>), configured[3], "conv3d_k3_wino2d")) return rc;
-  const int ntz = D / W2_TS, nty = H / W2_TS, ntx = W / W2_TS, ncog = Cout / 32;
-  const int nitems = N * ntz * nty * ntx * ncog;
+                "seg3d_conv3d_k3_wino2d_fwd: shape not supported (whole 4^3 cells, Cin %% 8 == 0, Cout %% 32 == 0)");
+  const int ncog = Cout / 32;
+  const int nitems = (int)w2_items(N, D, H, W, Cout);
   dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
+  if (w2_tiles(D, H, W)) {
+    static Seg3dOncePerDevice configured[4];
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<false, false>), configured[0], "conv3d_k3_wino2d")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<true, false>), configured[1], "conv3d_k3_wino2d")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<false, true>), configured[2], "conv3d_k3_wino2d")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<true, true>), configured[3], "conv3d_k3_wino2d")) return rc;
+    const int ntz = D / W2_TS, nty = H / W2_TS, ntx = W / W2_TS;
 #define W2_LAUNCH(B_, A_)                                                                                                       \
   hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<B_, A_>), grid, dim3(64 * W2_NW), (size_t)W2_LDS_FLOATS * 4, (hipStream_t)stream, x, \
                      wp, bias, y, stats, N, D, H, W, Cin, Cout, ntz, nty, ntx, ncog, nitems, addend)
-  if (bias) {
-    if (addend) W2_LAUNCH(true, true); else W2_LAUNCH(true, false);
-  } else {
-    if (addend) W2_LAUNCH(false, true); else W2_LAUNCH(false, false);
-  }
+    if (bias) {
+      if (addend) W2_LAUNCH(true, true); else W2_LAUNCH(true, false);
+    } else {
+      if (addend) W2_LAUNCH(false, true); else W2_LAUNCH(false, false);
+    }
 #undef W2_LAUNCH
+  } else {
+    static Seg3dOncePerDevice configured[4];
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<false, false>), configured[0], "conv3d_k3_wino2d_c4")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<true, false>), configured[1], "conv3d_k3_wino2d_c4")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<false, true>), configured[2], "conv3d_k3_wino2d_c4")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<true, true>), configured[3], "conv3d_k3_wino2d_c4")) return rc;
+    const int ncz = D / 4, ncy = H / 4, ncx = W / 4, ncells = N * ncz * ncy * ncx;
+#define W2_LAUNCH(B_, A_)                                                                                                          \
+  hipLaunchKernelGGL((conv3d_k3_wino2d_c4_kernel<B_, A_>), grid, dim3(64 * W2_NW), (size_t)C4_LDS_FLOATS * 4, (hipStream_t)stream, x, \
+                     wp, bias, y, stats, N, D, H, W, Cin, Cout, ncz, ncy, ncx, ncells, ncog, nitems, addend)
+    if (bias) {
+      if (addend) W2_LAUNCH(true, true); else W2_LAUNCH(true, false);
+    } else {
+      if (addend) W2_LAUNCH(false, true); else W2_LAUNCH(false, false);
+    }
+#undef W2_LAUNCH
+  }
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_fwd");
   return SEG3D_OK;
 }

@@ -148,7 +148,10 @@ def test_conv3d_k3_bench_variants_full_size(hip_device, shape, variant, form, mo
 
 
 @pytest.mark.parametrize('shape', [(1, 8, 32, 16, 24, 32), (2, 32, 32, 8, 16, 48), (1, 64, 96, 16, 16, 16), (3, 16, 64, 8, 8, 64),
-                                   (1, 128, 128, 8, 16, 16)])
+                                   (1, 128, 128, 8, 16, 16),
+                                   # whole 4^3 cells but not 8^3 tiles: the cell form of the F(2x2, 3x3) kernel (wino2d only) --
+                                   # the 12^3 level, a last item with three of four cells, cells of one item in two samples
+                                   (2, 16, 64, 12, 12, 12), (1, 8, 32, 4, 4, 12), (3, 24, 32, 4, 12, 8), (1, 64, 64, 12, 12, 20)])
 @pytest.mark.parametrize('flip', [0, 1])
 @pytest.mark.parametrize('form', ['wino', 'wino2d'])
 def test_conv3d_k3_winograd(hip_device, shape, flip, form):
@@ -159,8 +162,11 @@ def test_conv3d_k3_winograd(hip_device, shape, flip, form):
     from segmentation3d import _ops, _engine as E
     N, Cin, Cout, D, H, W = shape
     T = 36 if form == 'wino' else 48
+    cells = bool(D % 8 or H % 8 or W % 8)
+    if cells and form == 'wino':
+        pytest.skip('F(2, 3) along x takes whole 8^3 tiles only')
     assert E.query('seg3d_conv3d_k3_{}_supported'.format(form), N, D, H, W, Cin, Cout) == 1
-    assert E.query('seg3d_conv3d_k3_{}_supported'.format(form), N, D, H, W + 4, Cin, Cout) == 0       # not whole tiles
+    assert E.query('seg3d_conv3d_k3_{}_supported'.format(form), N, D, H, W + (4 if form == 'wino' else 2), Cin, Cout) == 0   # not whole tiles / cells
     assert E.query('seg3d_conv3d_k3_{}_supported'.format(form), N, D, H, W, Cin + 4, Cout) == 0
     assert E.query('seg3d_conv3d_k3_{}_preferred'.format(form), 1, 8, 8, 8, Cin, Cout) == 0           # too few items: split-K kernel
     x = _t(31, 'wx', (N, Cin, D, H, W))
@@ -199,6 +205,16 @@ def test_conv3d_k3_winograd(hip_device, shape, flip, form):
     y2 = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
     E.call('seg3d_conv3d_k3_{}_fwd'.format(form), E.ptr(xn), E.ptr(wp), None, None, E.ptr(y2), None, N, D, H, W, Cin, Cout, E.stream_ptr())
     assert float((y2 + bd + an - y).abs().max()) < 2e-6 * scale
+    # bias only / addend only (the other two instantiations), and run to run bitwise the same
+    y3 = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
+    E.call('seg3d_conv3d_k3_{}_fwd'.format(form), E.ptr(xn), E.ptr(wp), E.ptr(bd), None, E.ptr(y3), None, N, D, H, W, Cin, Cout, E.stream_ptr())
+    assert float((y3 + an - y).abs().max()) < 2e-6 * scale
+    y4 = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
+    E.call('seg3d_conv3d_k3_{}_fwd'.format(form), E.ptr(xn), E.ptr(wp), None, E.ptr(an), E.ptr(y4), None, N, D, H, W, Cin, Cout, E.stream_ptr())
+    assert float((y4 + bd - y).abs().max()) < 2e-6 * scale
+    y5 = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
+    E.call('seg3d_conv3d_k3_{}_fwd'.format(form), E.ptr(xn), E.ptr(wp), E.ptr(bd), E.ptr(an), E.ptr(y5), None, N, D, H, W, Cin, Cout, E.stream_ptr())
+    assert torch.equal(y5, y)
 
 
 @pytest.mark.parametrize('shape', [(1, 32, 32, 8, 8, 16), (2, 16, 48, 4, 8, 8), (1, 64, 32, 12, 12, 12), (3, 8, 40, 8, 4, 24),

@@ -118,7 +118,7 @@ class KernelTimer(object):
             a.record()
             rc = timer._orig(name, *args)
             b.record()
-            ma = (WINO2D_VARIANT if '2d' in name else WINO_VARIANT) if wino else E.query(
+            ma = ((WINO2D_CELL_VARIANT if (D % 8 or H % 8 or W % 8) else WINO2D_VARIANT) if '2d' in name else WINO_VARIANT) if wino else E.query(
                 'seg3d_conv3d_k3_bf16_variant' if 'bf16' in name else 'seg3d_conv3d_k3_mfma_variant', N, D, H, W, Cin, Cout)
             timer.records.append(((N, D, H, W, Cin, Cout, ma), a, b, 2 if 'bf16' in name else 4))
             return rc
@@ -163,6 +163,7 @@ WINO_VARIANT = 500   # the Winograd F(2,3) kernel (csrc/conv_wino.hip) in the va
 WINO_EXECUTED = 2.0 / 3.0   # it executes 4 multiplies per 2 outputs x 3 taps: 2/3 of the algorithmic FLOPs
 WINO2D_VARIANT = 600   # the Winograd F(2x2,3x3) kernel (csrc/conv_wino2d.hip)
 WINO2D_EXECUTED = 4.0 / 9.0   # 16 multiplies per 4 outputs x 9 (ky, kx) taps
+WINO2D_CELL_VARIANT = 601   # the same on 4^3 cells (conv3d_k3_wino2d_c4_kernel: levels that are multiples of 4 but not of 8)
 # weight-gradient entry points of the 3x3x3 C -> C layers: (kernel symbol, executed share of the algorithmic FLOPs)
 WGRAD_ENTRY_POINTS = {'seg3d_conv3d_k3_wino2d_wgrad': ('conv3d_k3_wgrad_wino2d_kernel', WINO2D_EXECUTED),   # F(3x3, 2x2)
                       'seg3d_conv3d_k3_wino_wgrad': ('conv3d_k3_wgrad_wino_kernel', WINO_EXECUTED),          # F(3, 2)
@@ -171,7 +172,7 @@ WGRAD_ENTRY_POINTS = {'seg3d_conv3d_k3_wino2d_wgrad': ('conv3d_k3_wgrad_wino2d_k
 
 
 def executed_share(variant):
-    return WINO_EXECUTED if variant == WINO_VARIANT else WINO2D_EXECUTED if variant == WINO2D_VARIANT else 1.0
+    return WINO_EXECUTED if variant == WINO_VARIANT else WINO2D_EXECUTED if variant in (WINO2D_VARIANT, WINO2D_CELL_VARIANT) else 1.0
 
 
 def variant_kernel_name(v):
@@ -180,6 +181,8 @@ def variant_kernel_name(v):
         return 'conv3d_k3_wino_kernel'
     if v == WINO2D_VARIANT:
         return 'conv3d_k3_wino2d_kernel'
+    if v == WINO2D_CELL_VARIANT:
+        return 'conv3d_k3_wino2d_c4_kernel'
     if v >= 400:
         return 'conv3d_k3_mfma2w8_bf16_kernel<{}, {}, true>'.format((v - 400) // 10, v % 10)
     if v >= 300:   # two waves per SIMD, MA row blocks per wave

@@ -21,6 +21,8 @@ for r in shapes:
     N, D, H, W, Ci, Co, v = r['N_D_H_W_Cin_Cout_variant']
     if v == 600:     # Winograd F(2x2,3x3): TFLOP/s below are ALGORITHMIC (the matrix cores execute 4/9 of them)
         name = 'conv3d_k3_wino2d_kernel'
+    elif v == 601:   # the same on 4^3 cells
+        name = 'conv3d_k3_wino2d_c4_kernel'
     elif v == 500:   # Winograd F(2,3): algorithmic as well (2/3 executed)
         name = 'conv3d_k3_wino_kernel'
     elif v >= 400:

@@ -124,6 +124,23 @@ __device__ __forceinline__ void w2_steps(F&& f, std::integer_sequence<int, I...>
   (f(std::integral_constant<int, I>{}), ...);
 }
 
+// the lane's four bias values bias[ub + 4 kq .. + 3] from the wave's 16 (ub is wave-uniform), each made a SCALAR by
+// readfirstlane right after its load.  A plain per-lane vector load puts its vmcnt wait in front of the first MFMA that reads
+// the accumulator -- step 3 of EVERY chunk of the one loop body, where it also waits for the chunk's own LDS-DMAs (cell kernel,
+// 12^3 256 -> 256: 0.176 ms with, 0.160 without) -- and hipcc turns a select among uniformly addressed loads back into exactly
+// that load; values already in SGPRs cannot be folded.  (An inline-assembly s_load_dwordx16 faulted: nothing makes the hazard
+// recogniser wait between the v_readfirstlane that forms its base and the scalar load.)
+__device__ __forceinline__ f32x4 w2_bias_quad(const float* __restrict__ bias, int ub, int kq) {
+  ub = __builtin_amdgcn_readfirstlane(ub);
+  float bs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bs[r] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bias[ub + r])));
+  f32x4 b4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b4[r] = kq == 0 ? bs[r] : (kq == 1 ? bs[4 + r] : (kq == 2 ? bs[8 + r] : bs[12 + r]));
+  return b4;
+}
+
 template <bool BIAS, bool ADD>
 __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                       const float* __restrict__ bias, float* __restrict__ y,
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
   };
   auto acc_init_rest = [&](int co) __attribute__((always_inline)) {
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (BIAS) b4 = *reinterpret_cast<const f32x4*>(bias + co);
+    if (BIAS) b4 = w2_bias_quad(bias, co - 4 * kq, kq);
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       if (p == 0 || p == 3 || p == 12 || p == 15) continue;
@@ -645,7 +662,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
   };
   auto acc_init = [&](int vq, int co) __attribute__((always_inline)) {
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (BIAS) b4 = *reinterpret_cast<const f32x4*>(bias + co);
+    if (BIAS) b4 = w2_bias_quad(bias, co - 4 * kq, kq);
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       if (ADD && (p == 0 || p == 3 || p == 12 || p == 15)) {

@@ -471,12 +471,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
 // ================================================================================================================
 #define C4_H 6                                    // halo edge of a cell
 #define C4_NV (C4_H * C4_H * C4_H)                // 216 halo voxels (256 slots = four 1-KiB pieces per cell)
-#define C4_PSTR (4 * 24 * 4)                      // floats between two points of T: [cell 4][z 6][quad 4][4]
-#define C4_T (16 * C4_PSTR)                       // 6144 floats
-#define C4_LDS_FLOATS (2 * W2_RAW + 2 * C4_T + 2 * W2_W)   // 32 + 48 + 48 KB
+#define C4_T (16 * 4 * 24 * 4)                    // floats of T at four cells per item: [16 p][cell][z 6][quad 4][4] = 6144
+#define C4_LDS_FLOATS (2 * W2_RAW + 2 * C4_T + 2 * W2_W)   // 32 + 48 + 48 KB (the same carve-up for two cells per item)
 
-template <bool BIAS, bool ADD>
-__global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+// NC = cells per item: 4 (eight waves) where that gives enough items, else 2 (four waves, one per SIMD: half the MFMAs per chunk
+// again, but twice the items -- 4 x 12^3 128 -> 128 is 108 items of four cells, 216 of two)
+template <bool BIAS, bool ADD, int NC>
+__global__ __launch_bounds__(128 * NC, 1) void conv3d_k3_wino2d_c4_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                                       float* __restrict__ stats, int N, int D, int H, int W, int Cin,
                                                                       int Cout, int ncz, int ncy, int ncx, int ncells, int ncog,
@@ -488,7 +489,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 3, hh = wave >> 2;        // cell of the item, output-channel half
+  constexpr int NWV = 2 * NC;                     // waves: cell x output-channel half
+  constexpr int WPW = 24 / NWV;                   // weight pieces per wave; raw pieces per wave: 4 NC / NWV = 2 = W2_XPW
+  constexpr int PSTR = NC * 24 * 4;               // floats between two points of T
+  const int wc = wave % NC, hh = wave / NC;       // cell of the item, output-channel half
   const int l16 = lane & 15, kq = lane >> 4;      // MFMA column (z = l16 >> 2, quad = l16 & 3) and K index
   const int NSC = Cin >> 2;
   const int AB = Cin >> 3;
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
   int hpos[W2_XPW];
 #pragma unroll
   for (int j = 0; j < W2_XPW; ++j) {
-    const int e = ((wave + W2_NW * j) & 3) * 64 + lane;
+    const int e = ((wave + NWV * j) & 3) * 64 + lane;
     hpos[j] = -1;
     if (e < C4_NV) {
       const int t = e / C4_H;
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
     }
   }
   const int abase = (16 * hh + l16) * 4 + kq;                 // weights [t][co][4]: + t * 128
-  const int bbase = (wc * 24 + l16) * 4 + kq;                 // T [p][cell][z][quad][4]: + p * C4_PSTR + kz * 16
+  const int bbase = (wc * 24 + l16) * 4 + kq;                 // T [p][cell][z][quad][4]: + p * PSTR + kz * 16
   // transform task of this lane: 192 (cell, z, quad, channel pair) tasks, 24 per wave (lanes >= 24 repeat task 23 of their wave)
   const int t_task = wave * 24 + (lane < 24 ? lane : 23);
   const int t_cell = t_task / 48, t_rem = t_task - 48 * t_cell;
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
 #pragma unroll
     for (int j = 0; j < W2_XPW; ++j) {
       int n, z0, y0, x0, cis;
-      cell_origin(4 * grp + ((wave + W2_NW * j) >> 2), n, z0, y0, x0, cis);
+      cell_origin(NC * grp + ((wave + NWV * j) >> 2), n, z0, y0, x0, cis);
       xsrc[j] = w2_zero16;
       const int hp = hpos[j];
       const int gz = z0 + ((hp >> 20) & 1023) - 1, gy = y0 + ((hp >> 10) & 1023) - 1, gx = x0 + (hp & 1023) - 1;
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
     }
   };
   auto dma_x = [&](int j, float* rdst) {
-    w2_glds16(xsrc[j], rdst + (wave + W2_NW * j) * 256);
+    w2_glds16(xsrc[j], rdst + (wave + NWV * j) * 256);
     xsrc[j] += ((xadv >> j) & 1) * 4;
   };
   int fw_item = item, fw_sc = 0;
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
   };
   const unsigned w_lane_off = ((lane >> 5) * 256 + (lane & 31) * 4) * 4;
   auto dma_w = [&](int j, const float* wsrc, float* wdst) {
-    const int piece = wave + W2_NW * j;
+    const int piece = wave + NWV * j;
     w2_glds16_sbase(wsrc + 2 * piece * 256, w_lane_off, wdst + piece * 256);
   };
   // RAW -> T (signs of column px = 3 / row py = 3 as in the tile kernel)
@@ -616,11 +620,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
     dxp[r][3] = w2_pk_sub(d[3], d[1]);
   };
   auto tr_y = [&](float* tdst, int px) {
-    float* dst = tdst + t_dst + px * C4_PSTR;
-    *reinterpret_cast<f32x2*>(dst + 0 * 4 * C4_PSTR) = w2_pk_sub(dxp[0][px], dxp[2][px]);
-    *reinterpret_cast<f32x2*>(dst + 1 * 4 * C4_PSTR) = w2_pk_add(dxp[1][px], dxp[2][px]);
-    *reinterpret_cast<f32x2*>(dst + 2 * 4 * C4_PSTR) = w2_pk_sub(dxp[2][px], dxp[1][px]);
-    *reinterpret_cast<f32x2*>(dst + 3 * 4 * C4_PSTR) = w2_pk_sub(dxp[3][px], dxp[1][px]);
+    float* dst = tdst + t_dst + px * PSTR;
+    *reinterpret_cast<f32x2*>(dst + 0 * 4 * PSTR) = w2_pk_sub(dxp[0][px], dxp[2][px]);
+    *reinterpret_cast<f32x2*>(dst + 1 * 4 * PSTR) = w2_pk_add(dxp[1][px], dxp[2][px]);
+    *reinterpret_cast<f32x2*>(dst + 2 * 4 * PSTR) = w2_pk_sub(dxp[2][px], dxp[1][px]);
+    *reinterpret_cast<f32x2*>(dst + 3 * 4 * PSTR) = w2_pk_sub(dxp[3][px], dxp[1][px]);
   };
 
   fx_setup(item);
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
     fx_advance();
     const float* w0 = fw_src();
 #pragma unroll
-    for (int j = 0; j < W2_WPW; ++j) dma_w(j, w0, wbuf);
+    for (int j = 0; j < WPW; ++j) dma_w(j, w0, wbuf);
     fw_advance();
 #pragma unroll
     for (int j = 0; j < W2_XPW; ++j) dma_x(j, raw + W2_RAW);
@@ -654,8 +658,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
     int cog;
     const int grp = group_of(it, cog);
     int n, z0, y0, x0, cis;
-    cell_origin(4 * grp + wc, n, z0, y0, x0, cis);
-    valid = 4 * grp + wc < ncells;
+    cell_origin(NC * grp + wc, n, z0, y0, x0, cis);
+    valid = NC * grp + wc < ncells;
     vq = ((n * D + z0 + (l16 >> 2)) * H + y0 + 2 * ((l16 >> 1) & 1)) * W + x0 + 2 * (l16 & 1);
     co = cog * 32 + 16 * hh + 4 * kq;
     slot = ((n * cps + cis) * ncog + cog) * 2 + hh;
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
       float* rdst2 = raw + ci_ * W2_RAW;
       const float* wsrc1 = fw_src();
       auto lda = [&](int s1) { return ws[(w2_kz(s1) * 16 + w2_pt(s1)) * 128 + abase]; };
-      auto ldb = [&](int s1) { return tcur[w2_pt(s1) * C4_PSTR + w2_kz(s1) * 16 + bbase]; };
+      auto ldb = [&](int s1) { return tcur[w2_pt(s1) * PSTR + w2_kz(s1) * 16 + bbase]; };
       float av[48], bv[48];
 #pragma unroll
       for (int st = 0; st < W2_PF; ++st) av[st] = lda(st), bv[st] = ldb(st);
@@ -700,8 +704,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
             constexpr int st = decltype(st_c)::value;
             constexpr int pt = w2_pt(st);
             if (st + W2_PF < 48) av[(st + W2_PF) % 48] = lda(st + W2_PF), bv[(st + W2_PF) % 48] = ldb(st + W2_PF);
-            if (st < W2_WPW) dma_w(st, wsrc1, wdst1);
-            else if (st - W2_WPW < W2_XPW) dma_x(st - W2_WPW, rdst2);
+            if (st < WPW) dma_w(st, wsrc1, wdst1);
+            else if (st - WPW < W2_XPW) dma_x(st - WPW, rdst2);
             if (st >= W2_TR0 && st <= W2_TR0 + 6 && ((st - W2_TR0) & 1) == 0) tr_read(rsrc1, (st - W2_TR0) >> 1);
             if (st >= W2_TR0 + 3 && st <= W2_TR0 + 9 && ((st - W2_TR0) & 1) == 1) tr_x((st - W2_TR0 - 3) >> 1);
             if (st >= W2_TR0 + 12 && st <= W2_TR0 + 21 && (st - W2_TR0 - 12) % 3 == 0) tr_y(tdst1, (st - W2_TR0 - 12) / 3);
@@ -770,9 +774,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_c4_kernel(const float
 // channel blocks of 8 / 32
 static bool w2_tiles(int D, int H, int W) { return !(D % W2_TS) && !(H % W2_TS) && !(W % W2_TS); }
 static bool w2_cells(int D, int H, int W) { return !(D % 4) && !(H % 4) && !(W % 4); }
-static long long w2_items(int N, int D, int H, int W, int Cout) {   // (tile | group of four cells, column block) items
+// cells per item of the cell kernel: four where that makes at least 192 items, else two
+static int w2_cells_per_item(int N, int D, int H, int W, int Cout) {
+  return (((long long)N * (D / 4) * (H / 4) * (W / 4) + 3) / 4) * (Cout / 32) >= 192 ? 4 : 2;
+}
+static long long w2_items(int N, int D, int H, int W, int Cout) {   // (tile | group of cells, column block) items
   if (w2_tiles(D, H, W)) return (long long)N * (D / W2_TS) * (H / W2_TS) * (W / W2_TS) * (Cout / 32);
-  return (((long long)N * (D / 4) * (H / 4) * (W / 4) + 3) / 4) * (Cout / 32);
+  const int nc = w2_cells_per_item(N, D, H, W, Cout);
+  return (((long long)N * (D / 4) * (H / 4) * (W / 4) + nc - 1) / nc) * (Cout / 32);
 }
 
 extern "C" int seg3d_conv3d_k3_wino2d_supported(int N, int D, int H, int W, int Cin, int Cout) {
@@ -823,19 +832,32 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
     }
 #undef W2_LAUNCH
   } else {
-    static Seg3dOncePerDevice configured[4];
-    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<false, false>), configured[0], "conv3d_k3_wino2d_c4")) return rc;
-    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<true, false>), configured[1], "conv3d_k3_wino2d_c4")) return rc;
-    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<false, true>), configured[2], "conv3d_k3_wino2d_c4")) return rc;
-    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<true, true>), configured[3], "conv3d_k3_wino2d_c4")) return rc;
+    static Seg3dOncePerDevice configured[8];
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<false, false, 4>), configured[0], "conv3d_k3_wino2d_c4")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<true, false, 4>), configured[1], "conv3d_k3_wino2d_c4")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<false, true, 4>), configured[2], "conv3d_k3_wino2d_c4")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<true, true, 4>), configured[3], "conv3d_k3_wino2d_c4")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<false, false, 2>), configured[4], "conv3d_k3_wino2d_c4")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<true, false, 2>), configured[5], "conv3d_k3_wino2d_c4")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<false, true, 2>), configured[6], "conv3d_k3_wino2d_c4")) return rc;
+    if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<true, true, 2>), configured[7], "conv3d_k3_wino2d_c4")) return rc;
     const int ncz = D / 4, ncy = H / 4, ncx = W / 4, ncells = N * ncz * ncy * ncx;
-#define W2_LAUNCH(B_, A_)                                                                                                          \
-  hipLaunchKernelGGL((conv3d_k3_wino2d_c4_kernel<B_, A_>), grid, dim3(64 * W2_NW), (size_t)C4_LDS_FLOATS * 4, (hipStream_t)stream, x, \
-                     wp, bias, y, stats, N, D, H, W, Cin, Cout, ncz, ncy, ncx, ncells, ncog, nitems, addend)
-    if (bias) {
-      if (addend) W2_LAUNCH(true, true); else W2_LAUNCH(true, false);
+    const int nc = w2_cells_per_item(N, D, H, W, Cout);
+#define W2_LAUNCH(B_, A_, NC_)                                                                                                       \
+  hipLaunchKernelGGL((conv3d_k3_wino2d_c4_kernel<B_, A_, NC_>), grid, dim3(128 * NC_), (size_t)C4_LDS_FLOATS * 4, (hipStream_t)stream, \
+                     x, wp, bias, y, stats, N, D, H, W, Cin, Cout, ncz, ncy, ncx, ncells, ncog, nitems, addend)
+    if (nc == 4) {
+      if (bias) {
+        if (addend) W2_LAUNCH(true, true, 4); else W2_LAUNCH(true, false, 4);
+      } else {
+        if (addend) W2_LAUNCH(false, true, 4); else W2_LAUNCH(false, false, 4);
+      }
     } else {
-      if (addend) W2_LAUNCH(false, true); else W2_LAUNCH(false, false);
+      if (bias) {
+        if (addend) W2_LAUNCH(true, true, 2); else W2_LAUNCH(true, false, 2);
+      } else {
+        if (addend) W2_LAUNCH(false, true, 2); else W2_LAUNCH(false, false, 2);
+      }
     }
 #undef W2_LAUNCH
   }

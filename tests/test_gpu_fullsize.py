@@ -114,8 +114,9 @@ def test_headline_train_step_4x96_vnet_1_2(hip_device, monkeypatch):
     assert all(v < 2e-2 for k, v in e.items() if k.startswith('g')), e
     assert e['adam_update_off_fraction'] < 1e-2, e
     # the kernels the bench line is quoted on ran: 96^3 / 48^3 / 24^3 levels on 8^3 tiles, forward (9) + data-gradient (9), and
-    # the three 256-channel units of the 12^3 level (up_256.rblock) on 4^3 cells, forward (3) + data-gradient (3)
-    assert c[WINO_FWD] == 24, c
+    # the six units of the 12^3 level (down_128.rblock: two cells per item, up_256.rblock: four) on 4^3 cells, forward (6) +
+    # data-gradient (6)
+    assert c[WINO_FWD] == 30, c
     assert c[WINO_WGRADS[0]] + c[WINO_WGRADS[1]] >= 12 and c[WINO_WGRADS[0]] >= 9, c
     assert c['seg3d_adam_step'] == 1, c
 

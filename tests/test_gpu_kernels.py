@@ -151,7 +151,9 @@ def test_conv3d_k3_bench_variants_full_size(hip_device, shape, variant, form, mo
                                    (1, 128, 128, 8, 16, 16),
                                    # whole 4^3 cells but not 8^3 tiles: the cell form of the F(2x2, 3x3) kernel (wino2d only) --
                                    # the 12^3 level, a last item with three of four cells, cells of one item in two samples
-                                   (2, 16, 64, 12, 12, 12), (1, 8, 32, 4, 4, 12), (3, 24, 32, 4, 12, 8), (1, 64, 64, 12, 12, 20)])
+                                   # (two cells per item below 192 items; the 256-channel case has 216 items of four cells)
+                                   (2, 16, 64, 12, 12, 12), (1, 8, 32, 4, 4, 12), (3, 24, 32, 4, 12, 8), (1, 64, 64, 12, 12, 20),
+                                   (4, 8, 256, 12, 12, 12)])
 @pytest.mark.parametrize('flip', [0, 1])
 @pytest.mark.parametrize('form', ['wino', 'wino2d'])
 def test_conv3d_k3_winograd(hip_device, shape, flip, form):

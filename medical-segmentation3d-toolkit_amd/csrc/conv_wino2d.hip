@@ -28,6 +28,8 @@
 //     [t][half][32 co][4] -- a 4-channel K chunk is one half;
 //   * bias and fused addend enter through the accumulators at item start, the epilogue contains no load (see the kernel);
 //   * LDS: 2 x 16 KB RAW + 2 x 40 KB T + 2 x 24 KB weights = 160 KB, all of it.
+// Levels that are whole 4 x 4 x 4 cells but not 8 x 8 x 8 tiles (the 12^3 level) run the same algorithm on CELLS
+// (conv3d_k3_wino2d_c4_kernel, further down): a cell's 4 z planes x 2 x 2 quads are the 16 columns of one MFMA group.
 // Rounds 2 and early 3 ran this with FOUR waves (one per SIMD, 32 quads x 32 channels on v_mfma_f32_32x32x2_f32, 256
 // accumulator registers): the eight-wave form issues the same instructions per SIMD in the K loop (that loop is bound by what
 // it issues: 96 MFMAs + ~100 vector / LDS-write / DMA instructions on the one fp32 pipe) but halves the

@@ -879,7 +879,8 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
 // Structure = conv3d_k3_wgrad_wino_kernel: one persistent workgroup per CU owns a 32 x 32 (ci, co) block pair and one slab
 // of 4 x 4 x 4 tiles; wave w owns the point row py = w: 12 accumulators [kz][px] in registers across all tiles; the next
 // tile's RAW x halo tile (6^3 voxels) and dy tile arrive by (inline-assembly) LDS-DMA behind the first K steps, branch-free;
-// between two tiles 192 threads transform RAW x into T[p][z][quad][32 ci] (two barriers per tile); E is formed from the raw
+// between two tiles all 256 threads transform the NEW planes of RAW x into T[p][plane slot][quad][32 ci] (a ring of six plane slots
+// along z: a workgroup walks its tiles z fastest, planes 4, 5 of a tile are planes 0, 1 of the next; two barriers per tile); E is formed from the raw
 // dy quad in registers (4 FMAs / adds per 12 MFMAs).  Partial slabs [slab][pair][48][32][32] are reduced in fixed order,
 // and turned into the 27 taps, by conv3d_k3_wgrad_wino2d_reduce16_kernel (bitwise reproducible).
 // A tile is only 96 MFMAs per wave (2.6 us): too short to cover a DMA issued in the same tile, so tiles are fetched TWO
@@ -954,19 +955,25 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
     }
   }
   int tn = 0, tz0 = 0, ty0 = 0, tx0 = 0;  // origin of the tile being fetched
+  // tiles are numbered z FASTEST and a workgroup walks a contiguous range of them: consecutive tiles are neighbours in z (until
+  // the column ends), and two of the six T planes of a tile are the last two of its predecessor (see the plane ring below)
   auto set_tile = [&](int tile) {
     int b = tile;
-    int q = fdiv(b, rNTX);
+    int q = fdiv(b, rNTZ);
+    const int tiz = b - q * ntz;
+    b = q;
+    q = fdiv(b, rNTX);
     const int tix = b - q * ntx;
     b = q;
     q = fdiv(b, rNTY);
     const int tiy = b - q * nty;
-    b = q;
-    q = fdiv(b, rNTZ);
-    const int tiz = b - q * ntz;
     tn = q;
     tz0 = tiz * 4, ty0 = tiy * 4, tx0 = tix * 4;
   };
+  auto tiz_of = [&](int tile) { return __builtin_amdgcn_readfirstlane(tile - fdiv(tile, rNTZ) * ntz); };
+  // T plane RING: halo plane k (0..5) of the tile at z index tiz lives in slot (4 tiz + k) % 6 of T[p][slot][quad][32 ci]; planes
+  // 4, 5 of a tile are planes 0, 1 of the next tile of the column and are not transformed again
+  auto slot_of = [](int tiz, int k) { return (4 * tiz + k) % 6; };
   auto issue_piece = [&](int g, float* xdst, float* ydst, const float* xbase, const float* ybase, int faces) {
     const float* base = g < G2_GX ? xbase : ybase;            // compile-time choice (g is an unrolled loop index)
     float* dst;
@@ -975,39 +982,40 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
     const float* src = (pflag[g] & faces) ? w2_zero16 : base + prel[g];
     w2_glds16(src, dst);
   };
-  // transform item of this thread (tid < 192): (z, quad, channel quad)
-  const int t_c4 = tid & 7, t_q = (tid >> 3) & 3, t_z = tid >> 5;
-  const int t_src = ((t_z * 6 + 2 * (t_q >> 1)) * 6 + 2 * (t_q & 1)) * 32 + 4 * t_c4;
-  const int t_dst = (t_z * 4 + t_q) * 32 + 4 * t_c4;
-  auto transform = [&](const float* rx) {   // RAW x -> T: V = B^T d B per (z, quad), 16 points; packed fp32 adds
-    if (tid < 192) {
-      f32x2 dxl[4][4], dxh[4][4];   // [row][px], channel pairs (0, 1) and (2, 3)
+  // RAW x -> T: V = B^T d B per (plane, quad), 16 points, as HALF tasks (plane, quad, channel pair): 256 of them for the four new
+  // planes of a tile that continues a column -- exactly one per thread, 32 packed adds -- and 384 for the six planes of a tile
+  // that starts one (threads 0 .. 127 take a second task).  (Rounds 2-3: 192 four-channel tasks of 64 packed adds on three of
+  // the four waves, all six planes for every tile.)
+  auto transform_task = [&](const float* rx, int t, int kbase, int tiz) {
+    const int kpl = __builtin_amdgcn_readfirstlane(kbase + (t >> 6));       // halo plane (wave-uniform)
+    const int t_q = (t >> 4) & 3, t_c2 = t & 15;
+    const float* src = rx + ((kpl * 6 + 2 * (t_q >> 1)) * 6 + 2 * (t_q & 1)) * 32 + 2 * t_c2;
+    float* dst = timg + (slot_of(tiz, kpl) * 4 + t_q) * 32 + 2 * t_c2;
+    f32x2 dx[4][4];   // [row][px]
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* s = rx + t_src + r * (6 * 32);
-        const f32x4 d0 = *reinterpret_cast<const f32x4*>(s);
-        const f32x4 d1 = *reinterpret_cast<const f32x4*>(s + 32);
-        const f32x4 d2 = *reinterpret_cast<const f32x4*>(s + 64);
-        const f32x4 d3 = *reinterpret_cast<const f32x4*>(s + 96);
-        const f32x2 d0l = {d0[0], d0[1]}, d0h = {d0[2], d0[3]}, d1l = {d1[0], d1[1]}, d1h = {d1[2], d1[3]};
-        const f32x2 d2l = {d2[0], d2[1]}, d2h = {d2[2], d2[3]}, d3l = {d3[0], d3[1]}, d3h = {d3[2], d3[3]};
-        dxl[r][0] = w2_pk_sub(d0l, d2l), dxh[r][0] = w2_pk_sub(d0h, d2h);
-        dxl[r][1] = w2_pk_add(d1l, d2l), dxh[r][1] = w2_pk_add(d1h, d2h);
-        dxl[r][2] = w2_pk_sub(d2l, d1l), dxh[r][2] = w2_pk_sub(d2h, d1h);
-        dxl[r][3] = w2_pk_sub(d1l, d3l), dxh[r][3] = w2_pk_sub(d1h, d3h);
-      }
-      float* dst = timg + t_dst;
+    for (int r = 0; r < 4; ++r) {
+      const float* sp = src + r * (6 * 32);
+      const f32x2 d0 = *reinterpret_cast<const f32x2*>(sp), d1 = *reinterpret_cast<const f32x2*>(sp + 32);
+      const f32x2 d2 = *reinterpret_cast<const f32x2*>(sp + 64), d3 = *reinterpret_cast<const f32x2*>(sp + 96);
+      dx[r][0] = w2_pk_sub(d0, d2);
+      dx[r][1] = w2_pk_add(d1, d2);
+      dx[r][2] = w2_pk_sub(d2, d1);
+      dx[r][3] = w2_pk_sub(d1, d3);
+    }
 #pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        const f32x2 v0l = w2_pk_sub(dxl[0][px], dxl[2][px]), v0h = w2_pk_sub(dxh[0][px], dxh[2][px]);
-        const f32x2 v1l = w2_pk_add(dxl[1][px], dxl[2][px]), v1h = w2_pk_add(dxh[1][px], dxh[2][px]);
-        const f32x2 v2l = w2_pk_sub(dxl[2][px], dxl[1][px]), v2h = w2_pk_sub(dxh[2][px], dxh[1][px]);
-        const f32x2 v3l = w2_pk_sub(dxl[1][px], dxl[3][px]), v3h = w2_pk_sub(dxh[1][px], dxh[3][px]);
-        *reinterpret_cast<f32x4*>(dst + (0 * 4 + px) * (24 * 32)) = f32x4{v0l[0], v0l[1], v0h[0], v0h[1]};
-        *reinterpret_cast<f32x4*>(dst + (1 * 4 + px) * (24 * 32)) = f32x4{v1l[0], v1l[1], v1h[0], v1h[1]};
-        *reinterpret_cast<f32x4*>(dst + (2 * 4 + px) * (24 * 32)) = f32x4{v2l[0], v2l[1], v2h[0], v2h[1]};
-        *reinterpret_cast<f32x4*>(dst + (3 * 4 + px) * (24 * 32)) = f32x4{v3l[0], v3l[1], v3h[0], v3h[1]};
-      }
+    for (int px = 0; px < 4; ++px) {
+      *reinterpret_cast<f32x2*>(dst + (0 * 4 + px) * (24 * 32)) = w2_pk_sub(dx[0][px], dx[2][px]);
+      *reinterpret_cast<f32x2*>(dst + (1 * 4 + px) * (24 * 32)) = w2_pk_add(dx[1][px], dx[2][px]);
+      *reinterpret_cast<f32x2*>(dst + (2 * 4 + px) * (24 * 32)) = w2_pk_sub(dx[2][px], dx[1][px]);
+      *reinterpret_cast<f32x2*>(dst + (3 * 4 + px) * (24 * 32)) = w2_pk_sub(dx[1][px], dx[3][px]);
+    }
+  };
+  auto transform = [&](const float* rx, int tiz, bool column_start) {
+    if (column_start) {   // wave-uniform
+      transform_task(rx, tid, 0, tiz);                    // planes 0 .. 3
+      if (tid < 128) transform_task(rx, tid, 4, tiz);     // planes 4, 5
+    } else {
+      transform_task(rx, tid, 2, tiz);                    // planes 2 .. 5; 0, 1 are the previous tile's 4, 5
     }
   };
   auto tile_faces = [&]() {
@@ -1015,14 +1023,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
            (tx0 == 0 ? 16 : 0) | (tx0 + 4 >= W ? 32 : 0);
   };
 
-  // tile walk: XCD-contiguous when the slab count allows (as the forward kernels)
-  int tile = slab, tstride = slabs, tlimit = ntiles;
-  if ((slabs & 7) == 0) {
-    const int per_xcd = (ntiles + 7) >> 3, xcd = slab & 7;
-    tile = xcd * per_xcd + (slab >> 3);
-    tstride = slabs >> 3;
-    tlimit = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
-  }
+  // tile walk: a contiguous range per workgroup (neighbouring ranges on one XCD when the slab count allows)
+  const int per_wg = (ntiles + slabs - 1) / slabs;
+  const int ord = (slabs & 7) == 0 ? (slab & 7) * (slabs >> 3) + (slab >> 3) : slab;
+  int tile = ord * per_wg;
+  const int tstride = 1;
+  const int tlimit = tile + per_wg < ntiles ? tile + per_wg : ntiles;
   auto fetch = [&](int t, float* xdst, float* ydst) {   // all pieces of tile t at once (prologue)
     set_tile(t);
     const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
@@ -1036,7 +1042,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
     fetch(tile + tstride < tlimit ? tile + tstride : tile, rawx + G2_XS, rawy + G2_YS);
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G2_NG) : "memory");   // the first tile landed, the second may be in flight
     __syncthreads();
-    transform(rawx);
+    transform(rawx, tiz_of(tile), true);
     __syncthreads();
   }
   for (; tile < tlimit; tile += tstride) {
@@ -1052,13 +1058,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
     const float* xbase = x + origin * Cin;
     const float* ybase = dy + origin * Cout;
     // K step k: quads 2k (lane half 0) and 2k + 1 (half 1) = (z, qy) = (k >> 1, k & 1), qx = lane half
-    const float* ta = timg + (wave * 4) * (24 * 32) + lane;        // + (px * 24 + (z + kz) * 4 + 2 qy) * 32
+    const int tiz = tiz_of(tile);
+    const float* ta = timg + (wave * 4) * (24 * 32) + lane;        // + (px * 24 + slot(z + kz) * 4 + 2 qy) * 32
+    const float* tk[6];                                            // per halo plane: its ring slot
+#pragma unroll
+    for (int kp = 0; kp < 6; ++kp) tk[kp] = ta + slot_of(tiz, kp) * (4 * 32);
     const float* yb = ycur + lh * 64 + li;                         // + ((z * 4 + 2 qy) * 4) * 32; j: + 32, i: + 128
-    auto aoff = [](int k, int kz, int px) { return (px * 24 + ((k >> 1) + kz) * 4 + 2 * (k & 1)) * 32; };
+    auto lda = [&](int k, int kz, int px) { return tk[(k >> 1) + kz][(px * 24 + 2 * (k & 1)) * 32]; };
     auto yoff = [](int k) { return (((k >> 1) * 4 + 2 * (k & 1)) * 4) * 32; };
     float a1[12], g00, g01, g10, g11;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) a1[j] = ta[aoff(0, j >> 2, j & 3)];
+    for (int j = 0; j < 12; ++j) a1[j] = lda(0, j >> 2, j & 3);
     g00 = yb[yoff(0) + g0off];
     g01 = yb[yoff(0) + g0off + 32];
     g10 = yb[yoff(0) + 128];
@@ -1075,7 +1085,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
       e[3] = r1;
       if (k + 1 < G2_KS) {   // operands of step k + 1 are read while step k is multiplied
 #pragma unroll
-        for (int j = 0; j < 12; ++j) a1[j] = ta[aoff(k + 1, j >> 2, j & 3)];
+        for (int j = 0; j < 12; ++j) a1[j] = lda(k + 1, j >> 2, j & 3);
         g00 = yb[yoff(k + 1) + g0off];
         g01 = yb[yoff(k + 1) + g0off + 32];
         g10 = yb[yoff(k + 1) + 128];
@@ -1095,7 +1105,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
     yi = yi == 2 ? 0 : yi + 1;
     if (more) {
 #ifndef G2_EXP_NOTR    // (diagnostic builds: what do the exposed transform and its barrier cost?)
-      transform(rawx + xi * G2_XS);   // the next tile's RAW x -> T
+      {                               // the next tile's RAW x -> T
+        const int ntiz = tiz_of(tile + tstride);
+        transform(rawx + xi * G2_XS, ntiz, ntiz == 0);
+      }
 #endif
 #ifndef G2_EXP_NOBAR2
       __syncthreads();

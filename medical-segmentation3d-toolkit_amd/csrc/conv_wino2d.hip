@@ -957,20 +957,34 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
   int tn = 0, tz0 = 0, ty0 = 0, tx0 = 0;  // origin of the tile being fetched
   // tiles are numbered z FASTEST and a workgroup walks a contiguous range of them: consecutive tiles are neighbours in z (until
   // the column ends), and two of the six T planes of a tile are the last two of its predecessor (see the plane ring below)
-  auto set_tile = [&](int tile) {
+  // the walk is contiguous, so the coordinates of the current tile and of the two fetched ahead are carried as wave-uniform
+  // counters (z, x, y, n in tiles) and stepped with scalar instructions; only the first tile is decoded by division
+  struct TileAt { int z, x, y, n; };
+  auto tile_at = [&](int tile) {
     int b = tile;
     int q = fdiv(b, rNTZ);
-    const int tiz = b - q * ntz;
+    TileAt t;
+    t.z = __builtin_amdgcn_readfirstlane(b - q * ntz);
     b = q;
     q = fdiv(b, rNTX);
-    const int tix = b - q * ntx;
+    t.x = __builtin_amdgcn_readfirstlane(b - q * ntx);
     b = q;
     q = fdiv(b, rNTY);
-    const int tiy = b - q * nty;
-    tn = q;
-    tz0 = tiz * 4, ty0 = tiy * 4, tx0 = tix * 4;
+    t.y = __builtin_amdgcn_readfirstlane(b - q * nty);
+    t.n = __builtin_amdgcn_readfirstlane(q);
+    return t;
   };
-  auto tiz_of = [&](int tile) { return __builtin_amdgcn_readfirstlane(tile - fdiv(tile, rNTZ) * ntz); };
+  auto step = [&](TileAt t) {
+    if (++t.z == ntz) {
+      t.z = 0;
+      if (++t.x == ntx) {
+        t.x = 0;
+        if (++t.y == nty) t.y = 0, ++t.n;
+      }
+    }
+    return t;
+  };
+  auto use_tile = [&](const TileAt& t) { tn = t.n, tz0 = t.z * 4, ty0 = t.y * 4, tx0 = t.x * 4; };
   // T plane RING: halo plane k (0..5) of the tile at z index tiz lives in slot (4 tiz + k) % 6 of T[p][slot][quad][32 ci]; planes
   // 4, 5 of a tile are planes 0, 1 of the next tile of the column and are not transformed again
   auto slot_of = [](int tiz, int k) { return (4 * tiz + k) % 6; };
@@ -1029,20 +1043,23 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
   int tile = ord * per_wg;
   const int tstride = 1;
   const int tlimit = tile + per_wg < ntiles ? tile + per_wg : ntiles;
-  auto fetch = [&](int t, float* xdst, float* ydst) {   // all pieces of tile t at once (prologue)
-    set_tile(t);
+  auto fetch = [&](const TileAt& t, float* xdst, float* ydst) {   // all pieces of tile t at once (prologue)
+    use_tile(t);
     const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
     const int faces = tile_faces();
 #pragma unroll
     for (int g = 0; g < G2_NG; ++g) issue_piece(g, xdst, ydst, x + origin * Cin, dy + origin * Cout, faces);
   };
   int xi = 0, yi = 0;   // buffers of the current tile: RAW x (already transformed) xi, dy yi
+  TileAt cur = tile_at(tile < ntiles ? tile : 0), nx1 = cur, nx2 = cur;   // this tile, the next one, the one after
   if (tile < tlimit) {
-    fetch(tile, rawx, rawy);
-    fetch(tile + tstride < tlimit ? tile + tstride : tile, rawx + G2_XS, rawy + G2_YS);
+    nx1 = tile + 1 < tlimit ? step(cur) : cur;        // past the end of the range: this tile once more (idle buffers)
+    nx2 = tile + 2 < tlimit ? step(nx1) : cur;
+    fetch(cur, rawx, rawy);
+    fetch(nx1, rawx + G2_XS, rawy + G2_YS);
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G2_NG) : "memory");   // the first tile landed, the second may be in flight
     __syncthreads();
-    transform(rawx, tiz_of(tile), true);
+    transform(rawx, cur.z, true);
     __syncthreads();
   }
   for (; tile < tlimit; tile += tstride) {
@@ -1052,13 +1069,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
     float* xnxt2 = rawx + xi * G2_XS;                    // RAW x of the current tile is dead (transformed): reuse it
     const bool more = tile + tstride < tlimit;
     // the tile after next -- past the end: this tile once more, into idle buffers (keeps the loop and the DMA count uniform)
-    set_tile(tile + 2 * tstride < tlimit ? tile + 2 * tstride : tile);
+    use_tile(nx2);
     const int faces = tile_faces();
     const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
     const float* xbase = x + origin * Cin;
     const float* ybase = dy + origin * Cout;
     // K step k: quads 2k (lane half 0) and 2k + 1 (half 1) = (z, qy) = (k >> 1, k & 1), qx = lane half
-    const int tiz = tiz_of(tile);
+    const int tiz = cur.z;
     const float* ta = timg + (wave * 4) * (24 * 32) + lane;        // + (px * 24 + slot(z + kz) * 4 + 2 qy) * 32
     const float* tk[6];                                            // per halo plane: its ring slot
 #pragma unroll
@@ -1106,14 +1123,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
     if (more) {
 #ifndef G2_EXP_NOTR    // (diagnostic builds: what do the exposed transform and its barrier cost?)
       {                               // the next tile's RAW x -> T
-        const int ntiz = tiz_of(tile + tstride);
-        transform(rawx + xi * G2_XS, ntiz, ntiz == 0);
+        transform(rawx + xi * G2_XS, nx1.z, nx1.z == 0);
       }
 #endif
 #ifndef G2_EXP_NOBAR2
       __syncthreads();
 #endif
     }
+    cur = nx1;
+    nx1 = nx2;
+    nx2 = tile + 3 < tlimit ? step(nx2) : nx2;   // (tile + 3 = the tile two ahead of the NEXT iteration's tile)
   }
   w2_dma_wait();   // nothing in flight when the workgroup's LDS is released
 

@@ -1,5 +1,7 @@
 // diagnostic harness: compiles conv_wino2d.hip with in-kernel s_memtime stamps (W2_STAMPS) and prints where a wave of
-// conv3d_k3_wino2d_kernel spends its cycles per K chunk.  Not part of the product library.
+// conv3d_k3_wino2d_kernel (the 8^3-tile kernel; waves 0-3 and 4-7 share the SIMDs) spends its cycles per K chunk, also by the
+// chunk's position inside its item.  Without -DW2_STAMPS it is a plain launch timer of seg3d_conv3d_k3_wino2d_fwd for any shape the
+// entry takes (tiles or cells): argv = N D H W C [mode: 0 bias, 1 neither, 2 fused addend].  Not part of the product library.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DW2_STAMPS -I include -I medical-segmentation3d-toolkit_amd/csrc \
 //         tools/ubench/wino2d_stamp.hip medical-segmentation3d-toolkit_amd/csrc/seg3d_api.cpp -o tools/ubench/wino2d_stamp
 #ifndef W2_SRC   // -DW2_SRC='"/path/to/an/experimental/copy.hip"' builds the harness around a variant of the kernel file

@@ -121,8 +121,20 @@ __device__ __forceinline__ float seg3d_wino_u(float g0, float g1, float g2, int 
   return p == 0 ? g0 : p == 1 ? 0.5f * ((g0 + g2) + g1) : p == 2 ? 0.5f * ((g0 + g2) - g1) : g2;
 }
 // Winograd F(2x2, 3x3) over (y, x) (conv_wino2d.hip): T = 48 selects U = G g G^T per kz, t = kz * 16 + py * 4 + px;
-// g = the 27 taps of one (a, b) with stride 1 (flip: read back to front)
+// g = the 27 taps of one (a, b) with stride 1 (flip: read back to front).
+// The T = 48 image has its OWN order inside an (32 x 8) chunk (round 4): wp[bb][ab][h 2][g 12][r 4][j 32][s 4] =
+// U(a = ab*8 + h*4 + r, b = bb*32 + j, t = seg3d_w2_step_t(4 g + s)) -- one half h = the 24-KB LDS image of a 4-channel K
+// chunk of the forward kernels, in which a lane (output channel j, K index r) finds the A operands of the four consecutive
+// steps 4 g .. 4 g + 3 in one aligned 16-byte word (ds_read_b128, conflict-free: tools/lds_bank_sim.py).
 #define SEG3D_WINO2D_T 48
+__device__ __forceinline__ void seg3d_wino2d_decode(int i, int& h, int& r, int& j, int& t48) {   // i = offset inside a chunk's 12288 floats
+  const int s4 = i & 3, g = (i >> 9) % 12;
+  j = (i >> 2) & 31;
+  r = (i >> 7) & 3;
+  h = (i >> 9) / 12;
+  // (seg3d_w2_step_t is constexpr arithmetic on small integers: a handful of scalar instructions here)
+  t48 = seg3d_w2_step_t(4 * g + s4);
+}
 __device__ __forceinline__ float seg3d_wino2d_u(const float* g, int flip, int t48) {
   const int kz = t48 >> 4, py = (t48 >> 2) & 3, px = t48 & 3;
   float r[3];
@@ -149,6 +161,7 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict_
     rest /= T;
     int ab = (int)(rest % AB);
     int bb = (int)(rest / AB);
+    if (T == SEG3D_WINO2D_T) seg3d_wino2d_decode((int)(idx % (48 * 256)), h, r, j, t);
     int a = ab * 8 + h * 4 + r, b = bb * 32 + j;
     float v = 0.f;
     if (a < A && b < B) {
@@ -320,7 +333,8 @@ __device__ __forceinline__ void pack_mfma_chunk(const Seg3dPackJob& jb, int chun
   if constexpr (WINO != 0 && !BF) {
     const int nw = AW * 32 * WINO;
     for (int i = threadIdx.x; i < nw; i += 256) {
-      const int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, tw = i / (HW * 64);
+      int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, tw = i / (HW * 64);
+      if constexpr (WINO == SEG3D_WINO2D_T) seg3d_wino2d_decode(i, h, r, j, tw);
       const float* g = tile + ((HW * h + r) * 32 + j) * 27;
       if constexpr (WINO == SEG3D_WINO_T) {
         const int t9 = tw >> 2;

@@ -77,6 +77,18 @@ static inline int seg3d_ew_grid(i64 work_items, int block) {
 }
 
 #ifdef __HIPCC__
+// ---- K-chunk step order of the F(2x2, 3x3) forward kernels (conv_wino2d.hip), shared with the T = 48 weight pack (layout.hip),
+// whose image holds the A operands of four consecutive steps next to each other (one 16-byte LDS read per lane and four steps).
+// 48 (kz, point) steps: the 16 Winograd points in PAIRS (a, b), each pair's six steps in the order a0 b0 a1 b1 a2 b2 (digit = kz),
+// so that the operands of one point are read once and used for all three kz; the twelve ordinary points first, the four
+// corner points 0, 3, 12, 15 (whose accumulators may still be waiting for a fused addend) in the last two pairs.
+__host__ __device__ constexpr int seg3d_w2_point(int i) {   // i-th point of the order
+  return i < 12 ? i + 1 + (i >= 2) + (i >= 10) : ((i - 12) >> 1) * 12 + ((i - 12) & 1) * 3;
+}
+__host__ __device__ constexpr int seg3d_w2_step_pi(int s) { return 2 * (s / 6) + ((s % 6) & 1); }   // index into the point order
+__host__ __device__ constexpr int seg3d_w2_step_kz(int s) { return (s % 6) >> 1; }
+__host__ __device__ constexpr int seg3d_w2_step_t(int s) { return seg3d_w2_step_kz(s) * 16 + seg3d_w2_point(seg3d_w2_step_pi(s)); }   // t = kz * 16 + py * 4 + px
+
 // ---- wave64 / workgroup reductions -------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -51,6 +51,8 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--infer-volume', default='512,512,400', help='X,Y,Z of the synthetic inference volume')
     ap.add_argument('--infer-batch', type=int, default=16)
+    ap.add_argument('--infer-timeout', type=float, default=240.0,
+                    help='N > 1: seconds the sharded inference leg may take before the ranks give up (exit code 3)')
     ap.add_argument('--kernel-report', default='', help='write the per-shape kernel timing table to this json file')
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
                     help="fp32 = the headline metric (BASELINE configs 2-4); bf16 = BASELINE config 5's mode (bf16 "
@@ -241,10 +243,36 @@ def pmc_traffic_gb(kernel_name):
     return round(kb * 1024 / 1e9, 3)
 
 
+def host_cpu():
+    """(model name, physical core count) of the host from /proc/cpuinfo; (None, None) where it cannot be read"""
+    try:
+        model, cores = None, set()
+        phys = core = None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                k, _, v = line.partition(':')
+                k, v = k.strip(), v.strip()
+                if k == 'model name' and model is None:
+                    model = v
+                elif k == 'physical id':
+                    phys = v
+                elif k == 'core id':
+                    core = v
+                elif not k and phys is not None and core is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        return model, (len(cores) or None)
+    except OSError:
+        return None, None
+
+
 def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):
     """the CPU side of every number this file reports, on this box's host cores, with
     oracle/torch_ref.py + oracle/numpy_ref.py = the stock torch CPU ops and host loops the reference composes:
-      * train step (fwd + loss + bwd + torch.optim.Adam) at batch 1 (2 timed steps after a warm-up) and batch 4 (1 step);
+      * train step (fwd + loss + bwd + torch.optim.Adam) at batch 1 (3 timed steps after a warm-up) and
+        batch 4 (1 step);
       * forward only, batch 1 (2 timed);
       * BASELINE config 1: whole-volume sliding window over a synthetic 128^3 volume (96^3 boxes, stride 48 => 8 patches,
         adaptive normaliser, accumulate, divide, arg-max) with ONE forward per patch and with the reference's TWO.
@@ -261,7 +289,7 @@ def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):
     x, t = x4[:1].contiguous(), t4[:1].contiguous()
     kw = {'weights': [1.0 / ncls] * ncls} if loss_name == 'Dice' else {'class_num': ncls, 'alpha': None, 'gamma': 2}
     times = []
-    for i in range(3):
+    for i in range(4):
         t0 = time.time()
         torch_ref.train_step(sd, opt, x, t, net_name, loss_name, kw)
         times.append(time.time() - t0)
@@ -277,7 +305,9 @@ def time_cpu_baseline(net_name, cin, ncls, patch, loss_name):
             torch_ref.segmentation_net(x, sd_eval, net_name)
             fwd.append(time.time() - t0)
     fwd_steady = fwd[1:]
+    cpu_model, physical = host_cpu()
     out = {'value': round(1.0 / (sum(steady) / len(steady)), 4), 'unit': 'patches/s', 'cores': torch.get_num_threads(),
+           'cpu_model': cpu_model, 'physical_cores': physical, 'logical_cpus': os.cpu_count(),
            'batch4_patches_per_s': round(4.0 / step_b4, 4),
            'forward_only_patches_per_s': round(1.0 / (sum(fwd_steady) / len(fwd_steady)), 4),
            'kind': 'port',
@@ -701,9 +731,9 @@ def main():
         else:
             # N > 1: the train-step measurement above is complete, and the sharded inference leg -- whose point-to-point halo
             # exchange has only ever been rehearsed over gloo -- must not cost the line: it runs in a worker thread; an
-            # exception is reported in its place, and if the leg has not returned after SEG3D_BENCH_INFER_TIMEOUT seconds
-            # (default 240; every rank would be stuck in the same collective) rank 0 prints the line without it and every
-            # rank leaves the process without waiting for the stuck thread.
+            # exception is reported in its place, and if the leg has not returned after --infer-timeout seconds (default 240;
+            # every rank would be stuck in the same collective) rank 0 prints the line with infer.timed_out = true and every
+            # rank leaves the process with exit code 3 without waiting for the stuck thread: a hang is a finding, never rc 0.
             import threading
             box = {}
 
@@ -716,10 +746,11 @@ def main():
                     box['infer'] = {'error': repr(exc), 'n_gpus': world}
             th = threading.Thread(target=leg, daemon=True)
             th.start()
-            th.join(float(os.environ.get('SEG3D_BENCH_INFER_TIMEOUT', '240')))
+            th.join(args.infer_timeout)
             if th.is_alive():
                 infer_timed_out = True
-                infer = {'error': 'sharded inference leg did not return within the time limit', 'n_gpus': world}
+                infer = {'error': 'sharded inference leg did not return within {:.0f} s'.format(args.infer_timeout),
+                         'timed_out': True, 'n_gpus': world}
             else:
                 infer = box['infer']
         if world == 1 and args.in_channels == 1 and 'error' not in infer:
@@ -761,7 +792,10 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if infer_timed_out:
-        os._exit(0)      # a collective is stuck: no clean shutdown is possible (the line, if this is rank 0, is out)
+        sys.stdout.flush()
+        sys.stderr.write('bench.py: rank {}: the sharded inference leg is stuck in a collective; leaving with exit code 3\n'.format(rank))
+        sys.stderr.flush()
+        os._exit(3)      # no clean shutdown is possible with a stuck collective; the line (rank 0) is out, the launcher sees rc != 0
     if world > 1:
         dist.destroy_process_group()
 

@@ -1119,7 +1119,7 @@ static int launch_fwd2(const float* x, const float* wp, const float* bias, float
     const int ncog = (Cout + 31) / 32 / NB;
     const int nitems = N * ntz * nty * ntx * ncog * ks;
     const int cib = Cin / 16, cpk = (cib + ks - 1) / ks;
-    dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
+    dim3 grid(seg3d_persistent_grid(nitems), 1, 1);
     if (ks > 1)
       hipLaunchKernelGGL((conv3d_k3_mfma2_bf16_splitk_kernel<MA, NB>), grid, dim3(256), lds, s, x, wp, kpart, N, D, H, W,
                          Cin / 2, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, ks, cpk);
@@ -1137,7 +1137,7 @@ static int launch_fwd2(const float* x, const float* wp, const float* bias, float
   const int ncog = (Cout + 31) / 32 / NB;
   const int nitems = N * ntz * nty * ntx * ncog * ks;
   const int cib = Cin / 8, cpk = (cib + ks - 1) / ks;
-  dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);  // persistent: one workgroup per CU walks the items
+  dim3 grid(seg3d_persistent_grid(nitems), 1, 1);  // persistent: one workgroup per CU walks the items
   if (ks > 1)
     hipLaunchKernelGGL((conv3d_k3_mfma2_splitk_kernel<MA, NB>), grid, dim3(256), lds, s, x, wp, kpart, N, D, H, W, Cin,
                        Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, ks, cpk);
@@ -1156,7 +1156,7 @@ static int launch_fwd2_w8_bf16(const float* x, const float* wp, const float* bia
   if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_mfma2w8_bf16_kernel<MA, 1, OUT_BF>), configured, "conv3d_k3_mfma2w8_bf16")) return rc;
   const int ncog = (Cout + 31) / 32;
   const int nitems = N * ntz * nty * ntx * ncog;
-  dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
+  dim3 grid(seg3d_persistent_grid(nitems), 1, 1);
   hipLaunchKernelGGL((conv3d_k3_mfma2w8_bf16_kernel<MA, 1, OUT_BF>), grid, dim3(512), lds, s, x, wp, bias, y, stats, N, D, H,
                      W, Cin / 2, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, addend);
   return SEG3D_OK;
@@ -1171,7 +1171,7 @@ static int launch_fwd2_w8(const float* x, const float* wp, const float* bias, fl
   if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_mfma2w8_kernel<MA, 1>), configured, "conv3d_k3_mfma2w8")) return rc;
   const int ncog = (Cout + 31) / 32;
   const int nitems = N * ntz * nty * ntx * ncog;
-  dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
+  dim3 grid(seg3d_persistent_grid(nitems), 1, 1);
   hipLaunchKernelGGL((conv3d_k3_mfma2w8_kernel<MA, 1>), grid, dim3(512), lds, s, x, wp, bias, y, stats, N, D, H, W, Cin,
                      Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ncog, nitems, addend);
   return SEG3D_OK;

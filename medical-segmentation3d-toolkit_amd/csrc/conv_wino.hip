@@ -343,7 +343,7 @@ extern "C" int seg3d_conv3d_k3_wino_fwd(const float* x, const float* wp, const f
   if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino_kernel), configured, "conv3d_k3_wino")) return rc;
   const int ntz = D / WN_TZ, nty = H / WN_TY, ntx = W / WN_TX, ncog = Cout / 32;
   const int nitems = N * ntz * nty * ntx * ncog;
-  dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
+  dim3 grid(seg3d_persistent_grid(nitems), 1, 1);
   hipLaunchKernelGGL(conv3d_k3_wino_kernel, grid, dim3(512), (size_t)WN_LDS_FLOATS * 4, (hipStream_t)stream, x, wp, bias, y,
                      stats, N, D, H, W, Cin, Cout, ntz, nty, ntx, ncog, nitems, addend);
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino_fwd");

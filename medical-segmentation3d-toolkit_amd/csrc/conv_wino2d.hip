@@ -914,7 +914,7 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
                 "seg3d_conv3d_k3_wino2d_fwd: shape not supported (whole 4^3 cells, Cin %% 8 == 0, Cout %% 32 == 0)");
   const int ncog = Cout / 32;
   const int nitems = (int)w2_items(N, D, H, W, Cout);
-  dim3 grid((unsigned)(nitems < 256 ? nitems : 256), 1, 1);
+  dim3 grid(seg3d_persistent_grid(nitems), 1, 1);
   if (w2_tiles(D, H, W)) {
     static Seg3dOncePerDevice configured[4];
     if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<false, false>), configured[0], "conv3d_k3_wino2d")) return rc;

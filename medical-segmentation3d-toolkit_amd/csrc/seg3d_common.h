@@ -65,6 +65,24 @@ static inline int seg3d_allow_full_lds(const void* kernel, Seg3dOncePerDevice& o
   return SEG3D_OK;
 }
 
+// compute units of the current device (hipDeviceAttributeMultiprocessorCount, cached per device ordinal): the size of a
+// persistent "one workgroup per CU" grid.  Workspace and statistics-slot counts do NOT depend on it (they are pure functions of
+// the shape, see SEG3D_NUM_CUS); the kernels walk their items with a stride of gridDim.x, so any grid size is correct.
+static inline int seg3d_device_cus() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return SEG3D_NUM_CUS;
+  if (dev >= 0 && dev < 64 && cached[dev] > 0) return cached[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = SEG3D_NUM_CUS;
+  if (dev >= 0 && dev < 64) cached[dev] = n;
+  return n;
+}
+static inline unsigned seg3d_persistent_grid(long long nitems) {
+  const long long cus = seg3d_device_cus();
+  return (unsigned)(nitems < cus ? nitems : cus);
+}
+
 static inline int seg3d_cdiv(i64 a, i64 b) { return (int)((a + b - 1) / b); }
 static inline int seg3d_round_up(int a, int b) { return ((a + b - 1) / b) * b; }
 

@@ -74,8 +74,11 @@ def _is_bf16(t):
 # ------------------------------------------------------------------------------------------------------------------
 # layout helpers
 # ------------------------------------------------------------------------------------------------------------------
-def to_ndhwc(x):
-    """logical NCDHW tensor -> contiguous [N,D,H,W,C] fp32 tensor (zero-copy when the memory is already NDHWC)"""
+def to_ndhwc(x, allow_slice=False):
+    """logical NCDHW tensor -> contiguous [N,D,H,W,C] fp32 tensor (zero-copy when the memory is already NDHWC).
+    allow_slice: a channel slice of a wider NDHWC buffer (rows of C floats at a constant stride > C) is returned as the strided
+    view it is instead of being repacked.  Only callers whose kernels take a row stride may ask for it -- the stride-2 conv of
+    an inference forward and up_cat's skip; every other consumer passes E.ptr() to a kernel that assumes C-contiguous rows."""
     E.require_device(x)
     if x.dim() != 5:
         raise ValueError('expected a 5-D [N,C,D,H,W] tensor, got shape {}'.format(tuple(x.shape)))
@@ -90,8 +93,9 @@ def to_ndhwc(x):
         return xp
     if _is_channel_slice(xp):
         # a channel slice of a wider NDHWC buffer (inference: an encoder feature living in its half of a decoder's concatenated
-        # skip buffer, VNetBase.forward): the two consumers that can meet one -- the stride-2 conv and up_cat -- read it in place
-        return xp
+        # skip buffer, VNetBase.forward; training: the skip gradient UpCatFunction.backward hands back without a link): the two
+        # consumers that can meet one in place -- the stride-2 conv and up_cat -- ask for it, everyone else gets a packed copy
+        return xp if allow_slice else xp.contiguous()
     N, C, D, H, W = x.shape
     xc = x.contiguous()
     out = torch.empty((N, D, H, W, C), dtype=torch.float32, device=x.device)
@@ -933,11 +937,14 @@ class ConvGnActFunction(torch.autograd.Function):
     When x is the residual itself (single-conv block) the two gradients are fused without a link."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in=None, link_out=None, out_slot=None):
+    def forward(ctx, x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in=None, link_out=None, out_slot=None,
+                no_backward=False):
         E.require_device(x, weight, bias, gamma, beta, residual)
-        if out_slot is not None and torch.is_grad_enabled() and any(ctx.needs_input_grad):
-            raise RuntimeError('out_slot (output written into a slice of another buffer) is an inference-only path')
-        xn = to_ndhwc(x)
+        # (the inference-only guard of out_slot and `no_backward` come from conv_gn_act(): grad mode is always off inside
+        # Function.forward, and needs_input_grad is set for parameters under torch.no_grad() as well)
+        # a channel-slice input is read in place only by the stride-2 conv, and only when no backward will follow, whose
+        # weight-gradient kernel would read the saved slice as packed rows
+        xn = to_ndhwc(x, allow_slice=(kind == 'k2s2' and no_backward))
         w = weight.detach()
         cout = w.shape[1] if kind == 'convT' else w.shape[0]
         want16 = BF16_CONV_OUTPUT and _out_bf16(cout) and (_is_bf16(xn) or (kind == 'k3' and xn.shape[4] <= 8))
@@ -996,13 +1003,19 @@ class ConvGnActFunction(torch.autograd.Function):
             else:
                 dw = conv_wgrad(xn, dy, ctx.w_shape, ctx.kind)
         return (dx, dw, dbias if ctx.has_bias else None, dgamma, dbeta,
-                from_ndhwc(dres) if dres is not None else None, None, None, None, None, None, None)
+                from_ndhwc(dres) if dres is not None else None, None, None, None, None, None, None, None)
 
 
 def conv_gn_act(x, weight, bias, gamma, beta, residual=None, kind='k3', relu=True, eps=GN_EPS, link_in=None,
                 link_out=None, out_slot=None):
     """out_slot (inference only): [N,D,H,W,C] channel slice of a wider NDHWC buffer the unit's output is written into"""
-    return ConvGnActFunction.apply(x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in, link_out, out_slot)
+    no_backward = not (torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (x, weight, bias, gamma, beta, residual)))
+    if out_slot is not None and not no_backward:
+        raise RuntimeError('out_slot (output written into a slice of another buffer) is an inference-only path: '
+                           'call it under torch.no_grad()')
+    return ConvGnActFunction.apply(x, weight, bias, gamma, beta, residual, kind, relu, eps, link_in, link_out, out_slot,
+                                   no_backward)
 
 
 class UpCatFunction(torch.autograd.Function):
@@ -1017,7 +1030,7 @@ class UpCatFunction(torch.autograd.Function):
         E.require_device(x, weight, bias, gamma, beta, skip)
         ctx.link_out = link_out
         xn = to_ndhwc(x)
-        sn = to_ndhwc(skip)
+        sn = to_ndhwc(skip, allow_slice=True)   # (copied into the concatenated buffer, or checked against cat_buf, below)
         w = weight.detach()
         want16 = BF16_CONV_OUTPUT and _is_bf16(xn) and _is_bf16(sn) and _out_bf16(w.shape[1])
         yn, partial = conv_forward(xn, w, None if bias is None else bias.detach(), 'convT', want_stats=True, out_bf16=want16)

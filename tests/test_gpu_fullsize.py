@@ -1,9 +1,8 @@
 """Full-size parity gates: the BASELINE configurations at the sizes bench.py quotes, each whole network against
 oracle/torch_ref (the stock torch CPU operators the reference composes) with the C-ABI entry points that ran recorded
 and asserted -- so every number DESIGN.md quotes for the 4 x 96^3 step, vbnet and the 128^3 patch has a checker behind
-the kernel instantiations those sizes select.  Bar (north_star): probabilities and loss within 1e-4 in fp32; gradient
-norms to 2e-2 (whole-network gradients move by up to ~1e-3 when a ReLU input of magnitude 1e-6 lands on the other side
-of zero under another summation order, tests/test_gpu_parity.py); bf16 mode to its own stated tolerance
+the kernel instantiations those sizes select.  Bar (north_star): probabilities and loss within 1e-4 in fp32; gradients
+to about twice the worst error observed per test (GRAD_BAR below: 1e-3 for the headline step); bf16 mode to its own stated tolerance
 (tests/test_gpu_bf16.py: probabilities max 3e-2 / mean 3e-3, loss 3e-3)."""
 import importlib
 
@@ -15,6 +14,18 @@ from gpu_util import report, max_err, rel_err
 from oracle import detgen, torch_ref
 
 pytestmark = pytest.mark.gpu
+
+# Gradient bars: about TWICE the worst figure observed per test (per-tensor relative gradient error and the worst relative
+# difference of the per-tensor gradient norms; profiles/r0*_parity_report.txt).  Operator gradients agree to ~1e-6; whole-network
+# gradients are looser because one ReLU input of magnitude ~1e-6 can land on the other side of zero under another fp32 summation
+# order (traced layer by layer in round 1, tests/test_gpu_parity.py) -- the compressed vbnet bottlenecks and the 6^3 level of the
+# 128^3 network show it most.  A kernel that dropped a tap of one channel group moves these figures by > 1e-1.
+#                 observed (round 3 / round 4)
+GRAD_BAR = {'headline': 1.0e-3,      # 4.2e-4
+            'vbnet': 1.0e-2,         # 4.9e-3
+            'vnet44_128': 6.0e-3,    # 2.6e-3
+            'vnet15_dice': 3.0e-3,   # 1.5e-3
+            'vnet15_focal': 7.0e-3}  # 3.3e-3
 
 WINO_FWD = 'seg3d_conv3d_k3_wino2d_fwd'
 WINO_WGRADS = ('seg3d_conv3d_k3_wino2d_wgrad', 'seg3d_conv3d_k3_wino_wgrad')
@@ -111,7 +122,7 @@ def test_headline_train_step_4x96_vnet_1_2(hip_device, monkeypatch):
     c = spy.counts(WINO_FWD, *WINO_WGRADS, 'seg3d_conv3d_k3_mfma_fwd', 'seg3d_adam_step')
     report('headline_train_step_4x96', **e, **{k.replace('seg3d_conv3d_k3_', 'n_'): float(v) for k, v in c.items()})
     assert e['probs'] < 1e-4 and e['loss'] < 1e-4, e
-    assert all(v < 2e-2 for k, v in e.items() if k.startswith('g')), e
+    assert all(v < GRAD_BAR['headline'] for k, v in e.items() if k.startswith('g')), e
     assert e['adam_update_off_fraction'] < 1e-2, e
     # the kernels the bench line is quoted on ran: 96^3 / 48^3 / 24^3 levels on 8^3 tiles, forward (9) + data-gradient (9), and
     # the six units of the 12^3 level (down_128.rblock: two cells per item, up_256.rblock: four) on 4^3 cells, forward (6) +
@@ -152,7 +163,7 @@ def test_vbnet_one_patch_96(hip_device, plugin, monkeypatch):
     c = spy.counts(WINO_FWD, *WINO_WGRADS, 'seg3d_conv3d_k3_mfma_fwd', 'seg3d_conv3d_k3_mfma_wgrad')
     report('vbnet_1x96', **e, **{k.replace('seg3d_conv3d_k3_', 'n_'): float(v) for k, v in c.items()})
     assert e['probs'] < 1e-4 and e['loss'] < 1e-4, e
-    assert all(v < 2e-2 for k, v in e.items() if k.startswith('g')), e
+    assert all(v < GRAD_BAR['vbnet'] for k, v in e.items() if k.startswith('g')), e
     assert c[WINO_FWD] >= 2 and c[WINO_WGRADS[0]] + c[WINO_WGRADS[1]] >= 1, c
 
 
@@ -198,7 +209,7 @@ def test_vnet_4_4_one_patch_128_fp32_and_bf16(hip_device, monkeypatch):
     c32 = {n: calls32.count(n) for n in (WINO_FWD,) + WINO_WGRADS}
     report('vnet_4_4_1x128_fp32', **e, **{k.replace('seg3d_conv3d_k3_', 'n_'): float(v) for k, v in c32.items()})
     assert e['probs'] < 1e-4 and e['loss'] < 1e-4, e
-    assert all(v < 2e-2 for k, v in e.items() if k.startswith('g')), e
+    assert all(v < GRAD_BAR['vnet44_128'] for k, v in e.items() if k.startswith('g')), e
     assert c32[WINO_FWD] >= 6 and c32[WINO_WGRADS[0]] + c32[WINO_WGRADS[1]] >= 3, c32
     p16, l16, g16, calls16 = res['bf16']
     gcos = np.array([float((g16[k].double() * g32[k].double()).sum() /
@@ -251,5 +262,68 @@ def test_vnet_1_5_four_patches_96_focal_and_dice(hip_device, monkeypatch):
         c = spy.counts(WINO_FWD, *WINO_WGRADS)
         report('vnet_1_5_4x96_' + loss_name, **e, **{k.replace('seg3d_conv3d_k3_', 'n_'): float(v) for k, v in c.items()})
         assert e['probs'] < 1e-4 and e['loss'] < 1e-4, e
-        assert all(v < 2e-2 for k, v in e.items() if k.startswith('g')), e
+        assert all(v < GRAD_BAR['vnet15_' + loss_name] for k, v in e.items() if k.startswith('g')), e
         assert c[WINO_FWD] >= 18, c
+
+
+def test_config4_whole_volume_512x512x400_batch16_graph_two_streams(hip_device):
+    """BASELINE config 4 at FULL size, exactly as bench.py runs it: a 512 x 512 x 400 volume, 96^3 boxes at stride 48 = the 800
+    patches of tests/golden/partitions.json (the reference's own image_partition_by_fixed_size, utils/image_tools.py:163-218),
+    batches of 16 patches, ONE captured hipGraph (gather -> net -> scatter) replayed 49 times behind an eager first batch, the
+    forward split over two streams, then divide + arg-max (core/seg_infer.py:313-339).  The oracle cannot run 800 forwards in
+    a test, so the gate is made of the size-independent properties of the path plus one oracle forward:
+      1. `count` equals the outer product of the three 1-D overlap counts of the committed partition table, bit for bit
+         (overlaps 1 ... 27, every tail-clamped patch, every replay with the right control block: core/seg_infer.py:315-323);
+      2. the class probabilities sum to 1 within 1e-6 wherever count > 0 (a mean of softmax rows: seg_infer.py:325-327);
+      3. the returned int8 mask is the arg-max of the returned probabilities, bit for bit (seg_infer.py:336-339);
+      4. the corner block [0:48]^3 is covered by patch 0 alone (count == 1): it equals ONE oracle forward of patch 0
+         (adaptive normaliser on the patch ROI, seg_infer.py:221-234) to 1e-4 -- so the graph replays run the same network as
+         the parity tests, and the accumulate / divide of a count-1 voxel is the identity."""
+    from conftest import golden_json
+    from segmentation3d.network import vnet
+    from segmentation3d.core.seg_infer import sliding_window_inference, release_graph_pool
+    from oracle import numpy_ref
+    case = golden_json('partitions')['vol512x512x400_96_48']
+    X, Y, Z = case['size']
+    starts, box = case['starts'], (96, 96, 96)
+    assert len(starts) == 800 and all(e[i] - s[i] == 96 for s, e in zip(starts, case['ends']) for i in range(3))
+    net = vnet.SegmentationNet(1, 2)
+    sd = _load(net, 41)
+    net = net.to(hip_device).eval()
+    norm = {'type': 1, 'clip_sigma': 3}
+    vol_host = (torch.randn((Z, Y, X), generator=torch.Generator().manual_seed(7)) * 150.0 - 200.0).contiguous()
+    vol = vol_host.to(hip_device)
+    probs, mask, batcher = sliding_window_inference(net, vol, starts, box, 2, norm, batch_size=16, use_graph=True,
+                                                    two_streams=True)
+    torch.cuda.synchronize()
+    assert tuple(probs.shape) == (2, Z, Y, X) and tuple(mask.shape) == (Z, Y, X) and mask.dtype == torch.int8
+    # 1. overlap counts
+    cnt1d = []
+    for axis, n in ((0, X), (1, Y), (2, Z)):
+        c = np.zeros(n, dtype=np.float32)
+        for s0 in sorted(set(s[axis] for s in starts)):
+            c[s0:s0 + 96] += 1.0
+        cnt1d.append(torch.from_numpy(c).to(hip_device))
+    expect = cnt1d[2][:, None, None] * cnt1d[1][None, :, None] * cnt1d[0][None, None, :]
+    assert float(expect.max()) == 27.0 and float(expect.min()) == 1.0
+    count_exact = bool(torch.equal(batcher.count, expect))
+    # 2. rows of probabilities
+    row_err = float((probs.sum(0) - 1.0).abs().max())
+    # 3. mask == arg-max of the returned probabilities (ties -> the lower class, as numpy / the reference's running maximum)
+    am = (probs[1] > probs[0]).to(torch.int8)
+    mask_exact = bool(torch.equal(mask, am))
+    # 4. one oracle forward on the count == 1 corner
+    assert starts[0] == [0, 0, 0] and float(batcher.count[:48, :48, :48].max()) == 1.0
+    roi = vol_host[:96, :96, :96].numpy()
+    ref_sd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    with torch.no_grad():
+        ref = torch_ref.segmentation_net(torch.from_numpy(numpy_ref.adaptive_normalize(roi, 3))[None, None], ref_sd, 'vnet')[0]
+    corner_err = max_err(probs[:, :48, :48, :48].cpu(), ref[:, :48, :48, :48])
+    report('config4_full_size_512x512x400', patches=800.0, count_exact=float(count_exact), row_sum_err=row_err,
+           mask_is_argmax=float(mask_exact), corner_vs_oracle=corner_err, mask_nonzero=float(mask.ne(0).sum()))
+    del probs, mask, batcher, expect, am
+    release_graph_pool(hip_device)
+    assert count_exact, 'overlap counts differ from the outer product of the partition table 1-D counts'
+    assert row_err < 1e-6, row_err
+    assert mask_exact, 'mask is not the arg-max of the returned probabilities'
+    assert corner_err < 1e-4, corner_err

@@ -107,7 +107,8 @@ def test_conv3d_k3_bench_variants_full_size(hip_device, shape, variant, form, mo
         return orig_call(fn, *a)
     monkeypatch.setattr(E, 'call', spy)
     winograd = form != 'direct'
-    name = 'bench_variant_{}_{}_{}'.format(variant, form, '_'.join(map(str, shape)))
+    # (the direct kernel's variant code names the direct runs only; a Winograd run is labelled by its form)
+    name = 'bench_{}_{}'.format('direct{}'.format(variant) if form == 'direct' else form, '_'.join(map(str, shape)))
     torch.set_num_threads(max(torch.get_num_threads(), 16))
     x = _t(15, name + 'x', (N, C, D, H, W)).requires_grad_(True)
     w = _t(16, name + 'w', (C, C, 3, 3, 3), std=(2.0 / (C * 27)) ** 0.5).requires_grad_(True)
@@ -1231,3 +1232,66 @@ def test_winograd_kernels_random_shapes_against_direct_kernels(hip_device):
             worst[form + '_wgrad'] = max(worst.get(form + '_wgrad', 0.0), e)
             assert e < 2e-5, (form + '_wgrad', case, (N, D, H, W, Cin, Cout), e)
     report('winograd_random_shapes_vs_direct', **worst)
+
+
+def test_channel_slice_inputs_equal_their_packed_copies(hip_device):
+    """A logical NCDHW tensor that is a CHANNEL SLICE of a wider NDHWC buffer (what UpCatFunction.backward hands back as the skip
+    gradient when no link is set, what an inference forward keeps in a decoder's concatenated buffer) must give every operator the
+    same result as its packed copy: only the stride-2 conv of a no-grad forward and up_cat's skip read a slice in place
+    (_ops.to_ndhwc(allow_slice=True)), all others repack it.  Forward and gradients, bit for bit."""
+    from segmentation3d import _ops
+    N, D, H, W, Ca, Cb = 2, 8, 8, 16, 16, 32
+    wide = _t(71, 'slice/wide', (N, D, H, W, Ca + Cb)).to(hip_device)
+    sl = _ops.from_ndhwc(wide[..., Ca:])                     # [N, Cb, D, H, W], rows of Cb floats at stride Ca + Cb
+    packed = _ops.from_ndhwc(wide[..., Ca:].contiguous())
+    assert _ops._is_channel_slice(sl.permute(0, 2, 3, 4, 1)) and not sl.permute(0, 2, 3, 4, 1).is_contiguous()
+    assert _ops.to_ndhwc(sl).is_contiguous()                  # the default is a packed copy ...
+    assert not _ops.to_ndhwc(sl, allow_slice=True).is_contiguous()   # ... the in-place view only on request
+
+    def both(fn, params, pair=None):
+        outs = []
+        for src in (pair or (sl, packed)):
+            x = src.detach().requires_grad_(True)
+            ps = [p.detach().clone().requires_grad_(True) for p in params]
+            y = fn(x, *ps)
+            g = torch.autograd.grad(y, [x] + ps, torch.ones_like(y) * 0.5 + y.detach() * 0.25)
+            outs.append([y.detach()] + [t.contiguous() for t in g])
+        for a, b in zip(*outs):
+            assert a.shape == b.shape and torch.equal(a.contiguous(), b.contiguous())
+
+    w3 = _t(72, 'slice/w3', (Cb, Cb, 3, 3, 3), std=0.05).to(hip_device)
+    w2 = _t(73, 'slice/w2', (2 * Cb, Cb, 2, 2, 2), std=0.1).to(hip_device)
+    b3, b2 = _t(74, 'slice/b3', (Cb,)).to(hip_device), _t(75, 'slice/b2', (2 * Cb,)).to(hip_device)
+    g3, be3 = _t(76, 'slice/g', (Cb,)).to(hip_device), _t(77, 'slice/be', (Cb,)).to(hip_device)
+    g2, be2 = _t(78, 'slice/g2', (2 * Cb,)).to(hip_device), _t(79, 'slice/be2', (2 * Cb,)).to(hip_device)
+    other = _ops.from_ndhwc(_t(80, 'slice/other', (N, D, H, W, Ca)).to(hip_device))
+    both(lambda x, w, b: _ops.conv(x, w, b, 'k3'), [w3, b3])
+    both(lambda x, w, b: _ops.conv(x, w, b, 'k2s2'), [w2, b2])
+    both(lambda x, g, b: _ops.group_norm(x, g, b, relu=True), [g3, be3])
+    both(lambda x, w, b, g, be: _ops.conv_gn_act(x, w, b, g, be, kind='k3'), [w3, b3, g3, be3])
+    both(lambda x, w, b, g, be: _ops.conv_gn_act(x, w, b, g, be, kind='k2s2'), [w2, b2, g2, be2])   # training: the slice is repacked
+    both(lambda x, w, b, g, be: _ops.conv_gn_act(x, w, b, g, be, residual=x, kind='k3'), [w3, b3, g3, be3])
+    both(lambda x: _ops.cat_channels(other, x), [])
+    both(lambda x: _ops.cat_channels(x, other), [])
+    sl8 = _ops.from_ndhwc(wide[..., Ca:Ca + 8])              # (the softmax kernel takes up to 16 classes)
+    both(lambda x: _ops.softmax_channels(x), [], pair=(sl8, _ops.from_ndhwc(wide[..., Ca:Ca + 8].contiguous())))
+    with torch.no_grad():                                     # inference: the stride-2 conv reads the slice in place
+        a = _ops.conv_gn_act(sl, w2, b2, g2, be2, kind='k2s2')
+        b = _ops.conv_gn_act(packed, w2, b2, g2, be2, kind='k2s2')
+    assert torch.equal(a, b)
+
+
+def test_out_slot_is_refused_when_a_gradient_is_wanted(hip_device):
+    """out_slot writes a unit's output into a slice of another buffer and saves nothing a backward could use: inference only"""
+    from segmentation3d import _ops
+    N, D, H, W, C = 1, 4, 4, 8, 16
+    x = _ops.from_ndhwc(_t(81, 'slot/x', (N, D, H, W, C)).to(hip_device))
+    w = _t(82, 'slot/w', (C, C, 3, 3, 3), std=0.05).to(hip_device).requires_grad_(True)
+    b, g, be = (torch.zeros(C, device=hip_device), torch.ones(C, device=hip_device), torch.zeros(C, device=hip_device))
+    buf = torch.zeros((N, D, H, W, 2 * C), device=hip_device)
+    with pytest.raises(RuntimeError):
+        _ops.conv_gn_act(x, w, b, g, be, kind='k3', out_slot=buf[..., C:])
+    with torch.no_grad():
+        out = _ops.conv_gn_act(x, w, b, g, be, kind='k3', out_slot=buf[..., C:])
+        ref = _ops.conv_gn_act(x, w, b, g, be, kind='k3')
+    assert torch.equal(out, ref) and torch.equal(buf[..., C:], ref.permute(0, 2, 3, 4, 1))

@@ -22,7 +22,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/fp32_write -
 say "fp32 SQ counters"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/fp32_sq -o p -- python3 $R/bench.py $PM > $O/fp32_sq.log 2>&1
 say "fp32 LDS counters"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/fp32_lds -o p -- python3 $R/bench.py $PM > $O/fp32_lds.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/fp32_lds -o p -- python3 $R/bench.py $PM > $O/fp32_lds.log 2>&1
 say "inference, single stream, kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/infer -o k -- python3 $R/tools/bench_infer.py 512,512,400 16 --single-stream > $O/infer_prof.log 2>&1
 if [ "$WHAT" = "all" ]; then

@@ -221,9 +221,10 @@ def pmc_traffic_gb(kernel_name):
     passes).  gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE under-reports wide coalesced reads
     by 2x, WRITE_SIZE is exact.  Counters cannot be collected from inside bench.py; returns None when absent."""
     prof = os.path.join(REPO, 'profiles')
-    cands = (['r03_bf16_pmc_fetch_write_per_kernel.json', 'r02_bf16_pmc_fetch_write_per_kernel.json',
-              'r01_i_bf16_pmc_fetch_write_per_kernel.json'] if 'bf16' in kernel_name
-             else ['r03_pmc_fetch_write_per_kernel.json', 'r02_pmc_fetch_write_per_kernel.json', 'r01_pmc_fetch_write_per_kernel.json'])
+    cands = (['r04_bf16_pmc_fetch_write_per_kernel.json', 'r03_bf16_pmc_fetch_write_per_kernel.json',
+              'r02_bf16_pmc_fetch_write_per_kernel.json', 'r01_i_bf16_pmc_fetch_write_per_kernel.json'] if 'bf16' in kernel_name
+             else ['r04_pmc_fetch_write_per_kernel.json', 'r03_pmc_fetch_write_per_kernel.json', 'r02_pmc_fetch_write_per_kernel.json',
+                   'r01_pmc_fetch_write_per_kernel.json'])
     path = next((os.path.join(prof, c) for c in cands if os.path.isfile(os.path.join(prof, c))), None)
     if path is None:
         return None

@@ -100,6 +100,27 @@ __device__ __forceinline__ void w2_glds16_sbase_at(const float* base_wave_unifor
   const uint64_t sb = ((uint64_t)hi << 32) | lo;
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_byte_offset), "s"(sb), "s"(lds_byte_off_wave_uniform) : "memory", "m0");
 }
+// LDS-DMA through a BUFFER RESOURCE (base + num_records in four scalars): lane l's 16 bytes at byte offset voff_l land at
+// M0 + 16 l, and a lane whose offset is out of range -- past the end, or "negative" = wrapped -- leaves ZEROS (measured:
+// tools/ubench/buffer_lds_test.hip).  The weight-gradient kernel gets its z padding from that range check and its (y, x) padding
+// from a per-column offset table, so a piece costs ONE vector add where the pointer form needed and / compare / two selects / a
+// 64-bit add.  `pred` (wave-uniform) is tested by a scalar branch inside the block: a skipped piece costs no issue slot at all.
+typedef int w2_srd __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ w2_srd w2_make_srd(const void* base_wave_uniform, unsigned num_bytes) {
+  const uint64_t b = (uint64_t)(uintptr_t)base_wave_uniform;
+  w2_srd r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xffffu));   // stride 0: a raw buffer, range-checked by byte offset
+  r[2] = __builtin_amdgcn_readfirstlane((int)num_bytes);
+  r[3] = 0x00020000;                                                              // gfx9 family: DATA_FORMAT = 32 bit, untyped
+  return r;
+}
+__device__ __forceinline__ void w2_bufdma16_if(int pred_wave_uniform, unsigned voff, w2_srd srd, unsigned lds_byte_off_wave_uniform) {
+  pred_wave_uniform = __builtin_amdgcn_readfirstlane(pred_wave_uniform);
+  lds_byte_off_wave_uniform = __builtin_amdgcn_readfirstlane(lds_byte_off_wave_uniform);
+  asm volatile("s_cmp_lg_u32 %3, 0\n\ts_cbranch_scc0 1f\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds\n1:"
+               : : "v"(voff), "s"(srd), "s"(lds_byte_off_wave_uniform), "s"(pred_wave_uniform) : "memory", "m0", "scc");
+}
 __device__ __forceinline__ void w2_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // a - b on two packed floats in one instruction (hipcc selects v_pk_add_f32 for additions but two v_sub_f32 for this)
 __device__ __forceinline__ f32x2 w2_pk_add(f32x2 a, f32x2 b) {
@@ -304,12 +325,25 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
     w2_glds16_sbase_at(wsrc + piece * 256, w_lane_off, lds0 + (wdst_float_off + piece * 256) * 4);
   };
   // RAW -> T for one channel pair of one (z, quad) item: V = B^T d B, 16 points, packed over the pair
+#ifdef W2_EXP_GNPRO
+  const f32x2 gn_scale = {1.0f + 1e-3f * (float)(tid & 3), 1.0f}, gn_shift = {1e-3f * (float)(tid & 1), 0.f}, gn_zero = {-1e30f, -1e30f};
+#endif
   f32x2 rd[2][4];
   f32x2 dxp[4][4];   // [row][px]
   auto tr_read = [&](const float* rw, int r) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       rd[r & 1][k] = w2_lds_read_b64(rw + ((k & 1) ? t_srcO[r >> 1] : t_srcE[r >> 1]) + r * (W2_H * 4) + 4 * k);
+#ifdef W2_EXP_GNPRO   // pricing build: what a GroupNorm + ReLU prologue on the operand path would cost -- three
+                      // instructions per RAW element pair (scale / shift per channel and sample, ReLU); halo lanes are not kept at 0 here
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x2 v = w2_pk_fma(rd[r & 1][k], gn_scale, gn_shift);   // (gfx950 has no packed fp32 max: the ReLU is two instructions)
+      v[0] = fmaxf(v[0], gn_zero[0]);
+      v[1] = fmaxf(v[1], gn_zero[1]);
+      rd[r & 1][k] = v;
+    }
+#endif
   };
   auto tr_x = [&](int r) {
     const f32x2* d = rd[r & 1];
@@ -1029,9 +1063,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   // DMA pieces of this wave (as conv3d_k3_wgrad_wino_kernel): group g < GX is x piece min(wave + 4 g, XPC - 1), group
-  // GX + g' is dy piece min(wave + 4 g', YPC - 1); lane -> voxel 8 p + (lane >> 3), channels 4 (lane & 7)..+3
+  // GX + g' is dy piece min(wave + 4 g', YPC - 1); lane -> voxel 8 p + (lane >> 3), channels 4 (lane & 7)..+3.
+  // The pieces come through buffer resources of the SAMPLE (w2_bufdma16_if): pconst = the lane's byte offset relative to the
+  // tile origin (negative for halo voxels in front of it), OOB for channels past the tensor's; z padding = the range check
+  // (plane -1 wraps, plane D is past the end), (y, x) padding = pyx, the table below refreshed once per tile column.
   const int lv = lane >> 3, lq = lane & 7;
-  int prel[G2_NG], pflag[G2_NG];
+  const unsigned OOB = 0x80000000u;                    // stays out of range after any tile offset (sample bytes < 2^31)
+  unsigned pconst[G2_NG], pyx[G2_GX];
+  int pflag[G2_GX];
 #pragma unroll
   for (int g = 0; g < G2_NG; ++g) {
     if (g < G2_GX) {
@@ -1041,17 +1080,18 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
       const int hx = v - t * 6;
       const int hz = fdiv(t, 1.0f / 6.0f);
       const int hy = t - hz * 6;
-      prel[g] = (((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + ci0 + 4 * lq;
-      pflag[g] = (hz == 0 ? 1 : 0) | (hz == 5 ? 2 : 0) | (hy == 0 ? 4 : 0) | (hy == 5 ? 8 : 0) | (hx == 0 ? 16 : 0) |
-                 (hx == 5 ? 32 : 0) | (ci0 + 4 * lq < Cin ? 0 : 64);
+      pconst[g] = ci0 + 4 * lq < Cin ? (unsigned)(((((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + ci0 + 4 * lq) * 4) : OOB;
+      pflag[g] = (hy == 0 ? 4 : 0) | (hy == 5 ? 8 : 0) | (hx == 0 ? 16 : 0) | (hx == 5 ? 32 : 0);
+      pyx[g] = pconst[g];
     } else {
       const int p = wave + 4 * (g - G2_GX) < G2_YPC ? wave + 4 * (g - G2_GX) : G2_YPC - 1;
       const int v = p * 8 + lv;
       const int co = co0 + 4 * lq;
-      prel[g] = (((v >> 4) * H + ((v >> 2) & 3)) * W + (v & 3)) * Cout + co;
-      pflag[g] = co < Cout ? 0 : 64;
+      pconst[g] = co < Cout ? (unsigned)(((((v >> 4) * H + ((v >> 2) & 3)) * W + (v & 3)) * Cout + co) * 4) : OOB;
     }
   }
+  const unsigned xbytes = (unsigned)D * H * W * Cin * 4u, ybytes = (unsigned)D * H * W * Cout * 4u;   // one sample
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(w2_lds_float*)lds);
   int tn = 0, tz0 = 0, ty0 = 0, tx0 = 0;  // origin of the tile being fetched
   // tiles are numbered z FASTEST and a workgroup walks a contiguous range of them: consecutive tiles are neighbours in z (until
   // the column ends), and two of the six T planes of a tile are the last two of its predecessor (see the plane ring below)
@@ -1086,13 +1126,24 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
   // T plane RING: halo plane k (0..5) of the tile at z index tiz lives in slot (4 tiz + k) % 6 of T[p][slot][quad][32 ci]; planes
   // 4, 5 of a tile are planes 0, 1 of the next tile of the column and are not transformed again
   auto slot_of = [](int tiz, int k) { return (4 * tiz + k) % 6; };
-  auto issue_piece = [&](int g, float* xdst, float* ydst, const float* xbase, const float* ybase, int faces) {
-    const float* base = g < G2_GX ? xbase : ybase;            // compile-time choice (g is an unrolled loop index)
-    float* dst;
-    if (g < G2_GX) dst = xdst + (wave + 4 * g < G2_XPC ? wave + 4 * g : G2_XPC - 1) * 256;
-    else dst = ydst + (wave + 4 * (g - G2_GX) < G2_YPC ? wave + 4 * (g - G2_GX) : G2_YPC - 1) * 256;
-    const float* src = (pflag[g] & faces) ? w2_zero16 : base + prel[g];
-    w2_glds16(src, dst);
+  // (y, x) padding of the x pieces for the column of the tile being fetched: refreshed only when that tile starts a column
+  auto column_table = [&]() {
+    const int fyx = (ty0 == 0 ? 4 : 0) | (ty0 + 4 >= H ? 8 : 0) | (tx0 == 0 ? 16 : 0) | (tx0 + 4 >= W ? 32 : 0);
+#pragma unroll
+    for (int g = 0; g < G2_GX; ++g) pyx[g] = (pflag[g] & fyx) ? OOB : pconst[g];
+  };
+  // piece g of the tile at (tn, tz0, ty0, tx0) into the buffers at the float offsets xdst / ydst of the carve-up.  A tile that
+  // CONTINUES a column needs no halo planes 0, 1 (they are planes 4, 5 of its predecessor, already in the T ring): its x pieces
+  // 0 .. 8 (= voxels 0 .. 71 = those two planes) are not fetched at all
+  auto issue_piece = [&](int g, unsigned xdst, unsigned ydst, w2_srd xsrd, w2_srd ysrd, unsigned xoff, unsigned yoff, int column_start) {
+    if (g < G2_GX) {
+      const int piece = wave + 4 * g < G2_XPC ? wave + 4 * g : G2_XPC - 1;
+      const int pred = (4 * g + 3 < 9) ? column_start : ((4 * g < 9) ? (column_start | (piece >= 9)) : 1);   // compile-time for g >= 3
+      w2_bufdma16_if(pred, pyx[g] + xoff, xsrd, lds0 + (xdst + piece * 256) * 4);
+    } else {
+      const int piece = wave + 4 * (g - G2_GX) < G2_YPC ? wave + 4 * (g - G2_GX) : G2_YPC - 1;
+      w2_bufdma16_if(1, pconst[g] + yoff, ysrd, lds0 + (ydst + piece * 256) * 4);
+    }
   };
   // RAW x -> T: V = B^T d B per (plane, quad), 16 points, as HALF tasks (plane, quad, channel pair): 256 of them for the four new
   // planes of a tile that continues a column -- exactly one per thread, 32 packed adds -- and 384 for the six planes of a tile
@@ -1130,10 +1181,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
       transform_task(rx, tid, 2, tiz);                    // planes 2 .. 5; 0, 1 are the previous tile's 4, 5
     }
   };
-  auto tile_faces = [&]() {
-    return 64 | (tz0 == 0 ? 1 : 0) | (tz0 + 4 >= D ? 2 : 0) | (ty0 == 0 ? 4 : 0) | (ty0 + 4 >= H ? 8 : 0) |
-           (tx0 == 0 ? 16 : 0) | (tx0 + 4 >= W ? 32 : 0);
-  };
 
   // tile walk: a contiguous range per workgroup (neighbouring ranges on one XCD when the slab count allows)
   const int per_wg = (ntiles + slabs - 1) / slabs;
@@ -1141,20 +1188,21 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
   int tile = ord * per_wg;
   const int tstride = 1;
   const int tlimit = tile + per_wg < ntiles ? tile + per_wg : ntiles;
-  auto fetch = [&](const TileAt& t, float* xdst, float* ydst) {   // all pieces of tile t at once (prologue)
+  auto fetch = [&](const TileAt& t, unsigned xdst, unsigned ydst) {   // all pieces of tile t at once (prologue)
     use_tile(t);
-    const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
-    const int faces = tile_faces();
+    column_table();
+    const unsigned origin = (unsigned)((tz0 * H + ty0) * W + tx0);   // voxels inside the sample
+    const w2_srd xsrd = w2_make_srd(x + (i64)tn * D * H * W * Cin, xbytes), ysrd = w2_make_srd(dy + (i64)tn * D * H * W * Cout, ybytes);
 #pragma unroll
-    for (int g = 0; g < G2_NG; ++g) issue_piece(g, xdst, ydst, x + origin * Cin, dy + origin * Cout, faces);
+    for (int g = 0; g < G2_NG; ++g) issue_piece(g, xdst, ydst, xsrd, ysrd, origin * Cin * 4u, origin * Cout * 4u, 1);
   };
   int xi = 0, yi = 0;   // buffers of the current tile: RAW x (already transformed) xi, dy yi
   TileAt cur = tile_at(tile < ntiles ? tile : 0), nx1 = cur, nx2 = cur;   // this tile, the next one, the one after
   if (tile < tlimit) {
     nx1 = tile + 1 < tlimit ? step(cur) : cur;        // past the end of the range: this tile once more (idle buffers)
     nx2 = tile + 2 < tlimit ? step(nx1) : cur;
-    fetch(cur, rawx, rawy);
-    fetch(nx1, rawx + G2_XS, rawy + G2_YS);
+    fetch(cur, 0, 2 * G2_XS + G2_TS);
+    fetch(nx1, G2_XS, 2 * G2_XS + G2_TS + G2_YS);
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G2_NG) : "memory");   // the first tile landed, the second may be in flight
     __syncthreads();
     transform(rawx, cur.z, true);
@@ -1163,15 +1211,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
   for (; tile < tlimit; tile += tstride) {
     const float* ycur = rawy + yi * G2_YS;
     const int y2 = yi == 0 ? 2 : yi - 1;                 // (yi + 2) % 3
-    float* ynxt2 = rawy + y2 * G2_YS;                    // dy buffer of the tile after next
-    float* xnxt2 = rawx + xi * G2_XS;                    // RAW x of the current tile is dead (transformed): reuse it
+    const unsigned ynxt2 = 2 * G2_XS + G2_TS + y2 * G2_YS;   // dy buffer of the tile after next (float offset in the carve-up)
+    const unsigned xnxt2 = xi * G2_XS;                       // RAW x of the current tile is dead (transformed): reuse it
     const bool more = tile + tstride < tlimit;
-    // the tile after next -- past the end: this tile once more, into idle buffers (keeps the loop and the DMA count uniform)
+    // the tile after next -- past the end: this tile once more, into idle buffers (keeps the loop uniform)
     use_tile(nx2);
-    const int faces = tile_faces();
-    const i64 origin = ((i64)(tn * D + tz0) * H + ty0) * W + tx0;
-    const float* xbase = x + origin * Cin;
-    const float* ybase = dy + origin * Cout;
+    const int f_start = nx2.z == 0;                          // it starts a column: new (y, x) padding, all six halo planes
+    if (f_start) column_table();
+    const unsigned origin = (unsigned)((tz0 * H + ty0) * W + tx0);
+    const w2_srd xsrd = w2_make_srd(x + (i64)tn * D * H * W * Cin, xbytes), ysrd = w2_make_srd(dy + (i64)tn * D * H * W * Cout, ybytes);
+    const unsigned fxoff = origin * Cin * 4u, fyoff = origin * Cout * 4u;
     // K step k: quads 2k (lane half 0) and 2k + 1 (half 1) = (z, qy) = (k >> 1, k & 1), qx = lane half
     const int tiz = cur.z;
     const float* ta = timg + (wave * 4) * (24 * 32) + lane;        // + (px * 24 + slot(z + kz) * 4 + 2 qy) * 32
@@ -1208,13 +1257,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
       }
 #pragma unroll
       for (int g = 0; g < G2_NG; ++g)
-        if (g % G2_KS == k) issue_piece(g, xnxt2, ynxt2, xbase, ybase, faces);
+        if (g % G2_KS == k) issue_piece(g, xnxt2, ynxt2, xsrd, ysrd, fxoff, fyoff, f_start);
       __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from sinking the reads above down to their first use
 #pragma unroll
       for (int j = 0; j < 12; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], e[j & 3], acc[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G2_NG) : "memory");   // the NEXT tile landed (fetched one tile ago)
+    // the NEXT tile landed (fetched one tile ago): all but the pieces of the latest fetch -- at least G2_NG - 3 of them (a tile
+    // that continues a column skips two or three x pieces per wave) -- so the wait asks for that many outstanding at most
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G2_NG - 3) : "memory");
     __syncthreads();     // everyone done with T
     xi ^= 1;
     yi = yi == 2 ? 0 : yi + 1;
@@ -1340,6 +1391,7 @@ extern "C" int seg3d_conv3d_k3_wino2d_wgrad_supported(int N, int D, int H, int W
   if ((D % 4) || (H % 4) || (W % 4) || (Cin & 3) || (Cout & 3)) return 0;
   if ((long long)N * D * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;
   if ((long long)N * (D / 4) * (H / 4) * (W / 4) >= SEG3D_FDIV_MAX) return 0;
+  if ((long long)D * H * W * (Cin > Cout ? Cin : Cout) * 4 >= (1ll << 31)) return 0;   // one SAMPLE per buffer resource: 32-bit byte offsets
   return 1;
 }
 

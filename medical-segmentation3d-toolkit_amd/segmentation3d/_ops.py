@@ -808,8 +808,9 @@ def gn_backward(doutn, outn, yn, mean_rstd, gamma, beta, relu, want_dres, want_d
 # backward (the bucketed all-reduce, core/ddp.py) call wgrad_stream_join() themselves.
 WGRAD_SIDE_STREAM = True      # False (bench.py --no-wgrad-overlap, profiling): weight gradients on the main stream
 _SIDE_STREAMS = {}
+_SIDE_STREAMS_UNPROBED = {}   # device index -> provisional stream handed out during a capture (never memoised as the choice)
 SIDE_KEEPALIVE = True     # inputs of side-stream weight gradients are held until the join (False: Tensor.record_stream)
-_SIDE_KEEP = {}           # device index -> [(x, dy)] of the weight gradients issued since the last join
+_SIDE_KEEP = {}           # device index -> [(x, dy, launching stream)] of the weight gradients issued since the last join
 _JOIN_QUEUED_FOR = [-1]   # id of the backward pass (graph task) whose end-of-backward join is already queued
 
 
@@ -849,16 +850,41 @@ def _side_stream(device):
     st = _SIDE_STREAMS.get(device.index)
     if st is None:
         with torch.cuda.device(device):
+            if torch.cuda.is_current_stream_capturing():
+                # no probe inside a capture (it synchronises): hand out a provisional stream and do NOT remember it as the
+                # choice -- the next eager use probes (TrainStep / GradientReducer call prepare_side_stream() in their
+                # constructors, so a capture normally finds the probed stream already)
+                st = _SIDE_STREAMS_UNPROBED.get(device.index)
+                if st is None:
+                    st = _SIDE_STREAMS_UNPROBED[device.index] = torch.cuda.Stream(device=device)
+                return st
             main = torch.cuda.current_stream()
-            cands = [torch.cuda.Stream(device=device) for _ in range(6)]
-            st = cands[0]
-            if not torch.cuda.is_current_stream_capturing():
-                for cand in cands:
-                    if _runs_beside(cand, main):
-                        st = cand
-                        break
+            first = _SIDE_STREAMS_UNPROBED.pop(device.index, None)
+            for i in range(6):                     # candidates are created one at a time, only as long as the probe fails
+                cand = first if (i == 0 and first is not None) else torch.cuda.Stream(device=device)
+                if st is None:
+                    st = cand                      # fallback when no candidate passes: the first one, as before the probe existed
+                if _runs_beside(cand, main):
+                    st = cand
+                    break
         _SIDE_STREAMS[device.index] = st
     return st
+
+
+def prepare_side_stream(device=None):
+    """choose (probe) the weight-gradient side stream of `device` NOW, outside any backward pass or stream capture: the probe
+    synchronises the device three times and launches spin kernels, which has no place inside the first backward or a
+    gradient hook.  Called by TrainStep and GradientReducer when they are built; a no-op once the stream is chosen."""
+    if not WGRAD_SIDE_STREAM:
+        return None
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return None
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    return _side_stream(device)
 
 
 def wgrad_stream_join():
@@ -867,7 +893,13 @@ def wgrad_stream_join():
     st = _SIDE_STREAMS.get(cur.device.index)
     if st is not None:
         cur.wait_stream(st)
-        _SIDE_KEEP.pop(cur.device.index, None)    # everything the side stream read is safe to recycle behind this wait
+        # everything the side stream read is safe to recycle behind this wait -- on the stream that waits.  A tensor whose
+        # allocator pool belongs to ANOTHER stream (forward under torch.cuda.stream(s), backward() joined on a different one)
+        # would become reusable on s before the side stream is done with it: those fall back to record_stream
+        for xn, dyn, owner in _SIDE_KEEP.pop(cur.device.index, ()):
+            if owner != cur.cuda_stream:
+                xn.record_stream(st)
+                dyn.record_stream(st)
 
 
 def _join_after_backward():
@@ -902,7 +934,7 @@ def _wgrad_to_sink(xn, dyn, w_shape, kind, sink_view):
     # (tools/ab_step.py SIDE_KEEPALIVE=True / False, three pairs, eager: 15.69 / 15.79 / 15.74 against 15.88 / 15.87 / 15.87 ms;
     # a reusable event + bare set_stream calls instead of wait_stream + the stream context manager: no change)
     if SIDE_KEEPALIVE:
-        _SIDE_KEEP.setdefault(dyn.device.index, []).append((xn, dyn))
+        _SIDE_KEEP.setdefault(dyn.device.index, []).append((xn, dyn, torch.cuda.current_stream().cuda_stream))
     else:
         xn.record_stream(side)
         dyn.record_stream(side)

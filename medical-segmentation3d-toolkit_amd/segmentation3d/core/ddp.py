@@ -97,6 +97,9 @@ class GradientReducer(object):
             self._join = _ops.wgrad_stream_join
             if dist.get_backend(process_group) == 'nccl':     # (gloo stages through the host: it needs the join)
                 self._side = _ops.wgrad_side_stream
+            # choose the side stream now: its probe synchronises the device, which has no place inside the first gradient hook
+            with torch.cuda.device(flat_buffers[0].device):
+                _ops.prepare_side_stream(flat_buffers[0].device)
         self.world_size = dist.get_world_size(process_group)
         self.buffers = flat_buffers
         self._buckets = []          # dict(buffer, lo, hi, pending, nparams, work)

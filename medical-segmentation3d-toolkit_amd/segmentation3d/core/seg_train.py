@@ -67,6 +67,9 @@ class TrainStep(object):
         # its collectives stay outside hipGraphs.
         self.use_graph = bool(use_graph) and self.reducer is None
         self._graph, self._gx, self._gt, self._gloss, self._eager_calls = None, None, None, None, 0
+        if self.device.type == 'cuda':
+            # the weight-gradient side stream is chosen by a probe that synchronises the device: here, not inside the first backward
+            _ops.prepare_side_stream(self.device)
 
     def __call__(self, crops, masks):
         """one optimisation step; returns the (device) loss tensor of this rank's batch"""

@@ -192,8 +192,12 @@ def test_weight_gradient_side_stream_runs_beside_the_main_stream(hip_device):
     HIP's hardware queues are serialised, which is what happened by default once an RCCL communicator existed in the
     process (tools/ddp_overhead.py: fp32 step 17.05 instead of 15.97 ms)"""
     from segmentation3d import _ops
-    side = _ops._side_stream(hip_device)
+    side = _ops.prepare_side_stream(hip_device)
     main = torch.cuda.current_stream()
     assert side is not main and side.cuda_stream != main.cuda_stream
-    assert _ops._runs_beside(side, main)
-    assert _ops.wgrad_side_stream(hip_device) is side
+    assert _ops.wgrad_side_stream(hip_device) is side and _ops._side_stream(hip_device) is side
+    # the probe is a timing measurement (majority of three readings each): on a device that other work shares a single call
+    # can lose, so it is asked up to three times before the choice is called wrong
+    assert any(_ops._runs_beside(side, main) for _ in range(3))
+    # a stream handed out during a capture is provisional: it is never remembered as the probed choice
+    assert hip_device.index not in _ops._SIDE_STREAMS_UNPROBED

@@ -1,6 +1,6 @@
 """per-kernel roofline table (markdown) from the committed round profiles:
   kernel statistics (rocprofv3 --kernel-trace --stats), the FETCH_SIZE / WRITE_SIZE PMC passes, the MFMA shape report
-usage: python tools/roofline_table.py <kernel_stats.csv> <pmc_fetch_write.json> <mfma_shapes.json> [steps | auto] > table.md"""
+usage: python tools/roofline_table.py <kernel_stats.csv> <pmc_fetch_write.json> <mfma_shapes.json> [steps | auto] [no-algo] > table.md"""
 import csv
 import json
 import sys
@@ -37,8 +37,25 @@ for r in shapes:
     e[0] += 2.0 * N * D * H * W * 27 * Ci * Co * r['launches_per_step']
     e[1] += r['avg_ms'] * r['launches_per_step']
 
-print('| kernel | launches/step | ms/step | avg us | traffic at the L2 boundary, GB/launch (2 x FETCH + WRITE) | GB/s | % of 8 TB/s | TFLOP/s | % of 157.3 |')
-print('|---|---|---|---|---|---|---|---|---|')
+# ALGORITHMIC bytes per launch (input + output tensors once, fp32) of the HBM-bound kernels that run once per step with ONE shape
+# in the headline configuration (vnet(1,2), batch 4, 96^3; SURVEY.md 8a layer table x 4 patches): the roof these kernels are priced
+# against is 8 TB/s on THESE bytes -- counter traffic above them is waste, not credit.  Multi-shape kernels (GroupNorm passes,
+# the stride-2 forward at four levels) have no single figure and keep '-'.
+V = 4 * 96 ** 3 * 4 / 1e6   # MB of one fp32 channel of the batch at full resolution
+ALGO_MB = {
+    'conv3d_k3_thin_in_persistent16_kernel<1': (1 + 16) * V,        # stem forward: 1 -> 16 channels
+    'conv3d_k3_thin_out_f32mfma_kernel<32, 2': (32 + 2) * V,         # head forward: 32 -> 2
+    'conv3d_k3_thin_in_persistent_kernel<2': (2 + 32) * V,           # head data-gradient: 2 -> 32
+    'k3_thin_wgrad_kernel<2>': (32 + 2) * V,                         # head weight gradient: x (32) and dy (2)
+    'k3_thin_wgrad_kernel<1>': (1 + 16) * V,                         # stem weight gradient: x (1) and dy (16)
+    'convT3d_k2s2_mfma_kernel<0, false, false, true>': (64 / 8 + 16) * V,        # up_32.up_conv: 64 ch at 48^3 -> 16 ch at 96^3
+    'convT3d_k2s2_mfma_kernel<0, false, true, true>': (32 / 8 + 16 + 16) * V,    # down_32 data-gradient + skip addend -> 16 ch at 96^3
+    'adam_step_devstep_kernel': 28 * 14563296 / 1e6,                 # 28 B per parameter
+}
+if len(sys.argv) > 5 and sys.argv[5] == 'no-algo':   # other configurations (bf16 mode, other networks): the figures above do not apply
+    ALGO_MB = {}
+print('| kernel | launches/step | ms/step | avg us | traffic at the L2 boundary, GB/launch (2 x FETCH + WRITE) | GB/s | % of 8 TB/s | algorithmic MB/launch | % of 8 TB/s on algorithmic bytes | TFLOP/s | % of 157.3 |')
+print('|---|---|---|---|---|---|---|---|---|---|---|')
 for r in stats[:40]:
     name = r['Name'].split('(')[0].strip()
     key = name
@@ -57,7 +74,11 @@ for r in stats[:40]:
     vkey = short if short in variant_flops else short.split('<')[0]
     if vkey in variant_flops and variant_flops[vkey][1] > 0:
         tf = variant_flops[vkey][0] / (variant_flops[vkey][1] * 1e-3) / 1e12
-    print('| `{}` | {:.1f} | {:.3f} | {:.1f} | {} | {} | {} | {} | {} |'.format(
+    amb = next((v for k, v in ALGO_MB.items() if short.startswith(k)), None)
+    if amb is not None and abs(calls - 1.0) > 0.2:
+        amb = None   # not the once-per-step launch the figure was derived for
+    print('| `{}` | {:.1f} | {:.3f} | {:.1f} | {} | {} | {} | {} | {} | {} | {} |'.format(
         short[:60], calls, ms, avg_us, '-' if gb is None else '{:.3f}'.format(gb), '-' if gbs is None else '{:.0f}'.format(gbs),
-        '-' if gbs is None else '{:.0f}'.format(100 * gbs / HBM_PEAK_GBS), '-' if tf is None else '{:.1f}'.format(tf),
-        '-' if tf is None else '{:.0f}'.format(100 * tf / MFMA_PEAK_TF)))
+        '-' if gbs is None else '{:.0f}'.format(100 * gbs / HBM_PEAK_GBS),
+        '-' if amb is None else '{:.0f}'.format(amb), '-' if amb is None else '{:.0f}'.format(100 * amb / 1e3 / (avg_us * 1e-6) / HBM_PEAK_GBS),
+        '-' if tf is None else '{:.1f}'.format(tf), '-' if tf is None else '{:.0f}'.format(100 * tf / MFMA_PEAK_TF)))

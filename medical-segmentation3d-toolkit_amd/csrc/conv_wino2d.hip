@@ -121,6 +121,13 @@ __device__ __forceinline__ void w2_bufdma16_if(int pred_wave_uniform, unsigned v
   asm volatile("s_cmp_lg_u32 %3, 0\n\ts_cbranch_scc0 1f\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds\n1:"
                : : "v"(voff), "s"(srd), "s"(lds_byte_off_wave_uniform), "s"(pred_wave_uniform) : "memory", "m0", "scc");
 }
+// the same unconditionally, with a wave-uniform byte offset in the instruction's scalar-offset field (the K chunk's channels)
+__device__ __forceinline__ void w2_bufdma16_soff(unsigned voff, w2_srd srd, unsigned soff_wave_uniform, unsigned lds_byte_off_wave_uniform) {
+  soff_wave_uniform = __builtin_amdgcn_readfirstlane(soff_wave_uniform);
+  lds_byte_off_wave_uniform = __builtin_amdgcn_readfirstlane(lds_byte_off_wave_uniform);
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               : : "v"(voff), "s"(srd), "s"(soff_wave_uniform), "s"(lds_byte_off_wave_uniform) : "memory", "m0");
+}
 __device__ __forceinline__ void w2_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // a - b on two packed floats in one instruction (hipcc selects v_pk_add_f32 for additions but two v_sub_f32 for this)
 __device__ __forceinline__ f32x2 w2_pk_add(f32x2 a, f32x2 b) {
@@ -212,19 +219,28 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
   auto fdiv = [](int v, float r) { return (int)(((float)v + 0.5f) * r); };
   const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz, rNCOG = 1.0f / (float)ncog;
 
-  int hpos[W2_XPW];
+  // RAW pieces of this wave come through a buffer resource of the SAMPLE (w2_bufdma16 below): xconst = the byte offset of the
+  // lane's halo voxel relative to the tile origin (negative in front of it), OOB for the padding slots 1000 .. 1023; z padding =
+  // the resource's range check (plane -1 wraps, plane D is past the end), (y, x) padding = a select per item on xflag
+  const unsigned OOB = 0x80000000u;                    // stays out of range after any tile / channel offset (sample bytes < 2^31)
+  unsigned xconst[W2_XPW];
+  int xflag[W2_XPW];
 #pragma unroll
   for (int j = 0; j < W2_XPW; ++j) {
     const int e = (wave + W2_NW * j) * 64 + lane;
-    hpos[j] = -1;
+    xconst[j] = OOB;
+    xflag[j] = 0;
     if (e < W2_NV) {   // RAW slot e holds the halo voxel (hz, hy, hx ^ swizzle): see the LDS images below
       const int t = e / W2_H;
-      const int hx = e - t * W2_H;
+      const int hxs = e - t * W2_H;
       const int hz = t / W2_H;
       const int hy = t - hz * W2_H;
-      hpos[j] = (hz << 20) | (hy << 10) | (hx ^ ((hy >> 1) & 1));
+      const int hx = hxs ^ ((hy >> 1) & 1);
+      xconst[j] = (unsigned)((((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin * 4);
+      xflag[j] = (hy == 0 ? 4 : 0) | (hy == W2_H - 1 ? 8 : 0) | (hx == 0 ? 16 : 0) | (hx == W2_H - 1 ? 32 : 0);
     }
   }
+  const unsigned xbytes = (unsigned)D * H * W * Cin * 4u;   // one sample
   // ---- LDS images, laid out for conflict-free access (tools/lds_bank_sim.py models every access kind below; round 3's images
   // [t][co][4] / [p][z][quad][4] made every operand read a 2-way conflict: lanes (l16, kq) and (l16 + 8, kq) on one bank) ----
   //   weights [g 12][kq 4][co 32][4 steps]: a lane's A operands of the steps 4 g .. 4 g + 3 are ONE ds_read_b128
@@ -273,22 +289,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
   if (item >= ilimit) return;
 
   int fx_item = item, fx_sc = 0;
-  const float* xsrc[W2_XPW];
-  int xadv = 0;
+  unsigned xvoff[W2_XPW];   // byte offset of the lane's halo voxel inside the sample of the item being fetched (OOB: padding)
+  w2_srd xsrd;
   auto fx_setup = [&](int it) {
     int n, z0, y0, x0, cog, tile;
     decode(it, n, z0, y0, x0, cog, tile);
-    xadv = 0;
+    const int fyx = (y0 == 0 ? 4 : 0) | (y0 + W2_TS >= H ? 8 : 0) | (x0 == 0 ? 16 : 0) | (x0 + W2_TS >= W ? 32 : 0);
+    const unsigned origin = (unsigned)(((z0 * H + y0) * W + x0) * Cin * 4);
 #pragma unroll
-    for (int j = 0; j < W2_XPW; ++j) {
-      xsrc[j] = w2_zero16;
-      const int hp = hpos[j];
-      const int gz = z0 + ((hp >> 20) & 1023) - 1, gy = y0 + ((hp >> 10) & 1023) - 1, gx = x0 + (hp & 1023) - 1;
-      if (hp >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        xsrc[j] = x + (i64)(((n * D + gz) * H + gy) * W + gx) * Cin;
-        xadv |= 1 << j;
-      }
-    }
+    for (int j = 0; j < W2_XPW; ++j) xvoff[j] = (xflag[j] & fyx) ? OOB : xconst[j] + origin;
+    xsrd = w2_make_srd(x + (i64)n * D * H * W * Cin, xbytes);
   };
   auto fx_advance = [&]() {
     ++fx_sc;
@@ -299,9 +309,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
     }
   };
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(w2_lds_float*)lds);   // byte offset of the carve-up
-  auto dma_x = [&](int j, unsigned rdst_float_off) {   // rdst: float offset of a RAW buffer inside the carve-up
-    w2_glds16_at(xsrc[j], lds0 + (rdst_float_off + (wave + W2_NW * j) * 256) * 4);
-    xsrc[j] += ((xadv >> j) & 1) * 4;
+  auto dma_x = [&](int j, unsigned rdst_float_off) {   // rdst: float offset of a RAW buffer inside the carve-up; channels 4 fx_sc .. + 3
+    w2_bufdma16_soff(xvoff[j], xsrd, (unsigned)fx_sc * 16u, lds0 + (rdst_float_off + (wave + W2_NW * j) * 256) * 4);
   };
   int fw_item = item, fw_sc = 0;
   auto cog_of = [&](int it) { return __builtin_amdgcn_readfirstlane(it - fdiv(it, rNCOG) * ncog); };
@@ -607,19 +616,26 @@ __global__ __launch_bounds__(128 * NC, 1) void conv3d_k3_wino2d_c4_kernel(const 
   const float rNCX = 1.0f / (float)ncx, rNCY = 1.0f / (float)ncy, rNCZ = 1.0f / (float)ncz, rNCOG = 1.0f / (float)ncog;
 
   // raw DMA pieces of this wave: piece p = wave + 8 j is slots 64 (p & 3) .. + 63 of cell p >> 2 of the item
-  int hpos[W2_XPW];
+  // (through a buffer resource of the cell's sample, as the tile kernel: byte offset relative to the cell origin, (y, x) flags)
+  const unsigned OOB = 0x80000000u;
+  unsigned xconst[W2_XPW];
+  int xflag[W2_XPW];
 #pragma unroll
   for (int j = 0; j < W2_XPW; ++j) {
     const int e = ((wave + NWV * j) & 3) * 64 + lane;
-    hpos[j] = -1;
+    xconst[j] = OOB;
+    xflag[j] = 0;
     if (e < C4_NV) {   // RAW slot e of a cell holds the halo voxel (hz, hy, hx ^ swizzle), as in the tile kernel
       const int t = e / C4_H;
-      const int hx = e - t * C4_H;
+      const int hxs = e - t * C4_H;
       const int hz = t / C4_H;
       const int hy = t - hz * C4_H;
-      hpos[j] = (hz << 20) | (hy << 10) | (hx ^ ((hy >> 1) & 1));
+      const int hx = hxs ^ ((hy >> 1) & 1);
+      xconst[j] = (unsigned)((((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin * 4);
+      xflag[j] = (hy == 0 ? 4 : 0) | (hy == C4_H - 1 ? 8 : 0) | (hx == 0 ? 16 : 0) | (hx == C4_H - 1 ? 32 : 0);
     }
   }
+  const unsigned xbytes = (unsigned)D * H * W * Cin * 4u;   // one sample
   // LDS images (conflict-free by tools/lds_bank_sim.py): weights as the tile kernel; T [p][cell][h 2][z 6][quad 4][2] -- the 32
   // lanes (column (z, quad), kq pair) of a read are 32 consecutive floats; RAW slots with the x pairs of every other row pair swapped
   const int abase = (kq * 32 + 16 * hh + l16) * 4;                                              // + g * 512
@@ -665,23 +681,19 @@ __global__ __launch_bounds__(128 * NC, 1) void conv3d_k3_wino2d_c4_kernel(const 
   if (item >= ilimit) return;
 
   int fx_item = item, fx_sc = 0;
-  const float* xsrc[W2_XPW];
-  int xadv = 0;
+  unsigned xvoff[W2_XPW];
+  w2_srd xsrd[W2_XPW];    // (a wave's two pieces belong to two cells, which may lie in two samples)
   auto fx_setup = [&](int it) {
     int cog;
     const int grp = group_of(it, cog);
-    xadv = 0;
 #pragma unroll
     for (int j = 0; j < W2_XPW; ++j) {
       int n, z0, y0, x0, cis;
       cell_origin(NC * grp + ((wave + NWV * j) >> 2), n, z0, y0, x0, cis);
-      xsrc[j] = w2_zero16;
-      const int hp = hpos[j];
-      const int gz = z0 + ((hp >> 20) & 1023) - 1, gy = y0 + ((hp >> 10) & 1023) - 1, gx = x0 + (hp & 1023) - 1;
-      if (hp >= 0 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        xsrc[j] = x + (i64)(((n * D + gz) * H + gy) * W + gx) * Cin;
-        xadv |= 1 << j;
-      }
+      const int fyx = (y0 == 0 ? 4 : 0) | (y0 + 4 >= H ? 8 : 0) | (x0 == 0 ? 16 : 0) | (x0 + 4 >= W ? 32 : 0);
+      const unsigned origin = (unsigned)(((z0 * H + y0) * W + x0) * Cin * 4);
+      xvoff[j] = (xflag[j] & fyx) ? OOB : xconst[j] + origin;
+      xsrd[j] = w2_make_srd(x + (i64)n * D * H * W * Cin, xbytes);
     }
   };
   auto fx_advance = [&]() {
@@ -694,8 +706,7 @@ __global__ __launch_bounds__(128 * NC, 1) void conv3d_k3_wino2d_c4_kernel(const 
   };
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(w2_lds_float*)lds);   // byte offset of the carve-up
   auto dma_x = [&](int j, unsigned rdst_float_off) {
-    w2_glds16_at(xsrc[j], lds0 + (rdst_float_off + (wave + NWV * j) * 256) * 4);
-    xsrc[j] += ((xadv >> j) & 1) * 4;
+    w2_bufdma16_soff(xvoff[j], xsrd[j], (unsigned)fx_sc * 16u, lds0 + (rdst_float_off + (wave + NWV * j) * 256) * 4);
   };
   int fw_item = item, fw_sc = 0;
   auto cog_of = [&](int it) { return __builtin_amdgcn_readfirstlane(it - fdiv(it, rNCOG) * ncog); };
@@ -923,6 +934,7 @@ extern "C" int seg3d_conv3d_k3_wino2d_supported(int N, int D, int H, int W, int 
   if (!w2_cells(D, H, W) || (Cin & 7) || (Cout & 31)) return 0;
   if (w2_items(N, D, H, W, Cout) >= (1 << 20)) return 0;
   if ((long long)N * D * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;
+  if ((long long)D * H * W * Cin * 4 >= (1ll << 31)) return 0;   // the input comes through one buffer resource per SAMPLE: 32-bit byte offsets
   return 1;
 }
 
@@ -1257,7 +1269,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
       }
 #pragma unroll
       for (int g = 0; g < G2_NG; ++g)
+#ifndef G2_EXP_NODMA
         if (g % G2_KS == k) issue_piece(g, xnxt2, ynxt2, xsrd, ysrd, fxoff, fyoff, f_start);
+#endif
       __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from sinking the reads above down to their first use
 #pragma unroll
       for (int j = 0; j < 12; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], e[j & 3], acc[j], 0, 0, 0);

@@ -113,7 +113,9 @@ int seg3d_conv3d_k3_wino_fwd(const float* x, const float* wp_wino, const float* 
 /* Winograd F(2x2, 3x3) over (y, x) form of the same convolution (csrc/conv_wino2d.hip): a 2 x 2 output quad of one z plane
  * from a 4 x 4 input patch with 16 multiplies instead of 36 per kz = 4/9 of the fp32 MFMAs of the direct kernel; coefficients
  * 1, 1/2, 1/4, exact fp32 transforms.  wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 48): T = 48 selects U = G g G^T per
- * kz (t = kz * 16 + py * 4 + px).  Same arguments as the F(2, 3) form.  Supported: D, H, W multiples of 4 (whole 8^3 tiles run
+ * kz (t = kz * 16 + py * 4 + px); the image is opaque to the caller (same size as any T = 48 pack; inside a 32 x 8 chunk it is
+ * ordered [4-channel half][group of four K steps][channel][output channel][step] -- the LDS image of the kernels, straight copy).
+ * Same arguments as the F(2, 3) form.  Supported: D, H, W multiples of 4 (whole 8^3 tiles run
  * the tile kernel, levels that are only whole 4^3 cells -- the 12^3 level -- the cell kernel), Cin % 8 == 0, Cout % 32 == 0;
  * preferred: at least 192 (tile | group of four cells, 32-channel column block) items.
  * replaces nn.Conv3d(C, C, 3, padding=1), network/module/conv_gn_relu3.py:10, and its input gradient */

@@ -127,13 +127,19 @@ __device__ __forceinline__ float seg3d_wino_u(float g0, float g1, float g2, int 
 // chunk of the forward kernels, in which a lane (output channel j, K index r) finds the A operands of the four consecutive
 // steps 4 g .. 4 g + 3 in one aligned 16-byte word (ds_read_b128, conflict-free: tools/lds_bank_sim.py).
 #define SEG3D_WINO2D_T 48
+struct Seg3dW2StepTable {   // t48 of every step of the chunk's step order, built at compile time
+  unsigned char t[48];
+  constexpr Seg3dW2StepTable() : t() {
+    for (int s = 0; s < 48; ++s) t[s] = (unsigned char)seg3d_w2_step_t(s);
+  }
+};
+__device__ const Seg3dW2StepTable seg3d_w2_step_table;
 __device__ __forceinline__ void seg3d_wino2d_decode(int i, int& h, int& r, int& j, int& t48) {   // i = offset inside a chunk's 12288 floats
-  const int s4 = i & 3, g = (i >> 9) % 12;
+  const int s4 = i & 3, g24 = i >> 9;         // g24 = h * 12 + g
   j = (i >> 2) & 31;
   r = (i >> 7) & 3;
-  h = (i >> 9) / 12;
-  // (seg3d_w2_step_t is constexpr arithmetic on small integers: a handful of scalar instructions here)
-  t48 = seg3d_w2_step_t(4 * g + s4);
+  h = g24 >= 12 ? 1 : 0;
+  t48 = seg3d_w2_step_table.t[4 * (g24 - 12 * h) + s4];   // (a table: the div / mod arithmetic of the step order per element made the multi-pack 17 % slower)
 }
 __device__ __forceinline__ float seg3d_wino2d_u(const float* g, int flip, int t48) {
   const int kz = t48 >> 4, py = (t48 >> 2) & 3, px = t48 & 3;

@@ -60,22 +60,44 @@ static K2Tile k2_pick_tile(int D, int H, int W) {
 //      8 bf16 channels, a chunk is 16 channels, one v_mfma_f32_32x32x16_bf16 per tap -- same LDS bytes, 1/8 of the MFMA
 //      cycles (the fp32 forms of these layers were MFMA-bound: N = 16..32 output channels fill half an MFMA tile)
 typedef __bf16 k2_bf16x8 __attribute__((ext_vector_type(8)));
+// input rows through a buffer resource of the SAMPLE (k2_make_rsrc): voff = byte offset of the entry inside the sample, or K2_OOB --
+// an offset past the resource's range returns zeros, so neither a zero source nor a select at the LDS store is needed, and the
+// chunk's channel offset rides in the instruction's scalar offset: no vector instruction per load
+typedef unsigned k2_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned k2_u32x2 __attribute__((ext_vector_type(2)));
+#define K2_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t k2_make_rsrc(const void* base_wave_uniform, unsigned num_bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base_wave_uniform), (short)0, (int)num_bytes, 0x00020000);
+}
 template <int MODE> struct K2In;
 template <> struct K2In<0> {
   typedef f32x4 raw;
   static constexpr int CPH = 4;   // channels per (voxel, half) entry
+  static constexpr int ESZ = 4;   // bytes per element
+  static __device__ __forceinline__ raw bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+  }
   static __device__ __forceinline__ raw load(const void* p, i64 e) { return Seg3dQuad<false>::load(p, e); }
   static __device__ __forceinline__ f32x4 cvt(raw r) { return r; }
 };
 template <> struct K2In<1> {
   typedef uint2 raw;
   static constexpr int CPH = 4;
+  static constexpr int ESZ = 2;
+  static __device__ __forceinline__ raw bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const k2_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    return uint2{v[0], v[1]};
+  }
   static __device__ __forceinline__ raw load(const void* p, i64 e) { return Seg3dQuad<true>::load(p, e); }
   static __device__ __forceinline__ f32x4 cvt(raw r) { return Seg3dQuad<true>::cvt(r); }
 };
 template <> struct K2In<2> {
   typedef f32x4 raw;              // 16 raw bytes = 8 bf16 channels
   static constexpr int CPH = 8;
+  static constexpr int ESZ = 2;
+  static __device__ __forceinline__ raw bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+  }
   static __device__ __forceinline__ raw load(const void* p, i64 e) {
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const seg3d_bf16*>(p) + e);
   }
@@ -116,8 +138,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
   constexpr int CPH = K2In<MODE>::CPH, CPC = 2 * CPH;   // channels per half / per chunk
   const int CIB = (Cin + CPC - 1) / CPC;
   const int cob = blockIdx.y;
-  // index decoding by float reciprocal (seg3d_fdiv): a workgroup owns ONE tile, so this prologue is paid per tile
-  const float rHX = 1.0f / (float)HX, rHY = 1.0f / (float)HY, rTX = 1.0f / (float)TX, rTY = 1.0f / (float)TY;
+  // A workgroup owns ONE tile, so this prologue is paid per tile -- and in fp32 every vector instruction of it is paid on the
+  // pipe the MFMAs use (round 3: 10.6 vector instructions per MFMA at the top level, 60 % of them here).  The tile edges are
+  // powers of two (k2_pick_tile): lane -> voxel decoding is shifts and masks, not reciprocal multiplies.
+  const int lgHX = __builtin_ctz(HX), lgHY = __builtin_ctz(HY), lgTX = __builtin_ctz(TX), lgTY = __builtin_ctz(TY);
   int b = blockIdx.x;
   int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
   const int tix = b - qd * ntx; b = qd;
@@ -128,27 +152,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
   const int n = qd;
   const int z0 = tiz * TZ, y0 = tiy * TY, x0 = tix * TX;
 
-  int goff[K2_MAXE];
+  // staged entries of this thread: byte offset inside the sample (K2_OOB: outside the volume / past the tile -> zeros)
+  constexpr int ESZ = K2In<MODE>::ESZ;
+  unsigned goff[K2_MAXE];
   const int hh = tid & 1;
 #pragma unroll
   for (int e = 0; e < K2_MAXE; ++e) {
     const int eidx = tid + e * 256;
-    goff[e] = -1;
+    goff[e] = K2_OOB;
     if (eidx < 2 * NV) {
       const int v = eidx >> 1;
-      const int t = seg3d_fdiv(v, rHX);
-      const int hx = v - t * HX;
-      const int hz = seg3d_fdiv(t, rHY);
-      const int hy = t - hz * HY;
+      const int hx = v & (HX - 1), t = v >> lgHX;
+      const int hy = t & (HY - 1), hz = t >> lgHY;
       const int gz = 2 * z0 + hz, gy = 2 * y0 + hy, gx = 2 * x0 + hx;
-      if (gz < Di && gy < Hi && gx < Wi) goff[e] = (((n * Di + gz) * Hi + gy) * Wi + gx) * ldx + hh * CPH;
+      if (gz < Di && gy < Hi && gx < Wi) goff[e] = (unsigned)((((gz * Hi + gy) * Wi + gx) * ldx + hh * CPH) * ESZ);
     }
   }
+  const __amdgpu_buffer_rsrc_t xrs = k2_make_rsrc(reinterpret_cast<const char*>(x) + (i64)n * Di * Hi * Wi * ldx * ESZ,
+                                                  (unsigned)Di * Hi * Wi * ldx * ESZ);
   for (int idx = tid; idx < MT; idx += 256) {
-    const int t = seg3d_fdiv(idx, rTX);
-    const int tx = idx - t * TX;
-    const int tz = seg3d_fdiv(t, rTY);
-    const int ty = t - tz * TY;
+    const int tx = idx & (TX - 1), t = idx >> lgTX;
+    const int ty = t & (TY - 1), tz = t >> lgTY;
     const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
     voff[idx] = (gz < Do && gy < Ho && gx < Wo) ? ((n * Do + gz) * Ho + gy) * Wo + gx : -1;
   }
@@ -157,10 +181,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
     const int idx = wave * 32 + li;
     int vb = 0;
     if (idx < MT) {
-      const int t = seg3d_fdiv(idx, rTX);
-      const int tx = idx - t * TX;
-      const int tz = seg3d_fdiv(t, rTY);
-      const int ty = t - tz * TY;
+      const int tx = idx & (TX - 1), t = idx >> lgTX;
+      const int ty = t & (TY - 1), tz = t >> lgTY;
       vb = ((2 * tz) * HY + 2 * ty) * HX + 2 * tx;
     }
     abase = (lh * NV + vb) * 4;
@@ -173,39 +195,30 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
   // Register-prefetch pipeline: all loads of chunk c+1 are issued back to back (branch-free, clamped addresses; the
   // zero-select happens at the LDS store) before the MFMAs of chunk c, so a workgroup keeps 32 KB in flight -- at the
   // top level this kernel is HBM-bound and a load consumed right where it is issued serialises on memory latency.
-  typename K2In<MODE>::raw xst[K2_MAXE];
-  f32x4 wst[2];
-  auto load_chunk = [&](int cib) {
-    const bool half_ok = cib * CPC + hh * CPH < Cin;
+  // TWO chunks in flight (round 4): a tile of the top level has only two chunks, and with one in flight their memory round trips
+  // were serialised (load 0 -> wait -> store -> issue load 1 -> MFMAs 0 -> wait ...); both register sets are requested up front
+  typename K2In<MODE>::raw xst[2][K2_MAXE];
+  f32x4 wst[2][2];
+  auto load_chunk = [&](int cib, int set) {
+    // (a half past the last channel: K2_OOB ored in -- only the last chunk of a channel count that is not a multiple of CPC)
+    const unsigned hk = cib * CPC + hh * CPH < Cin ? 0u : K2_OOB;
 #pragma unroll
-    for (int e = 0; e < K2_MAXE; ++e) {
-      const bool ok = goff[e] >= 0 && half_ok;
-      xst[e] = K2In<MODE>::load(x, ok ? (i64)goff[e] + cib * CPC : (i64)0);
-    }
+    for (int e = 0; e < K2_MAXE; ++e) xst[set][e] = K2In<MODE>::bload(xrs, goff[e] | hk, (unsigned)(cib * CPC * ESZ));
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + ((i64)cob * CIB + cib) * K2_W_CHUNK);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) wst[k] = wsrc[tid + k * 256];
+    for (int k = 0; k < 2; ++k) wst[set][k] = wsrc[tid + k * 256];
   };
-  auto store_chunk = [&](int cib) {
-    const bool half_ok = cib * CPC + hh * CPH < Cin;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  auto store_chunk = [&](int set) {
 #pragma unroll
     for (int e = 0; e < K2_MAXE; ++e) {
       const int eidx = tid + e * 256;
-      if (eidx < 2 * NV)
-        *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) =
-            (goff[e] >= 0 && half_ok) ? K2In<MODE>::cvt(xst[e]) : zero;
+      if (eidx < 2 * NV) *reinterpret_cast<f32x4*>(xs + (hh * NV + (eidx >> 1)) * 4) = K2In<MODE>::cvt(xst[set][e]);   // (zeros where out of range)
     }
     f32x4* wdst = reinterpret_cast<f32x4*>(ws);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) wdst[tid + k * 256] = wst[k];
+    for (int k = 0; k < 2; ++k) wdst[tid + k * 256] = wst[set][k];
   };
-  load_chunk(0);
-  for (int cib = 0; cib < CIB; ++cib) {
-    __syncthreads();  // previous chunk fully consumed (also publishes voff on the first pass)
-    store_chunk(cib);
-    __syncthreads();
-    if (cib + 1 < CIB) load_chunk(cib + 1);
+  auto multiply_chunk = [&]() {
 #pragma unroll
     for (int tap = 0; tap < 8; ++tap) {
       const int kz = tap >> 2, ky = (tap >> 1) & 1, kx = tap & 1;
@@ -214,6 +227,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
       const f32x4 av = *reinterpret_cast<const f32x4*>(xs + abase + tapoff);
       // A = weights, B = voxels: D[co][voxel] -- a lane owns voxel (lane & 31) and channels 8 g + 4 (lane >> 5) + c
       acc = k2_mfma_step<MODE>(bw, av, acc);
+    }
+  };
+  load_chunk(0, 0);
+  if (CIB > 1) load_chunk(1, 1);
+  for (int cib = 0; cib < CIB; cib += 2) {
+    __syncthreads();  // previous chunk fully consumed (also publishes voff on the first pass)
+    store_chunk(0);
+    __syncthreads();
+    if (cib + 2 < CIB) load_chunk(cib + 2, 0);
+    multiply_chunk();
+    if (cib + 1 < CIB) {
+      __syncthreads();
+      store_chunk(1);
+      __syncthreads();
+      if (cib + 3 < CIB) load_chunk(cib + 3, 1);
+      multiply_chunk();
     }
   }
 
@@ -270,6 +299,7 @@ static int k2_gather_launch(const void* x, int x_bf16, const float* wp, const fl
                 "seg3d_conv3d_k2s2_mfma_fwd: Cin and Cout must be multiples of 4 (got %d, %d)", Cin, Cout);
   SEG3D_REQUIRE((i64)N * Do * Ho * Wo * 8 * ldx < (1ll << 31) && (i64)N * Do * Ho * Wo * Cout < (1ll << 31),
                 "seg3d_conv3d_k2s2_mfma_fwd: tensor exceeds 2^31 elements");
+  SEG3D_REQUIRE((i64)Do * Ho * Wo * 8 * ldx * 4 < (1ll << 31), "seg3d_conv3d_k2s2_mfma_fwd: one sample of x exceeds 2^31 bytes");
   K2Tile t = k2_pick_tile(Do, Ho, Wo);
   const int ntz = seg3d_cdiv(Do, t.tz), nty = seg3d_cdiv(Ho, t.ty), ntx = seg3d_cdiv(Wo, t.tx);
   const int mt = t.tz * t.ty * t.tx;

@@ -112,10 +112,10 @@ class KernelTimer(object):
                 timer.wgrad_records.append(((N, D, H, W, Cin, Cout, name), a, b))
                 return rc
             if name not in ('seg3d_conv3d_k3_mfma_fwd', 'seg3d_conv3d_k3_bf16_fwd', 'seg3d_conv3d_k3_wino_fwd',
-                            'seg3d_conv3d_k3_wino2d_fwd'):
+                            'seg3d_conv3d_k3_wino2d_fwd', 'seg3d_conv3d_k3_wino2d_fwd_ws'):
                 return timer._orig(name, *args)
-            wino = name in ('seg3d_conv3d_k3_wino_fwd', 'seg3d_conv3d_k3_wino2d_fwd')
-            N, D, H, W, Cin, Cout = args[6:12] if wino else args[7:13]
+            wino = name in ('seg3d_conv3d_k3_wino_fwd', 'seg3d_conv3d_k3_wino2d_fwd', 'seg3d_conv3d_k3_wino2d_fwd_ws')
+            N, D, H, W, Cin, Cout = args[6:12] if (wino and not name.endswith('_ws')) else args[7:13]
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             rc = timer._orig(name, *args)

@@ -124,6 +124,16 @@ int seg3d_conv3d_k3_wino2d_preferred(int N, int D, int H, int W, int Cin, int Co
 long long seg3d_conv3d_k3_wino2d_stats_count(int N, int D, int H, int W, int Cin, int Cout);
 int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp_wino2d, const float* bias, const float* addend, float* y,
                                float* stats_partial, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+/* The same with a caller-owned workspace of seg3d_conv3d_k3_wino2d_fwd_workspace_floats(...) floats (0: none wanted, pass null):
+ * launches whose (tile, column block) items would leave more than 6 % of the CU-rounds empty -- 432 items on 256 CUs, the 24^3
+ * level of the 4 x 96^3 train step -- deal the K chunks of all items to the workgroups in equal contiguous ranges instead (stream-K);
+ * the pieces of an item that a range boundary cuts go through the workspace and a finish pass (one more launch on `stream`).
+ * Two calls that run concurrently (two streams) need two workspaces.  Same results up to the order of one fp32 addition per
+ * output of a cut item.  replaces nn.Conv3d(C, C, 3, padding=1), network/module/conv_gn_relu3.py:10 */
+long long seg3d_conv3d_k3_wino2d_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout);
+int seg3d_conv3d_k3_wino2d_fwd_ws(const float* x, const float* wp_wino2d, const float* bias, const float* addend, float* y,
+                                  float* stats_partial, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
+                                  void* stream);
 /* Winograd F(3, 2) along x form of the weight gradient of the same layers (csrc/conv_wino.hip): 36 point accumulators per
  * (kz, ky, ci block, co block) instead of 27 taps at one voxel PAIR per K slot = 2/3 of the fp32 MFMAs; partial slabs are
  * reduced in fixed order and turned into the three kx taps by the reduce kernel.  Supported: D, H, W multiples of 4, Cin and

@@ -203,7 +203,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
                                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                                       float* __restrict__ stats, int N, int D, int H, int W,
                                                                       int Cin, int Cout, int ntz, int nty, int ntx, int ncog,
-                                                                      int nitems, const float* __restrict__ addend) {
+                                                                      int nitems, const float* __restrict__ addend, int sk_per,
+                                                                      float* __restrict__ skws) {
+  // sk_per > 0: STREAM-K.  The launch's nitems * NSC K chunks are dealt to the workgroups in contiguous ranges of sk_per chunks
+  // (sk_per >= NSC, so an item is cut at most once); a workgroup whose range starts / ends inside an item writes that piece's
+  // outputs -- plain partial sums in the output domain, Y = A^T M A is linear -- into its slab 0 / 1 of skws instead of y, and
+  // conv3d_k3_wino2d_sk_finish_kernel adds the two pieces of every cut item.  The piece that holds chunk 0 carries the bias
+  // and the fused addend as usual, the other starts from zero: the finish pass only adds.  No workgroup waits for another.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* raw = lds;                               // [2][NV][4] (+ padding)
   float* timg = lds + 2 * W2_RAW;                 // [2][16][10][16][4]
@@ -280,15 +286,29 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
     z0 = tiz * W2_TS, y0 = tiy * W2_TS, x0 = tix * W2_TS;
   };
   int item = blockIdx.x, istride = G, ilimit = nitems;
-  if ((G & 7) == 0) {
+  int sc_first = 0, sc_last_end = NSC, sk_wg = 0;   // stream-K: chunk range inside the first / last item of this workgroup, its index
+  if (sk_per > 0) {
+    sk_wg = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // neighbouring ranges on one XCD
+    const int g0 = sk_wg * sk_per, total = nitems * NSC;
+    const int g1 = g0 + sk_per < total ? g0 + sk_per : total;
+    if (g0 >= g1) return;
+    const float rNSC = 1.0f / (float)NSC;
+    item = __builtin_amdgcn_readfirstlane(fdiv(g0, rNSC));
+    sc_first = g0 - item * NSC;
+    const int last = __builtin_amdgcn_readfirstlane(fdiv(g1 - 1, rNSC));
+    sc_last_end = g1 - last * NSC;
+    istride = 1;
+    ilimit = last + 1;
+  } else if ((G & 7) == 0) {
     const int per_xcd = (nitems + 7) >> 3, xcd = blockIdx.x & 7;
     item = xcd * per_xcd + (blockIdx.x >> 3);
     istride = G >> 3;
     ilimit = (xcd + 1) * per_xcd < nitems ? (xcd + 1) * per_xcd : nitems;
   }
   if (item >= ilimit) return;
+  const int first_item = item;
 
-  int fx_item = item, fx_sc = 0;
+  int fx_item = item, fx_sc = sc_first;
   unsigned xvoff[W2_XPW];   // byte offset of the lane's halo voxel inside the sample of the item being fetched (OOB: padding)
   w2_srd xsrd;
   auto fx_setup = [&](int it) {
@@ -312,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
   auto dma_x = [&](int j, unsigned rdst_float_off) {   // rdst: float offset of a RAW buffer inside the carve-up; channels 4 fx_sc .. + 3
     w2_bufdma16_soff(xvoff[j], xsrd, (unsigned)fx_sc * 16u, lds0 + (rdst_float_off + (wave + W2_NW * j) * 256) * 4);
   };
-  int fw_item = item, fw_sc = 0;
+  int fw_item = item, fw_sc = sc_first;
   auto cog_of = [&](int it) { return __builtin_amdgcn_readfirstlane(it - fdiv(it, rNCOG) * ncog); };
   int fw_cog = cog_of(fw_item);
   const int cog_step = cog_of(istride);   // the column block advances by istride mod ncog per item: scalar adds, no division in the loop
@@ -427,7 +447,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
   };
   int cur_n, cur_z0, cur_y0, cur_x0, cur_cog, cur_tile;
   decode(item, cur_n, cur_z0, cur_y0, cur_x0, cur_cog, cur_tile);
-  {
+  if (sc_first > 0) {   // (stream-K) this workgroup starts inside an item: a plain partial sum, bias and addend are in the other piece
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p][0] = acc[p][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
     const int vq = quad_voxel(cur_n, cur_z0, cur_y0, cur_x0), co = cur_cog * 32 + 16 * hh + 4 * kq;
     acc_init_plane(0, vq, co);
     acc_init_plane(1, vq, co);
@@ -453,7 +476,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
   for (;;) {
     const int next_item = item + istride;
     const bool more_items = next_item < ilimit;
-    for (int sc = 0; sc < NSC; ++sc) {
+    const int sc_b = item == first_item ? sc_first : 0, sc_e = more_items ? NSC : sc_last_end;   // (0, NSC unless stream-K cut the item)
+    for (int sc = sc_b; sc < sc_e; ++sc) {
       const float* ws = wbuf + ci_ * W2_W;
       const float* tcur = timg + ci_ * W2_T + bbase;
       const unsigned wdst1 = 2 * W2_RAW + 2 * W2_T + (ci_ ^ 1) * W2_W;   // (DMA destinations: float offsets inside the carve-up)
@@ -510,9 +534,19 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
     // ---- output transform Y = A^T M A (signs as explained above) + epilogue, plane by plane: 4 consecutive channels (co_lane ..)
     // of quad l16, packed fp32 math over the channel pairs (0, 1), (2, 3) of an accumulator (aligned register pairs).  After a
     // plane's accumulators have been read, the NEXT item's addend is requested into its corner points, then the plane is stored ----
-    const int co_lane = cur_cog * 32 + 16 * hh + 4 * kq;
-    const int vo_q = quad_voxel(cur_n, cur_z0, cur_y0, cur_x0);
+    int co_lane = cur_cog * 32 + 16 * hh + 4 * kq;
+    int vo_q = quad_voxel(cur_n, cur_z0, cur_y0, cur_x0);
     const int stat_slot = (cur_n * (ntz * nty * ntx) + cur_tile) * ncog + cur_cog;
+    // where the item's outputs go: y, or (stream-K, a cut item) this workgroup's slab 0 / 1 laid out as one 8^3 tile of 32 channels
+    const bool piece = sc_b > 0 || sc_e < NSC;
+    float* obase = y;
+    int oHW = H * W, oW = W, oC = Cout;
+    if (piece) {
+      obase = skws + (i64)(2 * sk_wg + (sc_b > 0 ? 0 : 1)) * (W2_TS * W2_TS * W2_TS * 32);
+      oHW = W2_TS * W2_TS, oW = W2_TS, oC = 32;
+      vo_q = ((2 * zw) * W2_TS + 2 * (l16 >> 2)) * W2_TS + 2 * (l16 & 3);
+      co_lane = 16 * hh + 4 * kq;
+    }
     int nco_lane = co_lane, nvo_q = vo_q;
     if (more_items) {
       decode(next_item, cur_n, cur_z0, cur_y0, cur_x0, cur_cog, cur_tile);
@@ -522,7 +556,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
     f32x2 s0p = {0.f, 0.f}, s1p = {0.f, 0.f};
 #pragma unroll
     for (int zz = 0; zz < 2; ++zz) {
-      const int vo00 = vo_q + zz * H * W;
+      const int vo00 = vo_q + zz * oHW;
       f32x2 v[2][2][2];   // [i][j][channel pair]
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
@@ -551,11 +585,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
 #ifdef W2_EXP_NOSTORE
           if (lo[0] == 123.456f)
 #endif
-          *reinterpret_cast<f32x4*>(y + (i64)(vo00 + i * W + j) * Cout + co_lane) = f32x4{lo[0], lo[1], hi[0], hi[1]};
+          *reinterpret_cast<f32x4*>(obase + (i64)(vo00 + i * oW + j) * oC + co_lane) = f32x4{lo[0], lo[1], hi[0], hi[1]};
         }
     }
     if (more_items) acc_init_rest(nco_lane);
-    if (stats) {
+    if (stats && !piece) {   // (the statistics of a cut item are taken by the finish pass)
       const float s0 = wave_sum(s0p[0] + s0p[1]), s1 = wave_sum(s1p[0] + s1p[1]);
       if (lane == 0) {
         float* dst = stats + ((i64)stat_slot * W2_NW + wave) * 2;
@@ -568,6 +602,53 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
     item = next_item;
   }
   w2_dma_wait();
+}
+
+// stream-K finish pass of the tile kernel: workgroup w - 1 of the grid owns the cut between the chunk ranges of the logical
+// workgroups w - 1 and w (w = 1 .. G - 1); if it falls inside an item, that item's outputs are slab 1 of w - 1 (the piece with
+// chunk 0: bias and addend inside) + slab 0 of w, added here, written to y, and the item's eight GroupNorm partial slots taken
+__global__ __launch_bounds__(512) void conv3d_k3_wino2d_sk_finish_kernel(const float* __restrict__ skws, float* __restrict__ y,
+                                                                         float* __restrict__ stats, int D, int H, int W, int Cout,
+                                                                         int ntz, int nty, int ntx, int ncog, int nitems, int NSC,
+                                                                         int sk_per) {
+  const int w = blockIdx.x + 1;
+  const long long cut = (long long)w * sk_per;
+  if (cut >= (long long)nitems * NSC || cut % NSC == 0) return;
+  const int item = (int)(cut / NSC);
+  const int cog = item % ncog;
+  int b = item / ncog;
+  const int tix = b % ntx; b /= ntx;
+  const int tiy = b % nty; b /= nty;
+  const int tiz = b % ntz;
+  const int n = b / ntz;
+  const int tile = (tiz * nty + tiy) * ntx + tix;
+  constexpr int SLAB = W2_TS * W2_TS * W2_TS * 32;
+  const f32x4* A = reinterpret_cast<const f32x4*>(skws + (i64)(2 * (w - 1) + 1) * SLAB);
+  const f32x4* B = reinterpret_cast<const f32x4*>(skws + (i64)(2 * w) * SLAB);
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int it = 0; it < SLAB / 4 / 512; ++it) {
+    const int idx = it * 512 + threadIdx.x;   // (voxel of the tile, channel quad)
+    const int v = idx >> 3, q = idx & 7;
+    const f32x4 a = A[idx], c = B[idx];
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[r] = a[r] + c[r];
+      s0 += o[r];
+      s1 = fmaf(o[r], o[r], s1);
+    }
+    const int lz = v >> 6, ly = (v >> 3) & 7, lx = v & 7;
+    *reinterpret_cast<f32x4*>(y + ((i64)((n * D + tiz * W2_TS + lz) * H + tiy * W2_TS + ly) * W + tix * W2_TS + lx) * Cout + cog * 32 + 4 * q) = o;
+  }
+  if (stats) {
+    s0 = wave_sum(s0), s1 = wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) {
+      float* dst = stats + ((i64)((n * (ntz * nty * ntx) + tile) * ncog + cog) * W2_NW + (threadIdx.x >> 6)) * 2;
+      dst[0] = s0;
+      dst[1] = s1;
+    }
+  }
 }
 
 // ================================================================================================================
@@ -951,16 +1032,40 @@ extern "C" long long seg3d_conv3d_k3_wino2d_stats_count(int N, int D, int H, int
   return (long long)(D / 4) * (H / 4) * (W / 4) * (Cout / 32) * 2;
 }
 
+// stream-K for the tile kernel: chunks per workgroup (0 = off).  Used when the plain walk would leave more than 6 % of the
+// CU-rounds empty (432 items on 256 CUs: the 24^3 level of the train step; 864: the same at inference batches, 48^3 32 -> 32)
+// and every workgroup's range is at least one item long (an item is then cut at most once)
+#ifndef W2_SK_FILL
+#define W2_SK_FILL 0.94
+#endif
+static int w2_sk_per(int N, int D, int H, int W, int Cin, int Cout) {
+  if (!w2_tiles(D, H, W)) return 0;
+  const long long nitems = w2_items(N, D, H, W, Cout), G = seg3d_device_cus();
+  const int NSC = Cin / 4;
+  if (nitems < G || NSC < 8 || nitems * NSC >= SEG3D_FDIV_MAX) return 0;
+  const long long rounds = (nitems + G - 1) / G;
+  if ((double)nitems / (double)(rounds * G) > W2_SK_FILL) return 0;
+  const long long per = (nitems * NSC + G - 1) / G;
+  return per >= NSC ? (int)per : 0;
+}
+// floats of workspace seg3d_conv3d_k3_wino2d_fwd_ws wants for this shape (two 8^3 x 32 slabs per workgroup; 0: none)
+extern "C" long long seg3d_conv3d_k3_wino2d_fwd_workspace_floats(int N, int D, int H, int W, int Cin, int Cout) {
+  if (!seg3d_conv3d_k3_wino2d_supported(N, D, H, W, Cin, Cout)) return 0;
+  return w2_sk_per(N, D, H, W, Cin, Cout) > 0 ? 2ll * seg3d_device_cus() * (W2_TS * W2_TS * W2_TS * 32) : 0;
+}
+
 // x [N][D][H][W][Cin], wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 48) (the F(2x2, 3x3) image), y [N][D][H][W][Cout];
-// bias, addend, stats as seg3d_conv3d_k3_mfma_fwd
-extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const float* bias, const float* addend, float* y,
-                                          float* stats, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+// bias, addend, stats as seg3d_conv3d_k3_mfma_fwd; workspace: seg3d_conv3d_k3_wino2d_fwd_workspace_floats floats, or null (no stream-K)
+extern "C" int seg3d_conv3d_k3_wino2d_fwd_ws(const float* x, const float* wp, const float* bias, const float* addend, float* y,
+                                             float* stats, float* workspace, int N, int D, int H, int W, int Cin, int Cout,
+                                             void* stream) {
   SEG3D_REQUIRE(x && wp && y, "seg3d_conv3d_k3_wino2d_fwd: null pointer");
   SEG3D_REQUIRE(seg3d_conv3d_k3_wino2d_supported(N, D, H, W, Cin, Cout),
                 "seg3d_conv3d_k3_wino2d_fwd: shape not supported (whole 4^3 cells, Cin %% 8 == 0, Cout %% 32 == 0)");
   const int ncog = Cout / 32;
   const int nitems = (int)w2_items(N, D, H, W, Cout);
-  dim3 grid(seg3d_persistent_grid(nitems), 1, 1);
+  const int sk_per = workspace ? w2_sk_per(N, D, H, W, Cin, Cout) : 0;
+  dim3 grid(sk_per > 0 ? (unsigned)seg3d_device_cus() : seg3d_persistent_grid(nitems), 1, 1);
   if (w2_tiles(D, H, W)) {
     static Seg3dOncePerDevice configured[4];
     if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_kernel<false, false>), configured[0], "conv3d_k3_wino2d")) return rc;
@@ -970,13 +1075,18 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
     const int ntz = D / W2_TS, nty = H / W2_TS, ntx = W / W2_TS;
 #define W2_LAUNCH(B_, A_)                                                                                                       \
   hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<B_, A_>), grid, dim3(64 * W2_NW), (size_t)W2_LDS_FLOATS * 4, (hipStream_t)stream, x, \
-                     wp, bias, y, stats, N, D, H, W, Cin, Cout, ntz, nty, ntx, ncog, nitems, addend)
+                     wp, bias, y, stats, N, D, H, W, Cin, Cout, ntz, nty, ntx, ncog, nitems, addend, sk_per, workspace)
     if (bias) {
       if (addend) W2_LAUNCH(true, true); else W2_LAUNCH(true, false);
     } else {
       if (addend) W2_LAUNCH(false, true); else W2_LAUNCH(false, false);
     }
 #undef W2_LAUNCH
+    if (sk_per > 0) {
+      SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_fwd");
+      hipLaunchKernelGGL(conv3d_k3_wino2d_sk_finish_kernel, dim3(grid.x - 1), dim3(512), 0, (hipStream_t)stream, workspace, y, stats, D,
+                         H, W, Cout, ntz, nty, ntx, ncog, nitems, Cin / 4, sk_per);
+    }
   } else {
     static Seg3dOncePerDevice configured[8];
     if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wino2d_c4_kernel<false, false, 4>), configured[0], "conv3d_k3_wino2d_c4")) return rc;
@@ -1009,6 +1119,12 @@ extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const
   }
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_fwd");
   return SEG3D_OK;
+}
+
+// the same without a workspace (every item whole in one workgroup)
+extern "C" int seg3d_conv3d_k3_wino2d_fwd(const float* x, const float* wp, const float* bias, const float* addend, float* y,
+                                          float* stats, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+  return seg3d_conv3d_k3_wino2d_fwd_ws(x, wp, bias, addend, y, stats, nullptr, N, D, H, W, Cin, Cout, stream);
 }
 
 // ================================================================================================================

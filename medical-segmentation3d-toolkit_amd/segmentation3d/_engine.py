@@ -95,6 +95,8 @@ _SIGNATURES = {
     'seg3d_conv3d_k3_wino2d_preferred': (_c_int, [_c_int] * 6),
     'seg3d_conv3d_k3_wino2d_stats_count': (_c_ll, [_c_int] * 6),
     'seg3d_conv3d_k3_wino2d_fwd': (_c_int, [_c_p] * 6 + [_c_int] * 6 + [_c_p]),
+    'seg3d_conv3d_k3_wino2d_fwd_workspace_floats': (_c_ll, [_c_int] * 6),
+    'seg3d_conv3d_k3_wino2d_fwd_ws': (_c_int, [_c_p] * 7 + [_c_int] * 6 + [_c_p]),
     'seg3d_conv3d_k3_wino2d_wgrad_supported': (_c_int, [_c_int] * 6),
     'seg3d_conv3d_k3_wino2d_wgrad_preferred': (_c_int, [_c_int] * 6),
     'seg3d_conv3d_k3_wino2d_wgrad_workspace_floats': (_c_ll, [_c_int] * 6),

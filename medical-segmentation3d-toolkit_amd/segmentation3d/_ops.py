@@ -8,6 +8,7 @@ module boundaries keep the reference's tensor shapes while the kernels see chann
 Fused unit (the reference's `ConvGnRelu3`, network/module/conv_gn_relu3.py:4-20, and the GN+ReLU tails of
 InputBlock/DownBlock/UpBlock/OutputBlock):   out = act( GN_1(conv(x) + b) [+ residual] )
 """
+import contextlib
 import ctypes
 
 import torch
@@ -25,6 +26,22 @@ FORCE_DIRECT = False
 # C -> C 3x3x3 forward / data-gradient at the big levels: Winograd F(2, 3) along x (False: the direct implicit GEMM everywhere)
 WINOGRAD = True
 WINOGRAD2D = True    # F(2x2, 3x3) over (y, x) where it is preferred, else F(2, 3) along x
+STREAM_K = True      # F(2x2, 3x3) tile kernel: stream-K chunk ranges where whole items would fill the CUs' rounds badly (432 / 864 items)
+_TWO_FORWARDS = 0    # > 0 inside two_forwards(): see there
+
+
+@contextlib.contextmanager
+def two_forwards():
+    """two forwards are being enqueued on two streams (core/seg_infer._forward_two_streams): the CUs a launch leaves idle in its
+    last round are taken by the other stream's kernels, so stream-K has nothing to win there and its finish pass is pure cost
+    (measured: 512x512x400 job 0.843 s with whole items, 0.857 s with stream-K; the one-stream train step 14.64 -> 14.51 ms WITH
+    it).  The choice is made when a launch is enqueued, so it is part of a captured hipGraph."""
+    global _TWO_FORWARDS
+    _TWO_FORWARDS += 1
+    try:
+        yield
+    finally:
+        _TWO_FORWARDS -= 1
 
 # bf16 mode (BASELINE config 5): activations between fused units and the gradients handed to the conv kernels are bf16,
 # packed k3 weights are bf16 (fp32 master weights), accumulation / conv outputs / GroupNorm statistics / losses fp32.
@@ -307,8 +324,12 @@ def _conv_k3_generic(xn, w, bias, A, B, sa, sb, flip, want_stats, addend=None, o
         stats = None
         if want_stats:
             stats = _empty((N, E.query('seg3d_conv3d_k3_wino2d_stats_count', N, D, H, W_, A, B), 2), xn)
-        E.call('seg3d_conv3d_k3_wino2d_fwd', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(addend), E.ptr(y), E.ptr(stats), N, D, H,
-               W_, A, B, E.stream_ptr())
+        # stream-K partial slabs where the (tile, column block) items would fill the CUs' rounds badly (the 24^3 level); a fresh block
+        # of the caching allocator per call: two forwards on two streams never share one
+        nws = E.query('seg3d_conv3d_k3_wino2d_fwd_workspace_floats', N, D, H, W_, A, B) if (STREAM_K and not _TWO_FORWARDS) else 0
+        ws = _empty((nws,), xn) if nws else None
+        E.call('seg3d_conv3d_k3_wino2d_fwd_ws', E.ptr(xn), E.ptr(wp), E.ptr(bias), E.ptr(addend), E.ptr(y), E.ptr(stats), E.ptr(ws),
+               N, D, H, W_, A, B, E.stream_ptr())
         return y, stats
     if _use_mfma(A, B) and WINOGRAD and E.query('seg3d_conv3d_k3_wino_preferred', N, D, H, W_, A, B):
         # the big levels: Winograd F(2, 3) along x, 2/3 of the fp32 MFMAs (csrc/conv_wino.hip); T = 36 = transformed image

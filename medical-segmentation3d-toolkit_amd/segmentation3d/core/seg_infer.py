@@ -290,9 +290,10 @@ def _forward_two_streams(net, batch, side):
     h = P // 2
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        out_b = net(batch[h:])
-    out_a = net(batch[:h])
+    with _ops.two_forwards():
+        with torch.cuda.stream(side):
+            out_b = net(batch[h:])
+        out_a = net(batch[:h])
     cur.wait_stream(side)
     out_b.record_stream(cur)
     return torch.cat([out_a, out_b], 0)

@@ -27,7 +27,7 @@ GRAD_BAR = {'headline': 1.0e-3,      # 4.2e-4
             'vnet15_dice': 3.0e-3,   # 1.5e-3
             'vnet15_focal': 7.0e-3}  # 3.3e-3
 
-WINO_FWD = 'seg3d_conv3d_k3_wino2d_fwd'
+WINO_FWD = 'seg3d_conv3d_k3_wino2d_fwd_ws'
 WINO_WGRADS = ('seg3d_conv3d_k3_wino2d_wgrad', 'seg3d_conv3d_k3_wino_wgrad')
 
 

@@ -136,7 +136,7 @@ def test_conv3d_k3_bench_variants_full_size(hip_device, shape, variant, form, mo
     report(name, **e)
     assert e['out'] < 1e-4 and e['dx'] < 1e-4 and e['dw'] < 2e-4 and e['dw_acc'] < 2e-4, e
     assert e['stat_sum'] < 1e-5 and e['stat_sq'] < 1e-5, e
-    fwd_name = {'direct': 'seg3d_conv3d_k3_mfma_fwd', 'wino': 'seg3d_conv3d_k3_wino_fwd', 'wino2d': 'seg3d_conv3d_k3_wino2d_fwd'}[form]
+    fwd_name = {'direct': 'seg3d_conv3d_k3_mfma_fwd', 'wino': 'seg3d_conv3d_k3_wino_fwd', 'wino2d': 'seg3d_conv3d_k3_wino2d_fwd_ws'}[form]
     assert called.count(fwd_name) == 2, called                        # forward + data-gradient
     wg = [c for c in called if c.endswith('_wgrad')]
     if form == 'direct':
@@ -218,6 +218,63 @@ def test_conv3d_k3_winograd(hip_device, shape, flip, form):
     y5 = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
     E.call('seg3d_conv3d_k3_{}_fwd'.format(form), E.ptr(xn), E.ptr(wp), E.ptr(bd), E.ptr(an), E.ptr(y5), None, N, D, H, W, Cin, Cout, E.stream_ptr())
     assert torch.equal(y5, y)
+
+
+@pytest.mark.parametrize('shape', [(4, 128, 128, 24, 24, 24),    # 432 items of 32 chunks on 256 CUs: the 24^3 level of the train step
+                                   (4, 32, 32, 48, 48, 48),       # 864 items of 8 chunks: ranges of 27 chunks, three or four items each
+                                   (3, 32, 64, 32, 40, 24),       # 360 items: ranges of 12 chunks, the last workgroups empty
+                                   (1, 64, 32, 64, 48, 48)])      # 288 items of 16 chunks, one column block
+def test_conv3d_k3_wino2d_stream_k(hip_device, shape):
+    """stream-K form of the F(2x2, 3x3) tile kernel (seg3d_conv3d_k3_wino2d_fwd_ws with its workspace: contiguous chunk ranges per
+    workgroup, cut items finished by conv3d_k3_wino2d_sk_finish_kernel) against the float64 convolution, against the same entry
+    point without a workspace (whole items per workgroup), the statistics slots of cut and uncut items, all four bias / addend
+    instantiations, and run to run bitwise the same"""
+    from segmentation3d import _ops, _engine as E
+    N, Cin, Cout, D, H, W = shape
+    nws = E.query('seg3d_conv3d_k3_wino2d_fwd_workspace_floats', N, D, H, W, Cin, Cout)
+    assert nws > 0, 'shape was chosen to take the stream-K path'
+    assert E.query('seg3d_conv3d_k3_wino2d_fwd_workspace_floats', 8, 96, 96, 96, 32, 32) == 0    # whole rounds: no stream-K
+    assert E.query('seg3d_conv3d_k3_wino2d_fwd_workspace_floats', 4, 12, 12, 12, 128, 128) == 0   # cells
+    x = _t(35, 'skx', (N, Cin, D, H, W))
+    w = _t(36, 'skw', (Cout, Cin, 3, 3, 3), std=(2.0 / (Cin * 27)) ** 0.5)
+    b = _t(37, 'skb', (Cout,), std=0.1)
+    ad = _t(38, 'ska', (N, Cout, D, H, W))
+    xn = _ops.to_ndhwc(x.to(hip_device))
+    an = _ops.to_ndhwc(ad.to(hip_device))
+    wd, bd = w.to(hip_device), b.to(hip_device)
+    wp = torch.empty((E.query('seg3d_packed_mfma_floats', Cin, Cout, 48),), device=hip_device)
+    E.call('seg3d_pack_weights_mfma', E.ptr(wd), E.ptr(wp), Cin, Cout, 48, 27, Cin * 27, 0, E.stream_ptr())
+    nst = E.query('seg3d_conv3d_k3_wino2d_stats_count', N, D, H, W, Cin, Cout)
+
+    def run(bias, addend, stats, workspace):
+        y = torch.full((N, D, H, W, Cout), float('nan'), device=hip_device)
+        st = torch.full((N, nst, 2), float('nan'), device=hip_device) if stats else None
+        ws = torch.full((nws,), float('nan'), device=hip_device) if workspace else None
+        E.call('seg3d_conv3d_k3_wino2d_fwd_ws', E.ptr(xn), E.ptr(wp), E.ptr(bd) if bias else None, E.ptr(an) if addend else None,
+               E.ptr(y), E.ptr(st), E.ptr(ws), N, D, H, W, Cin, Cout, E.stream_ptr())
+        return y, st
+
+    y, st = run(True, True, True, True)
+    y0, st0 = run(True, True, True, False)
+    ref = F.conv3d(x.double(), w.double(), b.double(), padding=1) + ad.double()
+    got = _ops.from_ndhwc(y).double().cpu()
+    scale = float(ref.abs().max())
+    err, err0 = float((got - ref).abs().max()), float((_ops.from_ndhwc(y0).double().cpu() - ref).abs().max())
+    report('wino2d_stream_k_{}'.format('_'.join(map(str, shape))), max_abs_err=err, whole_items_err=err0, out_scale=scale,
+           items_differ=float((y != y0).reshape(N, -1).any(1).sum()))
+    assert err < 1e-5 * scale and err < 2.0 * err0 + 1e-6 * scale, (err, err0, scale)
+    assert not torch.equal(y, y0), 'a cut item is summed in two pieces: the stream-K path did not run'
+    s = st.double().sum(1).cpu()
+    rr = got.reshape(N, -1)
+    assert float(((s[:, 0] - rr.sum(1)).abs() / rr.abs().sum(1)).max()) < 1e-5 and rel_err(s[:, 1], (rr * rr).sum(1)) < 1e-5
+    assert torch.isfinite(st).all()   # every slot of every item written exactly by one of the two kernels
+    assert rel_err(st.double().sum(1), st0.double().sum(1)) < 1e-5
+    for bias, addend in ((False, False), (True, False), (False, True)):
+        y2, _ = run(bias, addend, False, True)
+        full = y2 + (0 if bias else bd) + (0 if addend else an)
+        assert float((full - y).abs().max()) < 2e-6 * scale, (bias, addend)
+    y5, st5 = run(True, True, True, True)
+    assert torch.equal(y5, y) and torch.equal(st5, st)
 
 
 @pytest.mark.parametrize('shape', [(1, 32, 32, 8, 8, 16), (2, 16, 48, 4, 8, 8), (1, 64, 32, 12, 12, 12), (3, 8, 40, 8, 4, 24),

@@ -336,20 +336,47 @@ __device__ __forceinline__ void pack_mfma_chunk(const Seg3dPackJob& jb, int chun
   __syncthreads();
   // packed order inside the chunk: [t][h][j][r]  with a = 4 h + r, b = j
   constexpr int HW = AW / 2;   // channels per half
-  if constexpr (WINO != 0 && !BF) {
+  if constexpr (WINO == SEG3D_WINO2D_T && !BF) {
+    // one thread per (h, r, j) = one (a, b) pair of the chunk: its 27 taps once from the tile (stride 27 over j: conflict-free),
+    // all 3 x 16 transformed values in registers (the arithmetic of seg3d_wino2d_u, term by term), written as the twelve 16-byte
+    // words [g] of the image -- for one g the 32 lanes j of a (h, r) write 512 contiguous bytes.  (Round 4's first form computed
+    // every one of the 12 288 outputs on its own: nine tile reads, an index decode and the transform per element, 143 us per step.)
+    static_assert(AW == 8, "the T = 48 image is an fp32 image");
+    const int j = threadIdx.x & 31, r = (threadIdx.x >> 5) & 3, h = threadIdx.x >> 7;
+    const float* g = tile + ((HW * h + r) * 32 + j) * 27;
+    float gl[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) gl[i] = g[jb.flip ? 26 - i : i];
+    float u[48];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        float rw[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) rw[ky] = seg3d_wino_u(gl[(kz * 3 + ky) * 3], gl[(kz * 3 + ky) * 3 + 1], gl[(kz * 3 + ky) * 3 + 2], px);
+#pragma unroll
+        for (int py = 0; py < 4; ++py) u[kz * 16 + py * 4 + px] = seg3d_wino_u(rw[0], rw[1], rw[2], py);
+      }
+    float* dst = jb.wp + (i64)chunk * (AW * 32 * WINO) + ((h * 12) * 4 + r) * 128 + j * 4;
+#pragma unroll
+    for (int gq = 0; gq < 12; ++gq) {
+      seg3d_f32x4 o;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) o[s4] = u[seg3d_w2_step_t(4 * gq + s4)];
+      *reinterpret_cast<seg3d_f32x4*>(dst + gq * 512) = o;
+    }
+    return;
+  }
+  if constexpr (WINO == SEG3D_WINO_T && !BF) {
     const int nw = AW * 32 * WINO;
     for (int i = threadIdx.x; i < nw; i += 256) {
-      int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, tw = i / (HW * 64);
-      if constexpr (WINO == SEG3D_WINO2D_T) seg3d_wino2d_decode(i, h, r, j, tw);
+      const int r = i % HW, j = (i / HW) & 31, h = (i / (HW * 32)) & 1, tw = i / (HW * 64);
       const float* g = tile + ((HW * h + r) * 32 + j) * 27;
-      if constexpr (WINO == SEG3D_WINO_T) {
-        const int t9 = tw >> 2;
-        const float g0 = g[jb.flip ? 26 - 3 * t9 : 3 * t9], g1 = g[jb.flip ? 25 - 3 * t9 : 3 * t9 + 1],
-                    g2 = g[jb.flip ? 24 - 3 * t9 : 3 * t9 + 2];
-        jb.wp[(i64)chunk * nw + i] = seg3d_wino_u(g0, g1, g2, tw & 3);
-      } else {
-        jb.wp[(i64)chunk * nw + i] = seg3d_wino2d_u(g, jb.flip, tw);
-      }
+      const int t9 = tw >> 2;
+      const float g0 = g[jb.flip ? 26 - 3 * t9 : 3 * t9], g1 = g[jb.flip ? 25 - 3 * t9 : 3 * t9 + 1],
+                  g2 = g[jb.flip ? 24 - 3 * t9 : 3 * t9 + 2];
+      jb.wp[(i64)chunk * nw + i] = seg3d_wino_u(g0, g1, g2, tw & 3);
     }
     return;
   }

@@ -703,6 +703,40 @@ def test_bf16_multi_pack_equals_single_pack(hip_device):
             k += 1
 
 
+def test_fp32_multi_pack_equals_single_pack(hip_device):
+    """PackedWeightCache.repack_all() in fp32: ONE launch (pack_mfma_multi_kernel) refreshes the 27-tap images, the Winograd
+    F(2, 3) (T = 36) and F(2x2, 3x3) (T = 48: one thread per channel pair, twelve 16-byte words each) images and the 8-tap
+    stride-2 images; every image equals the per-tensor pack kernel's bit for bit, both weight orientations (the data-gradient
+    one with flipped taps), partial channel blocks included"""
+    from segmentation3d import _ops, _engine as E
+    cache = _ops.PackedWeightCache()
+    cache.enabled = True
+    specs = [(32, 32), (64, 16), (16, 48), (256, 128), (40, 72)]
+    ws, images = [], []
+    for k, (cin, cout) in enumerate(specs):
+        w = _t(180 + k, 'pk32', (cout, cin, 3, 3, 3), std=0.1).to(hip_device)
+        ws.append(w)
+        for T in (27, 36, 48):
+            images.append(cache.get(w, cin, cout, T, 27, cin * 27, 0))          # forward orientation
+            images.append(cache.get(w, cout, cin, T, cin * 27, 27, 1))          # data-gradient orientation
+    w8 = _t(190, 'pk8', (32, 16, 2, 2, 2), std=0.1).to(hip_device)               # stride-2 conv 16 -> 32
+    img8 = cache.get(w8, 16, 32, 8, 8, 16 * 8, 0)
+    for w in ws + [w8]:
+        w.mul_(1.5).add_(0.01)
+    cache.repack_all()
+    k = 0
+    for w, (cin, cout) in zip(ws, specs):
+        for T in (27, 36, 48):
+            for (A, B, sa, sb, flip) in ((cin, cout, 27, cin * 27, 0), (cout, cin, cin * 27, 27, 1)):
+                ref = torch.full((E.query('seg3d_packed_mfma_floats', A, B, T),), float('nan'), device=hip_device)
+                E.call('seg3d_pack_weights_mfma', E.ptr(w), E.ptr(ref), A, B, T, sa, sb, flip, E.stream_ptr())
+                assert torch.equal(images[k].view(torch.int32).cpu(), ref.view(torch.int32).cpu()), (cin, cout, T, flip)
+                k += 1
+    ref = torch.empty((E.query('seg3d_packed_mfma_floats', 16, 32, 8),), device=hip_device)
+    E.call('seg3d_pack_weights_mfma', E.ptr(w8), E.ptr(ref), 16, 32, 8, 8, 16 * 8, 0, E.stream_ptr())
+    assert torch.equal(img8.view(torch.int32).cpu(), ref.view(torch.int32).cpu())
+
+
 @pytest.mark.parametrize('shape', [(1, 32, 32, 16, 16, 16), (2, 48, 20, 4, 12, 20), (4, 256, 256, 6, 6, 6)])
 def test_conv3d_k3_bf16_out_bf16_is_rounded_fp32(hip_device, shape):
     """out_bf16 = 1 (data-gradient outputs): the stored tensor is exactly the bf16 rounding of what the fp32-output

@@ -16,6 +16,7 @@
 // with T = 8 (chunk image [8][half][32][4]).
 #include "seg3d_common.h"
 #include "seg3d_hip.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -283,6 +284,152 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
   }
 }
 
+#ifdef K2_STAMPS   // diagnostic build only (tools/ubench/k2_stamp.hip): s_memtime stamps of every wave of the direct gather kernel
+__device__ long long* k2_stamp_buf;
+#define K2_STAMP(k)                                                                                                          \
+  do {                                                                                                                       \
+    if ((threadIdx.x & 63) == 0)                                                                                             \
+      k2_stamp_buf[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define K2_STAMP(k)
+#endif
+// The gather kernel WITHOUT LDS (round 4): a lane of the 32x32 MFMA needs, per tap and 8-channel chunk, exactly the four
+// channels 4 lh .. 4 lh + 3 of ITS voxel's input voxel and the four weights (k = 4 lh + r, co = li) of the packed image -- one
+// 16-byte load each, the second perfectly coalesced (the T = 8 image is [tap][half][co][4]).  So nothing is staged and nothing
+// is shared: no barrier in the K loop, every wave runs on its own with the operands of TWO chunks in flight (a tap's registers
+// are refilled right behind its MFMAs), and the other waves of the SIMD cover the latency.  The staged kernel above spent its
+// time between barriers (wave cycles waiting 0.54-0.69, matrix pipe busy 0.13-0.35: profiles/r04_c_pmc_sq_summary.txt);
+// its tiles, grid, statistics slots and epilogue are kept.  The weights of a column block are re-read by every wave that
+// works on it (8 KB per chunk from L1 / L2: 64 B/clk/CU against 16 KB per 2 048 MFMA cycles).
+template <int MODE, bool OUT_BF = false, int NSET = 2>
+__global__ __launch_bounds__(256, 2) void conv3d_k2s2_direct_kernel(const void* __restrict__ x, const float* __restrict__ wp,
+                                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                                      float* __restrict__ stats, int N, int Do, int Ho, int Wo,
+                                                                      int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
+                                                                      int ntx, int ldx) {
+  __shared__ float red[8];
+  K2_STAMP(0);
+  const int MT = TZ * TY * TX;
+  const int Di = 2 * Do, Hi = 2 * Ho, Wi = 2 * Wo;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  constexpr int CPH = K2In<MODE>::CPH, CPC = 2 * CPH, ESZ = K2In<MODE>::ESZ;
+  const int CIB = (Cin + CPC - 1) / CPC;
+  const int cob = blockIdx.y;
+  const int lgTX = __builtin_ctz(TX), lgTY = __builtin_ctz(TY);
+  int b = blockIdx.x;
+  int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
+  const int tix = b - qd * ntx; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)nty);
+  const int tiy = b - qd * nty; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)ntz);
+  const int tiz = b - qd * ntz;
+  const int n = qd;
+  // this lane's output voxel and the byte offset of its 2^3 input cell inside the sample (K2_OOB: past the tile / the volume)
+  int vo = -1;
+  unsigned xoff = K2_OOB;
+  {
+    const int idx = wave * 32 + li;
+    const int tx = idx & (TX - 1), t = idx >> lgTX;
+    const int ty = t & (TY - 1), tz = t >> lgTY;
+    const int gz = tiz * TZ + tz, gy = tiy * TY + ty, gx = tix * TX + tx;
+    if (idx < MT && gz < Do && gy < Ho && gx < Wo) {
+      vo = ((n * Do + gz) * Ho + gy) * Wo + gx;
+      xoff = (unsigned)((((2 * gz * Hi + 2 * gy) * Wi + 2 * gx) * ldx + lh * CPH) * ESZ);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xrs = k2_make_rsrc(reinterpret_cast<const char*>(x) + (i64)n * Di * Hi * Wi * ldx * ESZ,
+                                                  (unsigned)Di * Hi * Wi * ldx * ESZ);
+  // K order: the (kx, channel) run of a (kz, ky) pair is 2 Cin contiguous floats of the input (ldx == Cin), and a STEP is four
+  // consecutive 8-channel chunks of it -- 128 contiguous bytes per lane's voxel, one cache line, requested by four back-to-back
+  // instructions.  (Chunk-major order -- all eight taps of chunk 0, then chunk 1, ... -- used 32 bytes of a line per visit and came
+  // back for the rest a whole chunk later, when the line had left the 32-KB L1: every chunk re-fetched whole lines from L2 and the
+  // launch ran at the L1 fill rate, 16 useful B/clk/CU: 23 600 of a wave's 59 700 cycles passed before its first MFMA.)
+  const int SPR = CIB >> 1;                      // steps per (kz, ky) run; host-checked: CIB even
+  const int NS = 4 * SPR;
+  const f32x4* wbase = reinterpret_cast<const f32x4*>(wp + (i64)cob * CIB * K2_W_CHUNK) + lane;   // + (cib * 8 + tap) * 64
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // NSET steps in flight (a ring of register sets): 2 where enough waves share a SIMD to cover the latency, 4 for the deep-K
+  // layers of the lower levels, whose grids leave a wave alone on its SIMD (host: k2_gather_launch)
+  typename K2In<MODE>::raw xv[NSET][4];
+  f32x4 wv[NSET][4];
+  int ld_run = 0, ld_piece = 0;   // (kz, ky) run and 128-byte piece of the step being fetched: scalar counters, no division
+  auto load_step = [&](int set, int j) __attribute__((always_inline)) {   // (set, j: constants after unrolling)
+    const int q = ld_piece * 4 + j;
+    const int kx = q >= CIB ? 1 : 0, cib = q - kx * CIB;
+    const int kz = ld_run >> 1, ky = ld_run & 1;
+    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((((kz * Hi + ky) * Wi + kx) * ldx + cib * CPC) * ESZ));
+    const unsigned hk = cib * CPC + lh * CPH < Cin ? 0u : K2_OOB;   // (a half past the last channel: zeros)
+    xv[set][j] = K2In<MODE>::bload(xrs, xoff | hk, soff);
+    wv[set][j] = wbase[__builtin_amdgcn_readfirstlane((cib * 8 + ld_run * 2 + kx) * 64)];
+  };
+  auto load_advance = [&]() __attribute__((always_inline)) {
+    if (++ld_piece == SPR) ld_piece = 0, ++ld_run;
+  };
+  // the refills are UNCONDITIONAL inside their blocks (a load behind a branch makes the compiler's s_waitcnt bookkeeping assume
+  // the worst at the join: a first version waited for vmcnt(0), i.e. for the refills it had just issued), the tail is peeled
+#pragma unroll
+  for (int set = 0; set < NSET; ++set) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_step(set, j);
+    load_advance();
+  }
+  K2_STAMP(1);
+  for (int st = 0; st + 2 * NSET <= NS; st += NSET) {   // steps st .. st + NSET - 1 multiplied, the NSET behind them requested
+#pragma unroll
+    for (int set = 0; set < NSET; ++set) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc = k2_mfma_step<MODE>(wv[set][j], K2In<MODE>::cvt(xv[set][j]), acc);
+        load_step(set, j);
+      }
+      load_advance();
+    }
+  }
+#pragma unroll
+  for (int set = 0; set < NSET; ++set)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = k2_mfma_step<MODE>(wv[set][j], K2In<MODE>::cvt(xv[set][j]), acc);
+  K2_STAMP(2);
+
+  float s[2] = {0.f, 0.f};
+  {
+    const int co0 = cob * 32 + 4 * lh;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int co = co0 + 8 * g4;
+      if (vo >= 0 && co < Cout) {   // Cout % 4 == 0 (host-checked)
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + co);
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[c] = acc[4 * g4 + c] + bv[c];
+          s[0] += v[c];
+          s[1] += v[c] * v[c];
+        }
+        Seg3dQuad<OUT_BF>::store(y, (i64)vo * Cout + co, v);
+      }
+    }
+  }
+  K2_STAMP(3);
+  if (stats) {
+    block_sum_256<2>(s, red);
+    if (tid == 0) {
+      const int tiles_per_sample = ntz * nty * ntx;
+      const int tile = (tiz * nty + tiy) * ntx + tix;
+      float* dst = stats + (((i64)n * tiles_per_sample + tile) * gridDim.y + cob) * 2;
+      dst[0] = s[0];
+      dst[1] = s[1];
+    }
+  }
+  K2_STAMP(4);
+}
+
 extern "C" long long seg3d_conv3d_k2s2_mfma_stats_count(int Do, int Ho, int Wo, int Cout) {
   K2Tile t = k2_pick_tile(Do, Ho, Wo);
   return (long long)seg3d_cdiv(Do, t.tz) * seg3d_cdiv(Ho, t.ty) * seg3d_cdiv(Wo, t.tx) * ((Cout + 31) / 32);
@@ -308,9 +455,22 @@ static int k2_gather_launch(const void* x, int x_bf16, const float* wp, const fl
   dim3 grid((unsigned)(N * ntz * nty * ntx), (unsigned)((Cout + 31) / 32));
   // x_bf16: 0 = fp32 input, 1 = bf16 input widened while staging (fp32 weight image), 2 = bf16 input + bf16 weight image
   SEG3D_REQUIRE(x_bf16 != 2 || (Cin % 16) == 0, "seg3d_conv3d_k2s2_bf16_fwd: the bf16 weight image needs Cin %% 16 == 0");
+#ifndef K2_GATHER_DIRECT
+#define K2_GATHER_DIRECT 1   // 0: the LDS-staged kernel (kept for same-box A/B builds)
+#endif
 #define K2_GATHER(MODE_, OB_)                                                                                        \
-  hipLaunchKernelGGL((conv3d_k2s2_mfma_kernel<MODE_, OB_>), grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, stats, \
-                     N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ldx)
+  do {                                                                                                               \
+    const int cib_ = (Cin + (MODE_ == 2 ? 15 : 7)) / (MODE_ == 2 ? 16 : 8);   /* 2 cib_ steps of four chunks */      \
+    if (K2_GATHER_DIRECT && cib_ % 2 == 0 && cib_ % 4 == 0 && (i64)grid.x * grid.y * 4 <= 2 * 1024)                 \
+      hipLaunchKernelGGL((conv3d_k2s2_direct_kernel<MODE_, OB_, 4>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
+                         stats, N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ldx);                     \
+    else if (K2_GATHER_DIRECT && cib_ % 2 == 0)                                                                      \
+      hipLaunchKernelGGL((conv3d_k2s2_direct_kernel<MODE_, OB_, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
+                         stats, N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ldx);                     \
+    else                                                                                                             \
+      hipLaunchKernelGGL((conv3d_k2s2_mfma_kernel<MODE_, OB_>), grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, \
+                         stats, N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ldx);                     \
+  } while (0)
   if (x_bf16 == 2 && out_bf16) K2_GATHER(2, true);
   else if (x_bf16 == 2) K2_GATHER(2, false);
   else if (x_bf16 && out_bf16) K2_GATHER(1, true);

@@ -274,12 +274,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_mfma_kernel(const void* __
   if (stats) {
     __syncthreads();
     block_sum_256<2>(s, xs);
-    if (tid == 0) {
+    if (tid < 4) {   // slots [tile][4][column block] (the direct kernel's waves write one each): the tile's sums in the first
       const int tiles_per_sample = ntz * nty * ntx;
       const int tile = (tiz * nty + tiy) * ntx + tix;
-      float* dst = stats + (((i64)n * tiles_per_sample + tile) * gridDim.y + cob) * 2;
-      dst[0] = s[0];
-      dst[1] = s[1];
+      float* dst = stats + ((((i64)n * tiles_per_sample + tile) * 4 + tid) * gridDim.y + cob) * 2;
+      dst[0] = tid == 0 ? s[0] : 0.f;
+      dst[1] = tid == 0 ? s[1] : 0.f;
     }
   }
 }
@@ -302,13 +302,23 @@ __device__ long long* k2_stamp_buf;
 // time between barriers (wave cycles waiting 0.54-0.69, matrix pipe busy 0.13-0.35: profiles/r04_c_pmc_sq_summary.txt);
 // its tiles, grid, statistics slots and epilogue are kept.  The weights of a column block are re-read by every wave that
 // works on it (8 KB per chunk from L1 / L2: 64 B/clk/CU against 16 KB per 2 048 MFMA cycles).
-template <int MODE, bool OUT_BF = false, int NSET = 2>
+// NCOB = 2: a wave multiplies its voxels' operands into TWO column blocks (the input is read once where Cout >= 64: as separate
+//   workgroups the column blocks of a tile are dispatched a whole grid apart and the second read came from HBM again).
+// KSPLIT = 4 (the lower levels: a few hundred 32 x 32 wave tiles with K = 8 x 64 .. 8 x 256): the four waves of a workgroup share
+//   ONE 32-voxel sub-tile and take one (kz, ky) run each -- a quarter of K -- then add their accumulators through LDS in wave
+//   order 0..3 (fixed: run to run bitwise the same) and store one channel quad each.
+// Statistics slots: [sample][tile][4][column block] -- a wave's own sums (no barrier), or the sub-tile's with KSPLIT.
+template <int MODE, bool OUT_BF = false, int NCOB = 1, int KSPLIT = 1>
 __global__ __launch_bounds__(256, 2) void conv3d_k2s2_direct_kernel(const void* __restrict__ x, const float* __restrict__ wp,
                                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                                       float* __restrict__ stats, int N, int Do, int Ho, int Wo,
                                                                       int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
                                                                       int ntx, int ldx) {
-  __shared__ float red[8];
+  static_assert((KSPLIT == 1 || KSPLIT == 4) && (NCOB == 1 || NCOB == 2) && (KSPLIT == 1 || NCOB == 1), "variants");
+  constexpr int NSET = 2;   // steps in flight (a ring of register sets; four measured no faster, also alone on a SIMD)
+  __shared__ __attribute__((aligned(16))) float red[KSPLIT == 4 ? 4 * 16 * 64 : 8];
+  __shared__ __attribute__((aligned(16))) float tbuf[OUT_BF ? 4 : (KSPLIT == 4 ? 32 * 36 : 4 * 32 * 36)];   // epilogue transpose: [voxel 32][36] per wave
+  __shared__ int vos[OUT_BF ? 1 : (KSPLIT == 4 ? 32 : 128)];
   K2_STAMP(0);
   const int MT = TZ * TY * TX;
   const int Di = 2 * Do, Hi = 2 * Ho, Wi = 2 * Wo;
@@ -317,9 +327,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_direct_kernel(const void* 
   const int li = lane & 31, lh = lane >> 5;
   constexpr int CPH = K2In<MODE>::CPH, CPC = 2 * CPH, ESZ = K2In<MODE>::ESZ;
   const int CIB = (Cin + CPC - 1) / CPC;
-  const int cob = blockIdx.y;
+  const int cob0 = blockIdx.y * NCOB, ncob = gridDim.y * NCOB;
   const int lgTX = __builtin_ctz(TX), lgTY = __builtin_ctz(TY);
-  int b = blockIdx.x;
+  int b = KSPLIT == 4 ? blockIdx.x >> 2 : blockIdx.x;
+  const int sub = KSPLIT == 4 ? (int)(blockIdx.x & 3) : wave;   // 32-voxel quarter of the tile this wave works on
   int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
   const int tix = b - qd * ntx; b = qd;
   qd = seg3d_fdiv(b, 1.0f / (float)nty);
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_direct_kernel(const void* 
   int vo = -1;
   unsigned xoff = K2_OOB;
   {
-    const int idx = wave * 32 + li;
+    const int idx = sub * 32 + li;
     const int tx = idx & (TX - 1), t = idx >> lgTX;
     const int ty = t & (TY - 1), tz = t >> lgTY;
     const int gz = tiz * TZ + tz, gy = tiy * TY + ty, gx = tix * TX + tx;
@@ -347,17 +358,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_direct_kernel(const void* 
   // instructions.  (Chunk-major order -- all eight taps of chunk 0, then chunk 1, ... -- used 32 bytes of a line per visit and came
   // back for the rest a whole chunk later, when the line had left the 32-KB L1: every chunk re-fetched whole lines from L2 and the
   // launch ran at the L1 fill rate, 16 useful B/clk/CU: 23 600 of a wave's 59 700 cycles passed before its first MFMA.)
-  const int SPR = CIB >> 1;                      // steps per (kz, ky) run; host-checked: CIB even
-  const int NS = 4 * SPR;
-  const f32x4* wbase = reinterpret_cast<const f32x4*>(wp + (i64)cob * CIB * K2_W_CHUNK) + lane;   // + (cib * 8 + tap) * 64
-  f32x16 acc;
+  const int SPR = CIB >> 1;                      // steps per (kz, ky) run; host-checked: CIB even (KSPLIT: SPR even)
+  const int NS = KSPLIT == 4 ? SPR : 4 * SPR;    // steps of this wave
+  const f32x4* wbase = reinterpret_cast<const f32x4*>(wp + (i64)cob0 * CIB * K2_W_CHUNK) + lane;   // + (cib * 8 + tap) * 64
+  f32x16 acc[NCOB];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // NSET steps in flight (a ring of register sets): 2 where enough waves share a SIMD to cover the latency, 4 for the deep-K
-  // layers of the lower levels, whose grids leave a wave alone on its SIMD (host: k2_gather_launch)
+  for (int c = 0; c < NCOB; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
   typename K2In<MODE>::raw xv[NSET][4];
-  f32x4 wv[NSET][4];
-  int ld_run = 0, ld_piece = 0;   // (kz, ky) run and 128-byte piece of the step being fetched: scalar counters, no division
+  f32x4 wv[NSET][4][NCOB];
+  int ld_run = KSPLIT == 4 ? wave : 0, ld_piece = 0;   // (kz, ky) run and 128-byte piece of the step being fetched: scalar counters
   auto load_step = [&](int set, int j) __attribute__((always_inline)) {   // (set, j: constants after unrolling)
     const int q = ld_piece * 4 + j;
     const int kx = q >= CIB ? 1 : 0, cib = q - kx * CIB;
@@ -365,10 +376,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_direct_kernel(const void* 
     const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((((kz * Hi + ky) * Wi + kx) * ldx + cib * CPC) * ESZ));
     const unsigned hk = cib * CPC + lh * CPH < Cin ? 0u : K2_OOB;   // (a half past the last channel: zeros)
     xv[set][j] = K2In<MODE>::bload(xrs, xoff | hk, soff);
-    wv[set][j] = wbase[__builtin_amdgcn_readfirstlane((cib * 8 + ld_run * 2 + kx) * 64)];
+    const int wi = __builtin_amdgcn_readfirstlane((cib * 8 + ld_run * 2 + kx) * 64);
+#pragma unroll
+    for (int c = 0; c < NCOB; ++c) wv[set][j][c] = wbase[wi + c * CIB * (K2_W_CHUNK / 4)];
   };
   auto load_advance = [&]() __attribute__((always_inline)) {
     if (++ld_piece == SPR) ld_piece = 0, ++ld_run;
+  };
+  auto multiply = [&](int set, int j) __attribute__((always_inline)) {
+    const f32x4 xb = K2In<MODE>::cvt(xv[set][j]);
+#pragma unroll
+    for (int c = 0; c < NCOB; ++c) acc[c] = k2_mfma_step<MODE>(wv[set][j][c], xb, acc[c]);
   };
   // the refills are UNCONDITIONAL inside their blocks (a load behind a branch makes the compiler's s_waitcnt bookkeeping assume
   // the worst at the join: a first version waited for vmcnt(0), i.e. for the refills it had just issued), the tail is peeled
@@ -384,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_direct_kernel(const void* 
     for (int set = 0; set < NSET; ++set) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc = k2_mfma_step<MODE>(wv[set][j], K2In<MODE>::cvt(xv[set][j]), acc);
+        multiply(set, j);
         load_step(set, j);
       }
       load_advance();
@@ -393,38 +411,72 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_direct_kernel(const void* 
 #pragma unroll
   for (int set = 0; set < NSET; ++set)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc = k2_mfma_step<MODE>(wv[set][j], K2In<MODE>::cvt(xv[set][j]), acc);
+    for (int j = 0; j < 4; ++j) multiply(set, j);
   K2_STAMP(2);
 
-  float s[2] = {0.f, 0.f};
-  {
-    const int co0 = cob * 32 + 4 * lh;
+  if constexpr (KSPLIT == 4) {   // acc[0] of the four waves -> the sum's registers 4 wave .. 4 wave + 3 (channel quad g4 = wave)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][r];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = 4 * wave + c;
+      acc[0][c] = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
+    }
+    __syncthreads();   // (red is reused by the statistics)
+  }
+  K2_STAMP(3);
+  const int tile = (tiz * nty + tiy) * ntx + tix, tiles_per_sample = ntz * nty * ntx;
+  // fp32 outputs go through an LDS transpose: a lane owns 16-byte pieces of ITS voxel's row, so a store instruction wrote 64
+  // pieces 128 .. 512 bytes apart (tools/ubench/stride_load.hip: 3.6 TB/s at best, 1.0 TB/s at 256 bytes -- the 64-channel rows of
+  // the top level's data-gradient); transposed, eight consecutive lanes write the 128 contiguous bytes of a voxel's column block
+  constexpr int ROW = 36;                          // floats per voxel row in LDS: 32 + 4 (b128 writes of 16 lanes: conflict-free)
+  float* tr = KSPLIT == 4 ? tbuf : tbuf + wave * (32 * ROW);
+  if (!OUT_BF && lh == 0) vos[(KSPLIT == 4 ? 0 : wave * 32) + li] = vo;
+#pragma unroll
+  for (int c = 0; c < NCOB; ++c) {
+    float s[2] = {0.f, 0.f};
+    const int co0 = (cob0 + c) * 32 + 4 * lh;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      const int co = co0 + 8 * g4;
+      if (KSPLIT == 4 && g4 > 0) break;
+      const int gq = KSPLIT == 4 ? wave : g4;      // channel quad 8 gq + 4 lh of the column block
+      const int co = co0 + 8 * gq;
       if (vo >= 0 && co < Cout) {   // Cout % 4 == 0 (host-checked)
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (bias) bv = *reinterpret_cast<const f32x4*>(bias + co);
         f32x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          v[c] = acc[4 * g4 + c] + bv[c];
-          s[0] += v[c];
-          s[1] += v[c] * v[c];
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[c][4 * g4 + e] + bv[e];
+          s[0] += v[e];
+          s[1] += v[e] * v[e];
         }
-        Seg3dQuad<OUT_BF>::store(y, (i64)vo * Cout + co, v);
+        if (OUT_BF) Seg3dQuad<OUT_BF>::store(y, (i64)vo * Cout + co, v);
+        else *reinterpret_cast<f32x4*>(tr + li * ROW + 8 * gq + 4 * lh) = v;
       }
     }
-  }
-  K2_STAMP(3);
-  if (stats) {
-    block_sum_256<2>(s, red);
-    if (tid == 0) {
-      const int tiles_per_sample = ntz * nty * ntx;
-      const int tile = (tiz * nty + tiy) * ntx + tix;
-      float* dst = stats + (((i64)n * tiles_per_sample + tile) * gridDim.y + cob) * 2;
-      dst[0] = s[0];
-      dst[1] = s[1];
+    if constexpr (!OUT_BF) {
+      if (KSPLIT == 4) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int t = KSPLIT == 4 ? tid : lane;      // KSPLIT: the workgroup's 256 threads store the sub-tile's 32 rows at once
+#pragma unroll
+      for (int it = 0; it < (KSPLIT == 4 ? 1 : 4); ++it) {
+        const int v = it * 8 + (t >> 3), piece = t & 7;
+        const int vo_v = vos[(KSPLIT == 4 ? 0 : wave * 32) + v];
+        const int co = (cob0 + c) * 32 + 4 * piece;
+        if (vo_v >= 0 && co < Cout) *reinterpret_cast<f32x4*>(y + (i64)vo_v * Cout + co) = *reinterpret_cast<const f32x4*>(tr + v * ROW + 4 * piece);
+      }
+      if (NCOB > 1 || KSPLIT == 4) { if (KSPLIT == 4) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+    }
+    if (stats) {
+      float* dst = stats + ((((i64)n * tiles_per_sample + tile) * 4 + sub) * ncob + cob0 + c) * 2;
+      if constexpr (KSPLIT == 4) {
+        block_sum_256<2>(s, red);
+        if (tid == 0) dst[0] = s[0], dst[1] = s[1];
+      } else {
+        s[0] = wave_sum(s[0]), s[1] = wave_sum(s[1]);
+        if (lane == 0) dst[0] = s[0], dst[1] = s[1];
+      }
     }
   }
   K2_STAMP(4);
@@ -432,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k2s2_direct_kernel(const void* 
 
 extern "C" long long seg3d_conv3d_k2s2_mfma_stats_count(int Do, int Ho, int Wo, int Cout) {
   K2Tile t = k2_pick_tile(Do, Ho, Wo);
-  return (long long)seg3d_cdiv(Do, t.tz) * seg3d_cdiv(Ho, t.ty) * seg3d_cdiv(Wo, t.tx) * ((Cout + 31) / 32);
+  return (long long)seg3d_cdiv(Do, t.tz) * seg3d_cdiv(Ho, t.ty) * seg3d_cdiv(Wo, t.tx) * 4 * ((Cout + 31) / 32);   // [tile][4][column block]
 }
 
 // x [N][2Do][2Ho][2Wo][Cin] -> y [N][Do][Ho][Wo][Cout];  wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 8)
@@ -458,14 +510,20 @@ static int k2_gather_launch(const void* x, int x_bf16, const float* wp, const fl
 #ifndef K2_GATHER_DIRECT
 #define K2_GATHER_DIRECT 1   // 0: the LDS-staged kernel (kept for same-box A/B builds)
 #endif
+  // the direct kernel's variants: KSPLIT where 128-voxel tiles give fewer than two waves per SIMD and K is deep enough to deal
+  // out ((kz, ky) runs of at least two steps: Cin >= 32 in fp32), two column blocks per wave where that still leaves three
+  const i64 waves1 = (i64)grid.x * grid.y * 4;
 #define K2_GATHER(MODE_, OB_)                                                                                        \
   do {                                                                                                               \
     const int cib_ = (Cin + (MODE_ == 2 ? 15 : 7)) / (MODE_ == 2 ? 16 : 8);   /* 2 cib_ steps of four chunks */      \
-    if (K2_GATHER_DIRECT && cib_ % 2 == 0 && cib_ % 4 == 0 && (i64)grid.x * grid.y * 4 <= 2 * 1024)                 \
-      hipLaunchKernelGGL((conv3d_k2s2_direct_kernel<MODE_, OB_, 4>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
-                         stats, N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ldx);                     \
+    if (K2_GATHER_DIRECT && cib_ % 4 == 0 && waves1 < 3072)                                                          \
+      hipLaunchKernelGGL((conv3d_k2s2_direct_kernel<MODE_, OB_, 1, 4>), dim3(grid.x * 4, grid.y), dim3(256), 0,      \
+                         (hipStream_t)stream, x, wp, bias, y, stats, N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ldx); \
+    else if (K2_GATHER_DIRECT && cib_ % 2 == 0 && Cout % 64 == 0 && waves1 >= 16384)                                \
+      hipLaunchKernelGGL((conv3d_k2s2_direct_kernel<MODE_, OB_, 2, 1>), dim3(grid.x, grid.y / 2), dim3(256), 0,      \
+                         (hipStream_t)stream, x, wp, bias, y, stats, N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ldx); \
     else if (K2_GATHER_DIRECT && cib_ % 2 == 0)                                                                      \
-      hipLaunchKernelGGL((conv3d_k2s2_direct_kernel<MODE_, OB_, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
+      hipLaunchKernelGGL((conv3d_k2s2_direct_kernel<MODE_, OB_, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
                          stats, N, Do, Ho, Wo, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ldx);                     \
     else                                                                                                             \
       hipLaunchKernelGGL((conv3d_k2s2_mfma_kernel<MODE_, OB_>), grid, dim3(256), lds, (hipStream_t)stream, x, wp, bias, y, \

@@ -793,19 +793,175 @@ __global__ __launch_bounds__(256, 2) void convT3d_k2s2_mfma_kernel(const void* _
   if (stats) {
     __syncthreads();
     block_sum_256<2>(s, xs);
+    if (tid < 4) {   // slots [tile][4][column block] (the direct kernel: one per 32-voxel sub-tile): the tile's sums in the first
+      const int tiles_per_sample = ntz * nty * ntx;
+      const int tile = (tiz * nty + tiy) * ntx + tix;
+      float* dst = stats + ((((i64)n * tiles_per_sample + tile) * 4 + tid) * gridDim.y + cob) * 2;
+      dst[0] = tid == 0 ? s[0] : 0.f;
+      dst[1] = tid == 0 ? s[1] : 0.f;
+    }
+  }
+}
+
+// The scatter kernel WITHOUT operand staging (round 4), the counterpart of conv3d_k2s2_direct_kernel: a workgroup owns one
+// 32-voxel sub-tile and one column block, wave w the tap pair (kz, ky) = (w >> 1, w & 1), kx = 0, 1 -- whose outputs of one input
+// voxel are 2 Cout CONTIGUOUS floats.  Operands come straight from global memory into the MFMA registers (x: 16 bytes of the
+// lane's voxel row per chunk, two consecutive chunks per step; weights: the coalesced 1-KB image of a (chunk, tap)), a ring of two
+// steps in flight, no barrier in the K loop; four times the waves of the staged kernel, each with two accumulators instead of
+// eight (the lower levels had 48 - 432 workgroups on 256 CUs with K loops of 16 - 32 chunks).  The epilogue transposes through
+// LDS: eight consecutive lanes write (and, ADD, read the addend of) 128 contiguous bytes.
+// PAIR (Cout <= 16): ONE accumulator, rows 0..15 = kx 0, 16..31 = kx 1: the lanes read the standard image at their own offsets.
+template <int MODE, bool ADD, bool PAIR>
+__global__ __launch_bounds__(256, 2) void convT3d_k2s2_direct_kernel(const void* __restrict__ x, const float* __restrict__ wp,
+                                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                                       float* __restrict__ stats, int N, int Di, int Hi, int Wi,
+                                                                       int Cin, int Cout, int TZ, int TY, int TX, int ntz, int nty,
+                                                                       int ntx, const float* __restrict__ addend, int lda) {
+  constexpr int NSET = 2, NACC = PAIR ? 1 : 2, ROW = 36;
+  __shared__ __attribute__((aligned(16))) float tbuf[4 * 32 * ROW];   // epilogue transpose: per wave [voxel 32][36]
+  __shared__ int obs[32];
+  __shared__ float red[8];
+  const int MT = TZ * TY * TX;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  constexpr int CPH = K2In<MODE>::CPH, CPC = 2 * CPH, ESZ = K2In<MODE>::ESZ;
+  const int CIB = (Cin + CPC - 1) / CPC;
+  const int cob = blockIdx.y;
+  const int kz = wave >> 1, ky = wave & 1;
+  const int lgTX = __builtin_ctz(TX), lgTY = __builtin_ctz(TY);
+  int b = blockIdx.x >> 2;
+  const int sub = blockIdx.x & 3;
+  int qd = seg3d_fdiv(b, 1.0f / (float)ntx);
+  const int tix = b - qd * ntx; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)nty);
+  const int tiy = b - qd * nty; b = qd;
+  qd = seg3d_fdiv(b, 1.0f / (float)ntz);
+  const int tiz = b - qd * ntz;
+  const int n = qd;
+  unsigned xoff = K2_OOB;
+  {
+    const int idx = sub * 32 + li;
+    const int tx = idx & (TX - 1), t = idx >> lgTX;
+    const int ty = t & (TY - 1), tz = t >> lgTY;
+    const int gz = tiz * TZ + tz, gy = tiy * TY + ty, gx = tix * TX + tx;
+    int o = -1;
+    if (idx < MT && gz < Di && gy < Hi && gx < Wi) {
+      o = ((n * 2 * Di + 2 * gz) * Ho + 2 * gy) * Wo + 2 * gx;   // output voxel of tap (0, 0, 0)
+      xoff = (unsigned)((((gz * Hi + gy) * Wi + gx) * Cin + lh * CPH) * ESZ);
+    }
+    if (wave == 0 && lh == 0) obs[li] = o;
+  }
+  const __amdgpu_buffer_rsrc_t xrs = k2_make_rsrc(reinterpret_cast<const char*>(x) + (i64)n * Di * Hi * Wi * Cin * ESZ,
+                                                  (unsigned)Di * Hi * Wi * Cin * ESZ);
+  // this lane's weight quad of (chunk cib, accumulator a): float4 index (cib * 8 + tap) * 64 + half * 32 + co
+  const int tap0 = 4 * kz + 2 * ky;
+  const f32x4* wbase = reinterpret_cast<const f32x4*>(wp + (i64)cob * CIB * K2_W_CHUNK) +
+                       (PAIR ? (tap0 + (li >> 4)) * 64 + lh * 32 + (li & 15) : tap0 * 64 + lane);
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  typename K2In<MODE>::raw xv[NSET][2];
+  f32x4 wv[NSET][2][NACC];
+  int ld_cib = 0;
+  auto load_step = [&](int set, int j) __attribute__((always_inline)) {
+    const int cib = ld_cib + j;
+    const unsigned hk = cib * CPC + lh * CPH < Cin ? 0u : K2_OOB;
+    xv[set][j] = K2In<MODE>::bload(xrs, xoff | hk, __builtin_amdgcn_readfirstlane((unsigned)(cib * CPC * ESZ)));
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) wv[set][j][a] = wbase[__builtin_amdgcn_readfirstlane((cib * 8 + a) * 64)];
+  };
+  auto multiply = [&](int set, int j) __attribute__((always_inline)) {
+    const f32x4 xb = K2In<MODE>::cvt(xv[set][j]);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = k2_mfma_step<MODE>(wv[set][j][a], xb, acc[a]);
+  };
+  const int NS = CIB >> 1;   // steps of two chunks; host-checked: CIB % 4 == 0
+#pragma unroll
+  for (int set = 0; set < NSET; ++set) {
+    load_step(set, 0), load_step(set, 1);
+    ld_cib += 2;
+  }
+  for (int st = 0; st + 2 * NSET <= NS; st += NSET) {
+#pragma unroll
+    for (int set = 0; set < NSET; ++set) {
+      multiply(set, 0);
+      load_step(set, 0);
+      multiply(set, 1);
+      load_step(set, 1);
+      ld_cib += 2;
+    }
+  }
+#pragma unroll
+  for (int set = 0; set < NSET; ++set) multiply(set, 0), multiply(set, 1);
+
+  // ---- epilogue: bias, statistics, transpose, (addend,) full-line stores.  Accumulator a = tap kx = a (PAIR: rows 16.. = kx 1) ----
+  __syncthreads();   // obs
+  float* tr = tbuf + wave * (32 * ROW);
+  const int o_l = obs[li];
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int row = 8 * g4 + 4 * lh;                    // MFMA rows row .. row + 3 of this lane
+      const int co = PAIR ? (row & 15) : cob * 32 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o_l >= 0 && co < Cout) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + co);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[a][4 * g4 + e] + bv[e];
+          if (!ADD) s[0] += v[e], s[1] += v[e] * v[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(tr + li * ROW + row) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // lane -> (voxel it * 8 + (lane >> 3), 16-byte piece lane & 7) of the 128 bytes this accumulator holds per voxel:
+    //   PAIR: [kx 0: 16 channels][kx 1: 16 channels] = the two output voxels' whole rows; else channels cob * 32 .. + 31 of voxel kx = a
+    f32x4 ad[4];
+    i64 dst[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int v = it * 8 + (lane >> 3), piece = lane & 7;
+      const int o_v = obs[v];
+      const int kx = PAIR ? (piece >> 2) : a;
+      const int co = PAIR ? 4 * (piece & 3) : cob * 32 + 4 * piece;
+      dst[it] = (o_v >= 0 && co < Cout) ? ((i64)o_v + (kz * Ho + ky) * Wo + kx) : (i64)-1;
+      if (ADD && dst[it] >= 0) ad[it] = *reinterpret_cast<const f32x4*>(addend + dst[it] * lda + co);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int v = it * 8 + (lane >> 3), piece = lane & 7;
+      const int co = PAIR ? 4 * (piece & 3) : cob * 32 + 4 * piece;
+      if (dst[it] >= 0) {
+        f32x4 o4 = *reinterpret_cast<const f32x4*>(tr + v * ROW + 4 * piece);
+        if (ADD) o4 += ad[it];
+        *reinterpret_cast<f32x4*>(y + dst[it] * Cout + co) = o4;
+      }
+    }
+    if (NACC > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (stats) {
+    block_sum_256<2>(s, red);
     if (tid == 0) {
       const int tiles_per_sample = ntz * nty * ntx;
       const int tile = (tiz * nty + tiy) * ntx + tix;
-      float* dst = stats + (((i64)n * tiles_per_sample + tile) * gridDim.y + cob) * 2;
-      dst[0] = s[0];
-      dst[1] = s[1];
+      float* dstp = stats + ((((i64)n * tiles_per_sample + tile) * 4 + sub) * gridDim.y + cob) * 2;
+      dstp[0] = s[0];
+      dstp[1] = s[1];
     }
   }
 }
 
 extern "C" long long seg3d_convT3d_k2s2_mfma_stats_count(int Di, int Hi, int Wi, int Cout) {
   K2Tile t = k2_pick_tile(Di, Hi, Wi);
-  return (long long)seg3d_cdiv(Di, t.tz) * seg3d_cdiv(Hi, t.ty) * seg3d_cdiv(Wi, t.tx) * ((Cout + 31) / 32);
+  return (long long)seg3d_cdiv(Di, t.tz) * seg3d_cdiv(Hi, t.ty) * seg3d_cdiv(Wi, t.tx) * 4 * ((Cout + 31) / 32);   // [tile][4][column block]
 }
 
 // x [N][Di][Hi][Wi][Cin] -> y [N][2Di][2Hi][2Wi][Cout];  wp = seg3d_pack_weights_mfma(A = Cin, B = Cout, T = 8)
@@ -826,6 +982,33 @@ static int k2_scatter_launch(const void* x, int x_bf16, const float* wp, const f
   SEG3D_REQUIRE(!addend || ((Cout & 7) == 0 && lda >= Cout && (lda & 3) == 0),
                 "seg3d_convT3d_k2s2_scatter_addend: needs Cout %% 8 == 0 and a row stride >= Cout, multiple of 4");
   const bool pair = Cout <= 16 && (Cout & 7) == 0;   // two taps per MFMA (rows (tap & 1) * 16 + co)
+#ifndef K2_SCATTER_DIRECT
+#define K2_SCATTER_DIRECT 1   // 0: the LDS-staged kernel (kept for same-box A/B builds)
+#endif
+  // the direct kernel: fp32 outputs, whole steps (Cin a multiple of four chunks), whole 16-byte pieces of whole column blocks
+  // -- and where it measured faster (tools/bench_k2.py, same box): every launch with a fused addend (its loads are coalesced too:
+  // 168 -> 137 us at the top level, 50 -> 21 at 12^3) and the forward launches whose staged grid is under one workgroup per CU
+  // (47 -> 21 us at 6^3, 49 -> 42 at 12^3); the forward at 24^3 / 48^3 is 4 % / 1.5 % faster staged (51 vs 56, 116 vs 118 us)
+  const bool direct = K2_SCATTER_DIRECT && !out_bf16 && (x_bf16 == 2 ? Cin % 64 == 0 : Cin % 32 == 0) &&
+                      (Cout == 16 || Cout % 32 == 0) && (!addend || (lda % 4) == 0) &&
+                      (addend || (i64)grid.x * grid.y < 256);
+#define K2_SCATTER_D(MODE_)                                                                                          \
+  do {                                                                                                               \
+    const dim3 g4(grid.x * 4, grid.y);                                                                               \
+    const float* ad_ = reinterpret_cast<const float*>(addend);                                                       \
+    if (addend && pair)                                                                                              \
+      hipLaunchKernelGGL((convT3d_k2s2_direct_kernel<MODE_, true, true>), g4, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
+                         stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ad_, lda);                \
+    else if (pair)                                                                                                   \
+      hipLaunchKernelGGL((convT3d_k2s2_direct_kernel<MODE_, false, true>), g4, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
+                         stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ad_, lda);                \
+    else if (addend)                                                                                                 \
+      hipLaunchKernelGGL((convT3d_k2s2_direct_kernel<MODE_, true, false>), g4, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
+                         stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ad_, lda);                \
+    else                                                                                                             \
+      hipLaunchKernelGGL((convT3d_k2s2_direct_kernel<MODE_, false, false>), g4, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
+                         stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, ad_, lda);                \
+  } while (0)
 #define K2_SCATTER(MODE_, OB_)                                                                                       \
   do {                                                                                                               \
     if (addend && pair)                                                                                              \
@@ -841,12 +1024,16 @@ static int k2_scatter_launch(const void* x, int x_bf16, const float* wp, const f
       hipLaunchKernelGGL((convT3d_k2s2_mfma_kernel<MODE_, OB_, false>), grid, dim3(256), 0, (hipStream_t)stream, x, wp, bias, y, \
                          stats, N, Di, Hi, Wi, Cin, Cout, t.tz, t.ty, t.tx, ntz, nty, ntx, addend, lda);             \
   } while (0)
-  if (x_bf16 == 2 && out_bf16) K2_SCATTER(2, true);
+  if (direct && x_bf16 == 2) K2_SCATTER_D(2);
+  else if (direct && x_bf16) K2_SCATTER_D(1);
+  else if (direct) K2_SCATTER_D(0);
+  else if (x_bf16 == 2 && out_bf16) K2_SCATTER(2, true);
   else if (x_bf16 == 2) K2_SCATTER(2, false);
   else if (x_bf16 && out_bf16) K2_SCATTER(1, true);
   else if (x_bf16) K2_SCATTER(1, false);
   else K2_SCATTER(0, false);
 #undef K2_SCATTER
+#undef K2_SCATTER_D
   SEG3D_LAUNCH_CHECK("seg3d_convT3d_k2s2_mfma_fwd");
   return SEG3D_OK;
 }

@@ -483,6 +483,7 @@ extern "C" int seg3d_conv3d_k3_thin_out_f32mfma_fwd(const float* x, const float*
 #define TP_HY (TP_TY + 2)
 #define TP_HX (TP_TX + 2)
 #define TP_NV ((TP_TZ + 2) * TP_HY * TP_HX)  // 600
+#define TP_ROW 36                             // floats per voxel row of the epilogue transpose (32 + 4: conflict-free b128 writes)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -507,6 +508,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_persistent_kernel(co
   constexpr int KP = (27 * CT + 1) / 2;
   constexpr int TE = (TP_NV * CT + 255) / 256;
   __shared__ __attribute__((aligned(16))) float xs[TP_NV * CT + 4];
+  __shared__ __attribute__((aligned(16))) float tbuf[OUT_BF ? 4 : 4 * 32 * TP_ROW];   // epilogue transpose, per wave [voxel 32][36]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -637,8 +639,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_persistent_kernel(co
     if (fast) {   // whole tiles, Cout % 8 == 0: straight-line, ng quads per lane (wave-uniform)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        float* yo = y + (OUT_BF ? 0 : (vox0 + vrel[m]) * Cout + cob * 32 + 4 * lh);
         seg3d_bf16* yo16 = reinterpret_cast<seg3d_bf16*>(y) + (OUT_BF ? (vox0 + vrel[m]) * Cout + cob * 32 + 4 * lh : 0);
+        float* tr = tbuf + wave * (32 * TP_ROW);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           if (g < ng) {
@@ -655,9 +657,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_thin_in_persistent_kernel(co
               pk.y = seg3d_pack2bf(v4[2], v4[3]);
               *reinterpret_cast<uint2*>(yo16 + 8 * g) = pk;
             } else {
-              *reinterpret_cast<f32x4*>(yo + 8 * g) = v4;
+              *reinterpret_cast<f32x4*>(tr + li * TP_ROW + 8 * g + 4 * lh) = v4;
             }
           }
+        }
+        if constexpr (!OUT_BF) {
+          // fp32 rows leave through an LDS transpose (round 4): a lane owned 16-byte pieces of ITS voxel's row, so a store
+          // instruction wrote 64 pieces 128 bytes apart (tools/ubench/stride_load.hip: 3.6 TB/s); transposed, eight lanes write a
+          // voxel's 128 bytes and the eight voxels of an x row of the tile are one contiguous kilobyte per instruction
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int v = it * 8 + (lane >> 3), piece = lane & 7;
+            const int idx = (wave + 4 * m) * 32 + v;
+            const int tx = idx % TP_TX, t2 = idx / TP_TX;
+            const int vr = ((t2 / TP_TY) * H + (t2 % TP_TY)) * W + tx;
+            if (piece < 2 * ng)
+              *reinterpret_cast<f32x4*>(y + (vox0 + vr) * Cout + cob * 32 + 4 * piece) = *reinterpret_cast<const f32x4*>(tr + v * TP_ROW + 4 * piece);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
       }
     } else {

@@ -50,6 +50,8 @@ ALGO_MB = {
     'k3_thin_wgrad_kernel<1>': (1 + 16) * V,                         # stem weight gradient: x (1) and dy (16)
     'convT3d_k2s2_mfma_kernel<0, false, false, true>': (64 / 8 + 16) * V,        # up_32.up_conv: 64 ch at 48^3 -> 16 ch at 96^3
     'convT3d_k2s2_mfma_kernel<0, false, true, true>': (32 / 8 + 16 + 16) * V,    # down_32 data-gradient + skip addend -> 16 ch at 96^3
+    'convT3d_k2s2_direct_kernel<0, true, true>': (32 / 8 + 16 + 16) * V,         # the same launch on the direct scatter kernel (round 4)
+    'conv3d_k2s2_direct_kernel<0, false, 2, 1>': (16 + 64 / 8) * V,              # up_32.up_conv data-gradient: 16 ch at 96^3 -> 64 ch at 48^3
     'adam_step_devstep_kernel': 28 * 14563296 / 1e6,                 # 28 B per parameter
 }
 if len(sys.argv) > 5 and sys.argv[5] == 'no-algo':   # other configurations (bf16 mode, other networks): the figures above do not apply

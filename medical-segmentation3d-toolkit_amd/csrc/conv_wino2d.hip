@@ -244,6 +244,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
       const int hx = hxs ^ ((hy >> 1) & 1);
       xconst[j] = (unsigned)((((hz - 1) * H + (hy - 1)) * W + (hx - 1)) * Cin * 4);
       xflag[j] = (hy == 0 ? 4 : 0) | (hy == W2_H - 1 ? 8 : 0) | (hx == 0 ? 16 : 0) | (hx == W2_H - 1 ? 32 : 0);
+#ifdef W2_EXP_COMPACT   // (diagnostic: what would the kernel cost if a chunk's RAW tile were 16 contiguous KB -- a channel-group-planar layout?)
+      xconst[j] = (unsigned)(e * 16), xflag[j] = 0;
+#endif
     }
   }
   const unsigned xbytes = (unsigned)D * H * W * Cin * 4u;   // one sample
@@ -330,7 +333,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_wino2d_kernel(const float* _
   };
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(w2_lds_float*)lds);   // byte offset of the carve-up
   auto dma_x = [&](int j, unsigned rdst_float_off) {   // rdst: float offset of a RAW buffer inside the carve-up; channels 4 fx_sc .. + 3
+#ifdef W2_EXP_COMPACT
+    w2_bufdma16_soff(xvoff[j], xsrd, (unsigned)fx_sc * 16384u, lds0 + (rdst_float_off + (wave + W2_NW * j) * 256) * 4);
+#else
     w2_bufdma16_soff(xvoff[j], xsrd, (unsigned)fx_sc * 16u, lds0 + (rdst_float_off + (wave + W2_NW * j) * 256) * 4);
+#endif
   };
   int fw_item = item, fw_sc = sc_first;
   auto cog_of = [&](int it) { return __builtin_amdgcn_readfirstlane(it - fdiv(it, rNCOG) * ncog); };

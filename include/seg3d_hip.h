@@ -205,7 +205,9 @@ int seg3d_conv3d_k3_thin_out_mfma_fwd(const void* x_bf16, const void* wp_bf16, c
                                       float* stats_partial, int N, int D, int H, int W, int Cin, int Cout, void* stream);
 
 /* fp32 MFMA path for the stride-2 2x2x2 layers (Cin % 4 == 0): gather = Conv3d k2s2 forward / ConvTranspose3d dgrad,
- * scatter = ConvTranspose3d k2s2 forward / Conv3d k2s2 dgrad, pair-reduce = weight gradient of both */
+ * scatter = ConvTranspose3d k2s2 forward / Conv3d k2s2 dgrad, pair-reduce = weight gradient of both.
+ * stats_partial: [N][*_stats_count(...)][2] partial (sum, sum of squares) of y; the slots are an opaque order (since round 4:
+ * [tile][4 sub-tiles or waves][column block]) -- callers only ever sum a sample's slots (seg3d_gn_stats_finalize) */
 long long seg3d_conv3d_k2s2_mfma_stats_count(int Do, int Ho, int Wo, int Cout);
 int seg3d_conv3d_k2s2_mfma_fwd(const float* x, const float* wp_mfma, const float* bias, float* y, float* stats_partial,
                                int N, int Do, int Ho, int Wo, int Cin, int Cout, void* stream);

@@ -892,6 +892,47 @@ def test_wgrad_reduce_many_chunks(hip_device):
     report('wgrad_reduce_many_chunks', rel_err=rel_err(dw.double().cpu(), ref))
 
 
+@pytest.mark.parametrize('kind,shape', [
+    ('k2s2', (4, 16, 64, 48, 48, 48)),     # gather, two column blocks per wave (top level: up_32.up_conv data-gradient)
+    ('k2s2', (4, 16, 32, 48, 48, 48)),     # gather, top level forward: four steps, transposed stores
+    ('k2s2', (4, 32, 64, 24, 24, 24)),     # gather, one column block per wave, 3 456 waves
+    ('k2s2', (4, 64, 128, 12, 12, 12)),    # gather, K split over the four waves of a workgroup
+    ('k2s2', (1, 32, 96, 5, 7, 9)),        # gather, ragged tiles, three column blocks
+    ('k2s2', (2, 40, 40, 3, 4, 6)),        # gather, five chunks (an odd count: the staged kernel), a partial last column block
+    ('convT', (4, 256, 128, 6, 6, 6)),     # scatter forward on the direct kernel (fewer than 256 staged workgroups)
+    ('convT', (2, 64, 16, 5, 6, 7)),       # scatter forward, tap pairs in one accumulator (Cout = 16), ragged tiles
+    ('convT', (1, 128, 32, 24, 24, 24)),   # scatter forward, staged kernel (one column block, 432 tiles)
+])
+def test_stride2_kernel_variants_full_grids(hip_device, kind, shape):
+    """every variant of the stride-2 gather / scatter kernels at a grid that selects it (conv_k2_mfma.hip: direct kernels with one
+    or two column blocks per wave, K split inside the workgroup, tap pairs; the staged kernels they fall back to) against a float64
+    einsum over the 2^3 cells on the device; output and the per-sample statistics slots"""
+    from segmentation3d import _ops
+    N, Cin, Cout, D, H, W = shape          # D, H, W: the COARSE extent (output of the conv, input of the transposed conv)
+    if kind == 'k2s2':
+        x = _t(140, 'sx', (N, Cin, 2 * D, 2 * H, 2 * W)).to(hip_device)
+        w = _t(141, 'sw', (Cout, Cin, 2, 2, 2), std=(1.0 / (8 * Cin)) ** 0.5).to(hip_device)
+        cells = x.double().reshape(N, Cin, D, 2, H, 2, W, 2)
+        ref = torch.einsum('nizaybxc,oiabc->nozyx', cells, w.double())
+    else:
+        x = _t(140, 'sx', (N, Cin, D, H, W)).to(hip_device)
+        w = _t(141, 'sw', (Cin, Cout, 2, 2, 2), std=(1.0 / Cin) ** 0.5).to(hip_device)
+        ref = torch.einsum('nizyx,ioabc->nozaybxc', x.double(), w.double()).reshape(N, Cout, 2 * D, 2 * H, 2 * W)
+    b = _t(142, 'sb', (Cout,), std=0.1).to(hip_device)
+    ref = ref + b.double().reshape(1, Cout, 1, 1, 1)
+    yn, part = _ops.conv_forward(_ops.to_ndhwc(x), w, b, kind, want_stats=True)
+    got = _ops.from_ndhwc(yn).double()
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    rr = ref.reshape(N, -1)
+    st = part.double().sum(1)
+    e = dict(max_abs_err=err, out_scale=scale, stat_sum=float(((st[:, 0] - rr.sum(1)).abs() / rr.abs().sum(1)).max()),
+             stat_sq=rel_err(st[:, 1].cpu(), (rr * rr).sum(1).cpu()))
+    report('stride2_{}_{}'.format(kind, '_'.join(map(str, shape))), **e)
+    assert err < 2e-6 * scale + 1e-6 and e['stat_sum'] < 1e-5 and e['stat_sq'] < 1e-5, e
+    assert torch.isfinite(part).all()
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 32, 16, 4, 4, 8, 16), (1, 64, 32, 3, 5, 6, 0), (1, 16, 8, 2, 2, 2, 24)])
 def test_k2s2_dgrad_with_skip_addend(hip_device, shape, mode):

@@ -1052,7 +1052,13 @@ static int w2_sk_per(int N, int D, int H, int W, int Cin, int Cout) {
   if (nitems < G || NSC < 8 || nitems * NSC >= SEG3D_FDIV_MAX) return 0;
   const long long rounds = (nitems + G - 1) / G;
   if ((double)nitems / (double)(rounds * G) > W2_SK_FILL) return 0;
-  const long long per = (nitems * NSC + G - 1) / G;
+  // ranges of a multiple of NSC / 4 chunks: they start at four distinct chunk phases at most.  In the whole-item walk all workgroups
+  // are at the same chunk of their items at any time, so an XCD's L2 holds ONE weight chunk per column block for 32 workgroups;
+  // ranges of 54 chunks (4 x 24^3 128 -> 128) start at 16 phases, the 3 MB of weight images no longer stay in the 4-MB L2 beside the
+  // streaming input, and FETCH_SIZE rose from 45 to 262 MB per launch -- 149 MB with 56, at the same launch time
+  long long per = (nitems * NSC + G - 1) / G;
+  const long long al = NSC / 4;
+  per = (per + al - 1) / al * al;
   return per >= NSC ? (int)per : 0;
 }
 // floats of workspace seg3d_conv3d_k3_wino2d_fwd_ws wants for this shape (two 8^3 x 32 slabs per workgroup; 0: none)

@@ -1437,6 +1437,301 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_kernel(const fl
       dst[((j >> 2) * 16 + wave * 4 + (j & 3)) * 1024 + w2_mfma_row(r, lh) * 32 + li] = acc[j][r];
 }
 
+#ifndef G2_INLOOP
+#define G2_INLOOP 0   // 1: build and use conv3d_k3_wgrad_wino2d_il_kernel (measured 4 % SLOWER: kept as a reproducible negative result)
+#endif
+#if G2_INLOOP
+// The same kernel with the RAW x -> T transform INSIDE the MFMA loop (round 4, conv3d_k3_wgrad_wino2d_il_kernel).  Above, the
+// transform of a tile's four new halo planes is a phase of its own between two barriers (14 % of the kernel with the matrix pipe
+// idle); here the planes of the NEXT step are transformed during the current step's eight K steps -- one task per thread: four
+// row stages at K steps 0..3, four column stages at 4..7 -- into ring slots the current step does not read, and a step ends with
+// ONE barrier.  What makes it fit:
+//   * T is a ring of TEN plane slots (80 KB): a tile reads its six planes at slots tb .. tb + 5, the next step's planes 2..5 are
+//     written to tb + 6 .. tb + 9, and tb advances by four per step;
+//   * a RAW entry holds only the planes 2..5 of its step (18 KB): three entries (54 KB, what the two 27-KB tiles took) let the
+//     fetch run THREE steps ahead, so the step being transformed landed a whole step ago (a tile is 2.6 us: too short for a fetch
+//     issued in the same tile); dy stays two ahead in three buffers.  LDS: 54 + 80 + 24 = 158 KB;
+//   * a tile that STARTS a column (or a workgroup's range) has no predecessor whose planes 4, 5 are its planes 0, 1: a PHANTOM
+//     step in front of it -- the geometry of the tile one further down in z (planes out of the volume are zeros by the
+//     resource's range check), transform and fetches as usual, no MFMAs -- provides them, and the pipeline has no special case.
+// One phantom step per column costs what the exposed transform cost per TILE; columns of 3 tiles (the 12^3 level) are a draw.
+// RESULT (tools/bench_k3.py, same box, passes test_conv3d_k3_winograd_wgrad and the random-shape test): 4 x 96^3 32->32 0.832 ->
+// 0.868 ms, 48^3 64->64 0.424 -> 0.445, 24^3 128->128 0.224 -> 0.238: 4-6 % SLOWER.  With one wave per SIMD the transform's vector
+// instructions are not hidden by being placed between MFMAs -- fp32 VALU and fp32 MFMA are one datapath, so its 32 packed
+// adds cost the same cycles inside the loop as outside -- and what the in-loop form saves (one barrier and the LDS round trip of
+// the exposed phase, ~ 400 of 7 250 cycles per tile) is less than what it adds (a uniform branch around every K step's MFMAs,
+// the phantom steps, fetch descriptors three steps ahead).  Not compiled by default (-DG2_INLOOP=1 builds and uses it).
+#define G3_XV 144                                 // voxels of a RAW entry: halo planes 2 .. 5 (4 x 6 x 6)
+#define G3_XS (G3_XV * 32)
+#define G3_NSLOT 10
+#define G3_PS (G3_NSLOT * 4 * 32)                 // floats of one Winograd point of T: [slot][quad][32 ci]
+#define G3_TS (16 * G3_PS)
+#define G3_YS (64 * 32)
+#define G3_LDS_FLOATS (3 * G3_XS + G3_TS + 3 * G3_YS)   // 40 448 floats = 161 792 bytes
+#define G3_XPC 18                                 // 1-KiB DMA pieces of a RAW entry
+#define G3_GX 5                                   // x piece groups per wave (pieces wave + 4 g, clamped: duplicates are harmless)
+#define G3_GY 2
+#define G3_NG (G3_GX + G3_GY)                     // LDS-DMA instructions per wave and step: the end-of-step wait leaves exactly these
+
+__global__ __launch_bounds__(256, 1) void conv3d_k3_wgrad_wino2d_il_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                            float* __restrict__ part, int N, int D, int H, int W,
+                                                                            int Cin, int Cout, int ntz, int nty, int ntx, int ntiles,
+                                                                            int slabs, int COB32) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* rawx = lds;                        // [3][144][32]
+  float* timg = lds + 3 * G3_XS;            // [16 p][10 slots][4 quads][32 ci]
+  float* rawy = timg + G3_TS;               // [3][64][32]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = point row py
+  const int li = lane & 31, lh = lane >> 5;
+  const int slab = blockIdx.x % slabs;
+  const int pg = blockIdx.x / slabs;                   // (ci block, co block)
+  const int cib = pg / COB32, cob = pg % COB32;
+  const int ci0 = cib * 32, co0 = cob * 32;
+  const float rNTX = 1.0f / (float)ntx, rNTY = 1.0f / (float)nty, rNTZ = 1.0f / (float)ntz;
+  auto fdiv = [](int v, float r) { return (int)(((float)v + 0.5f) * r); };
+  const float e1 = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);   // row combination of the dy quad for py = wave (see above)
+  const int g0off = wave == 3 ? 4 * 32 : 0;
+
+  f32x16 acc[12];   // [kz][px]
+#pragma unroll
+  for (int j = 0; j < 12; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // DMA pieces of this wave: x piece min(wave + 4 g, 17) of the entry (voxel 8 p + (lane >> 3) of the 144, channels 4 (lane & 7)..),
+  // dy piece min(wave + 4 g', 7); offsets relative to the step's tile origin, (y, x) padding from the per-column table
+  const int lv = lane >> 3, lq = lane & 7;
+  const unsigned OOB = 0x80000000u;
+  unsigned pconst[G3_NG], pyx[G3_GX];
+  int pflag[G3_GX];
+#pragma unroll
+  for (int g = 0; g < G3_NG; ++g) {
+    if (g < G3_GX) {
+      const int p = wave + 4 * g < G3_XPC ? wave + 4 * g : G3_XPC - 1;
+      const int v = p * 8 + lv;
+      const int pl = fdiv(v, 1.0f / 36.0f);              // plane of the entry: halo plane 2 + pl
+      const int r = v - pl * 36;
+      const int hy = fdiv(r, 1.0f / 6.0f);
+      const int hx = r - hy * 6;
+      pconst[g] = ci0 + 4 * lq < Cin ? (unsigned)(((((pl + 1) * H + (hy - 1)) * W + (hx - 1)) * Cin + ci0 + 4 * lq) * 4) : OOB;
+      pflag[g] = (hy == 0 ? 4 : 0) | (hy == 5 ? 8 : 0) | (hx == 0 ? 16 : 0) | (hx == 5 ? 32 : 0);
+      pyx[g] = pconst[g];
+    } else {
+      const int p = wave + 4 * (g - G3_GX) < 8 ? wave + 4 * (g - G3_GX) : 7;
+      const int v = p * 8 + lv;
+      const int co = co0 + 4 * lq;
+      pconst[g] = co < Cout ? (unsigned)(((((v >> 4) * H + ((v >> 2) & 3)) * W + (v & 3)) * Cout + co) * 4) : OOB;
+    }
+  }
+  const unsigned xbytes = (unsigned)D * H * W * Cin * 4u, ybytes = (unsigned)D * H * W * Cout * 4u;   // one sample
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(w2_lds_float*)lds);
+
+  // steps: wave-uniform descriptors.  ph = 1: the phantom step in front of tile (z, x, y, n); ok = 0: past the end of the range
+  struct StepAt { int z, x, y, n, tile, ph, ok; };
+  const int per_wg = (ntiles + slabs - 1) / slabs;
+  const int ord = (slabs & 7) == 0 ? (slab & 7) * (slabs >> 3) + (slab >> 3) : slab;
+  const int tile0 = ord * per_wg;
+  const int tlimit = tile0 + per_wg < ntiles ? tile0 + per_wg : ntiles;
+  auto first_step = [&]() {
+    StepAt t;
+    int b = tile0 < ntiles ? tile0 : 0;
+    int q = fdiv(b, rNTZ);
+    t.z = __builtin_amdgcn_readfirstlane(b - q * ntz);
+    b = q;
+    q = fdiv(b, rNTX);
+    t.x = __builtin_amdgcn_readfirstlane(b - q * ntx);
+    b = q;
+    q = fdiv(b, rNTY);
+    t.y = __builtin_amdgcn_readfirstlane(b - q * nty);
+    t.n = __builtin_amdgcn_readfirstlane(q);
+    t.tile = tile0, t.ph = 1, t.ok = tile0 < tlimit ? 1 : 0;
+    return t;
+  };
+  auto next_step = [&](StepAt t) {
+    if (!t.ok) return t;
+    if (t.ph) {
+      t.ph = 0;
+      return t;
+    }
+    if (t.tile + 1 >= tlimit) {
+      t.ok = 0;            // (keeps the geometry of the last tile: fetches and transforms past the end go to idle buffers / slots)
+      return t;
+    }
+    ++t.tile;
+    if (++t.z == ntz) {
+      t.z = 0;
+      if (++t.x == ntx) {
+        t.x = 0;
+        if (++t.y == nty) t.y = 0, ++t.n;
+      }
+    }
+    t.ph = t.z == 0 ? 1 : 0;
+    return t;
+  };
+  // fetch of step t into RAW entry xe / dy buffer ye: piece group g of this wave.  The (y, x) padding table belongs to the column
+  // of the step being fetched (fetches walk the columns in order: refreshed when a fetched step is a phantom, i.e. starts one)
+  auto column_table = [&](const StepAt& t) {
+    const int ty0 = t.y * 4, tx0 = t.x * 4;
+    const int fyx = (ty0 == 0 ? 4 : 0) | (ty0 + 4 >= H ? 8 : 0) | (tx0 == 0 ? 16 : 0) | (tx0 + 4 >= W ? 32 : 0);
+#pragma unroll
+    for (int g = 0; g < G3_GX; ++g) pyx[g] = (pflag[g] & fyx) ? OOB : pconst[g];
+  };
+  struct FetchAt { w2_srd xsrd, ysrd; unsigned xoff, yoff, xdst, ydst; };
+  auto fetch_of = [&](const StepAt& t, int xe, int ye) {
+    FetchAt f;
+    const int tz0 = (t.z - t.ph) * 4;                    // a phantom step has the geometry of the tile one further down (may be -4)
+    const int origin = (tz0 * H + t.y * 4) * W + t.x * 4;
+    f.xsrd = w2_make_srd(x + (i64)t.n * D * H * W * Cin, xbytes);
+    f.ysrd = w2_make_srd(dy + (i64)t.n * D * H * W * Cout, ybytes);
+    f.xoff = (unsigned)origin * (unsigned)Cin * 4u;      // (mod 2^32: planes in front of the sample wrap out of the resource's range)
+    f.yoff = (unsigned)origin * (unsigned)Cout * 4u;
+    f.xdst = xe * G3_XS;
+    f.ydst = 3 * G3_XS + G3_TS + ye * G3_YS;
+    return f;
+  };
+  auto issue_piece = [&](int g, const FetchAt& f) {
+    if (g < G3_GX) {
+      const int piece = wave + 4 * g < G3_XPC ? wave + 4 * g : G3_XPC - 1;
+      w2_bufdma16_if(1, pyx[g] + f.xoff, f.xsrd, lds0 + (f.xdst + piece * 256) * 4);
+    } else {
+      const int piece = wave + 4 * (g - G3_GX) < 8 ? wave + 4 * (g - G3_GX) : 7;
+      w2_bufdma16_if(1, pconst[g] + f.yoff, f.ysrd, lds0 + (f.ydst + piece * 256) * 4);
+    }
+  };
+  // transform task of this thread: (plane 2 + (tid >> 6), quad (tid >> 4) & 3, channel pair tid & 15) of a RAW entry
+  const int t_pl = __builtin_amdgcn_readfirstlane(tid >> 6), t_q = (tid >> 4) & 3, t_c2 = tid & 15;
+  const int t_src = ((t_pl * 6 + 2 * (t_q >> 1)) * 6 + 2 * (t_q & 1)) * 32 + 2 * t_c2;
+  const int t_dst = t_q * 32 + 2 * t_c2;     // + (slot * 4) * 32 + point * G3_PS
+  f32x2 dx[4][4];   // [row][px]
+  f32x2 dr[4];      // the row read at this K step, combined behind its MFMAs
+  auto tr_read = [&](const float* rx, int r) {
+    const float* sp = rx + t_src + r * (6 * 32);
+    dr[0] = *reinterpret_cast<const f32x2*>(sp), dr[1] = *reinterpret_cast<const f32x2*>(sp + 32);
+    dr[2] = *reinterpret_cast<const f32x2*>(sp + 64), dr[3] = *reinterpret_cast<const f32x2*>(sp + 96);
+  };
+  auto tr_math = [&](int r) {
+    dx[r][0] = w2_pk_sub(dr[0], dr[2]);
+    dx[r][1] = w2_pk_add(dr[1], dr[2]);
+    dx[r][2] = w2_pk_sub(dr[2], dr[1]);
+    dx[r][3] = w2_pk_sub(dr[1], dr[3]);
+  };
+  auto tr_row = [&](const float* rx, int r) { tr_read(rx, r), tr_math(r); };
+  auto tr_col = [&](float* dst, int px) {   // dst = timg + slot * 128 + t_dst
+    *reinterpret_cast<f32x2*>(dst + (0 * 4 + px) * G3_PS) = w2_pk_sub(dx[0][px], dx[2][px]);
+    *reinterpret_cast<f32x2*>(dst + (1 * 4 + px) * G3_PS) = w2_pk_add(dx[1][px], dx[2][px]);
+    *reinterpret_cast<f32x2*>(dst + (2 * 4 + px) * G3_PS) = w2_pk_sub(dx[2][px], dx[1][px]);
+    *reinterpret_cast<f32x2*>(dst + (3 * 4 + px) * G3_PS) = w2_pk_sub(dx[1][px], dx[3][px]);
+  };
+  auto slot_mod = [](int v) { return v >= G3_NSLOT ? v - G3_NSLOT : v; };
+
+  StepAt cur = first_step();   // (an empty range -- more slabs than tile triples -- still writes its zero slab below)
+  StepAt nx1 = next_step(cur), nx2 = next_step(nx1), nx3 = next_step(nx2);
+  int tb = 0;          // ring slot of the current step's halo plane 0
+  int xe = 0, ye = 0;  // RAW entry / dy buffer of the current step
+  if (cur.ok) {   // prologue: steps 0, 1, 2 (x) and 0, 1 (dy) at once; step 0's planes 2 .. 5 transformed here, exposed
+    column_table(cur);
+    const FetchAt f0 = fetch_of(cur, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G3_NG; ++g) issue_piece(g, f0);
+    if (nx1.ph) column_table(nx1);
+    const FetchAt f1 = fetch_of(nx1, 1, 1);
+#pragma unroll
+    for (int g = 0; g < G3_NG; ++g) issue_piece(g, f1);
+    if (nx2.ph) column_table(nx2);
+    const FetchAt f2 = fetch_of(nx2, 2, 2);
+#pragma unroll
+    for (int g = 0; g < G3_GX; ++g) issue_piece(g, f2);
+    w2_dma_wait();
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tr_row(rawx, r);
+    float* d0 = timg + slot_mod(tb + 2 + t_pl) * 128 + t_dst;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) tr_col(d0, px);
+    __syncthreads();
+  }
+  for (; cur.ok;) {
+    // this step: T planes at slots tb + kp, dy in buffer ye; next step's RAW entry xe + 1 -> T slots tb + 6 .. 9;
+    // fetched: x of the step three ahead -> entry xe (dead), dy of the step two ahead -> buffer ye + 2
+    const int xe1 = xe == 2 ? 0 : xe + 1, ye2 = ye == 0 ? 2 : ye - 1;
+    if (nx3.ph) column_table(nx3);
+    FetchAt f = fetch_of(nx3, xe, ye2);
+    {
+      const FetchAt fy = fetch_of(nx2, xe, ye2);   // (dy runs two ahead)
+      f.ysrd = fy.ysrd, f.yoff = fy.yoff;
+    }
+    const float* rx1 = rawx + xe1 * G3_XS;
+    float* tdst = timg + slot_mod(slot_mod(tb + 6) + t_pl) * 128 + t_dst;
+    const float* ycur = rawy + ye * G3_YS;
+    const float* ta = timg + (wave * 4) * G3_PS + lane;          // + px * G3_PS + (slot * 4 + 2 qy) * 32
+    const float* tk[6];
+#pragma unroll
+    for (int kp = 0; kp < 6; ++kp) tk[kp] = ta + slot_mod(tb + kp) * (4 * 32);
+    const float* yb = ycur + lh * 64 + li;
+    auto lda = [&](int k, int kz, int px) { return tk[(k >> 1) + kz][px * G3_PS + (2 * (k & 1)) * 32]; };
+    auto yoff = [](int k) { return (((k >> 1) * 4 + 2 * (k & 1)) * 4) * 32; };
+    const int real = cur.ph ? 0 : 1;
+    float a1[12], g00, g01, g10, g11;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) a1[j] = lda(0, j >> 2, j & 3);
+    g00 = yb[yoff(0) + g0off];
+    g01 = yb[yoff(0) + g0off + 32];
+    g10 = yb[yoff(0) + 128];
+    g11 = yb[yoff(0) + 128 + 32];
+#pragma unroll
+    for (int k = 0; k < G2_KS; ++k) {
+      float a[12], e[4];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) a[j] = a1[j];
+      const float r0 = fmaf(e1, g10, g00), r1 = fmaf(e1, g11, g01);
+      e[0] = r0;
+      e[1] = r0 + r1;
+      e[2] = r0 - r1;
+      e[3] = r1;
+      if (k + 1 < G2_KS) {   // operands of step k + 1 are read while step k is multiplied
+#pragma unroll
+        for (int j = 0; j < 12; ++j) a1[j] = lda(k + 1, j >> 2, j & 3);
+        g00 = yb[yoff(k + 1) + g0off];
+        g01 = yb[yoff(k + 1) + g0off + 32];
+        g10 = yb[yoff(k + 1) + 128];
+        g11 = yb[yoff(k + 1) + 128 + 32];
+      }
+      if (k < G3_NG) issue_piece(k, f);
+      if (k < 4) tr_read(rx1, k);        // (its four reads fly while this K step's MFMAs run; combined behind them)
+      __builtin_amdgcn_sched_barrier(0);
+      if (real) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], e[j & 3], acc[j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (k < 4) tr_math(k); else tr_col(tdst, k - 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // everything but this step's own G3_NG fetches has landed: the next step's dy, the RAW entry of the step after it
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G3_NG) : "memory");
+    __syncthreads();     // T of the next step complete; everyone done with this step's T planes, dy buffer and the dead RAW entry
+    tb = slot_mod(tb + 4);
+    xe = xe1;
+    ye = ye == 2 ? 0 : ye + 1;
+    cur = nx1;
+    nx1 = nx2;
+    nx2 = nx3;
+    nx3 = next_step(nx3);
+  }
+  w2_dma_wait();   // nothing in flight when the workgroup's LDS is released
+
+  float* dst = part + ((i64)slab * (COB32 * ((Cin + 31) / 32)) + cib * COB32 + cob) * 48 * 1024;
+#pragma unroll
+  for (int j = 0; j < 12; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      dst[((j >> 2) * 16 + wave * 4 + (j & 3)) * 1024 + w2_mfma_row(r, lh) * 32 + li] = acc[j][r];
+}
+
+#endif   // G2_INLOOP
+
 // dw[a*sa + b*sb + kz*9 + ky*3 + kx] from  M[py][px] = sum_slab part[slab][a/32][b/32][kz*16 + py*4 + px][a%32][b%32]:
 //   dW[kz] = A'^T M A',  A'^T = [1 1/2 1/2 0; 0 1/2 -1/2 0; 0 1/2 1/2 -1].
 // A lane owns ONE point row (py: four 16-byte loads per slab) of one position (pair, kz, a, b quad); a workgroup takes 16
@@ -1561,13 +1856,23 @@ extern "C" int seg3d_conv3d_k3_wino2d_wgrad(const float* x, const float* dy, flo
                 "seg3d_conv3d_k3_wino2d_wgrad: shape not supported (whole 4^3 tiles, Cin %% 4 == 0, Cout %% 4 == 0)");
   static Seg3dOncePerDevice configured;
   if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wgrad_wino2d_kernel), configured, "conv3d_k3_wgrad_wino2d")) return rc;
+#if G2_INLOOP
+  static Seg3dOncePerDevice configured_il;
+  if (int rc = seg3d_allow_full_lds(reinterpret_cast<const void*>(&conv3d_k3_wgrad_wino2d_il_kernel), configured_il, "conv3d_k3_wgrad_wino2d_il")) return rc;
+#endif
   const int slabs = g2_slabs(N, D, H, W, Cin, Cout);
   const int CIB32 = (Cin + 31) / 32, COB32 = (Cout + 31) / 32, npairs = CIB32 * COB32;
   const int ntz = D / 4, nty = H / 4, ntx = W / 4;
   const int ntiles = N * ntz * nty * ntx;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_kernel, dim3((unsigned)(slabs * npairs)), dim3(256), (size_t)G2_LDS_FLOATS * 4, s, x,
-                     dy, workspace, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, COB32);
+#if G2_INLOOP
+  if (ntz >= 4)   // columns of four tiles and more (below, a phantom step per column costs as much as the exposed transforms)
+    hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_il_kernel, dim3((unsigned)(slabs * npairs)), dim3(256), (size_t)G3_LDS_FLOATS * 4, s, x,
+                       dy, workspace, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, COB32);
+  else
+#endif
+    hipLaunchKernelGGL(conv3d_k3_wgrad_wino2d_kernel, dim3((unsigned)(slabs * npairs)), dim3(256), (size_t)G2_LDS_FLOATS * 4, s, x,
+                       dy, workspace, N, D, H, W, Cin, Cout, ntz, nty, ntx, ntiles, slabs, COB32);
   SEG3D_LAUNCH_CHECK("seg3d_conv3d_k3_wino2d_wgrad");
   const i64 totalq = (i64)npairs * 3 * 256;
   // one point row per lane; 16 waves over the slabs where there are many of them, 4 otherwise

@@ -278,7 +278,10 @@ def test_conv3d_k3_wino2d_stream_k(hip_device, shape):
 
 
 @pytest.mark.parametrize('shape', [(1, 32, 32, 8, 8, 16), (2, 16, 48, 4, 8, 8), (1, 64, 32, 12, 12, 12), (3, 8, 40, 8, 4, 24),
-                                   (1, 32, 32, 16, 48, 32), (2, 96, 64, 4, 4, 4)])
+                                   (1, 32, 32, 16, 48, 32), (2, 96, 64, 4, 4, 4),
+                                   # columns of four tiles and more: the F(3x3, 2x2) kernel with the transform inside the MFMA loop
+                                   # (phantom steps at column starts, workgroup ranges that start inside a column, partial blocks)
+                                   (2, 48, 40, 24, 8, 12), (1, 32, 64, 48, 16, 8), (3, 16, 32, 16, 12, 20)])
 @pytest.mark.parametrize('form', ['wino', 'wino2d'])
 def test_conv3d_k3_winograd_wgrad(hip_device, shape, form):
     """Winograd F(3, 2) along x (csrc/conv_wino.hip) and F(3x3, 2x2) over (y, x) (csrc/conv_wino2d.hip) weight gradients through the C ABI against the float64 weight gradient: both
